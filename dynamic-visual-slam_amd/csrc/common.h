@@ -1,0 +1,56 @@
+// common.h — error plumbing shared by the C-ABI translation units of libdvslam_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dvslam_hip.h"
+
+namespace dvs {
+
+void set_error(const char* fmt, ...);  // util.hip
+dvs_status check_device(int device);   // selects the device; DVS_ERR_NO_DEVICE if none / not gfx950
+
+#define DVS_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      dvs::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return DVS_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+#define DVS_TRY(call)                \
+  do {                               \
+    dvs_status s_ = (call);          \
+    if (s_ != DVS_OK) return s_;     \
+  } while (0)
+
+#define DVS_ARG(cond)                                                            \
+  do {                                                                           \
+    if (!(cond)) {                                                               \
+      dvs::set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond);      \
+      return DVS_ERR_ARG;                                                        \
+    }                                                                            \
+  } while (0)
+
+// stage timer: pairs of hipEvents recorded on the handle's stream, resolved lazily
+struct StageTimer {
+  static const int kMaxPending = 4096;
+  struct Pending { hipEvent_t a, b; int stage; };
+  Pending pending[kMaxPending];
+  int npending = 0;
+  double ms[16] = {0};
+  int64_t calls[16] = {0};
+  bool on = false;
+  void begin(int stage, hipStream_t s);
+  void end(hipStream_t s);
+  void resolve();
+  void reset();
+  ~StageTimer();
+ private:
+  hipEvent_t pool[2 * kMaxPending];
+  int npool = 0, cur = -1;
+};
+
+}  // namespace dvs

@@ -1,0 +1,157 @@
+// lsort.h — operation-for-operation replica of libstdc++'s std::sort (GCC 4.x..14: introsort with
+// median-of-3 pivot, _S_threshold = 16, heapsort fallback at depth 2*floor(lg n), final insertion
+// sort).  The reference sorts its quad-tree expansion candidates with std::sort and an order that
+// has ties (ORBextractor.cpp:538-553, 700), so WHICH permutation comes out is part of the result.
+// This header is compiled for host and device; tests/test_host_logic.py checks it against the real
+// std::sort on adversarial tie-heavy inputs.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define LSORT_HD __host__ __device__ __forceinline__
+#else
+#define LSORT_HD inline
+#endif
+
+namespace lsort {
+
+// element = 64-bit word; ordering = less(a, b) on (a >> SHIFT): payload bits below SHIFT are ignored.
+template <int SHIFT>
+struct Less {
+  LSORT_HD bool operator()(uint64_t a, uint64_t b) const { return (a >> SHIFT) < (b >> SHIFT); }
+};
+
+template <class T>
+LSORT_HD void swp(T* a, T* b) { T t = *a; *a = *b; *b = t; }
+
+template <class T, class C>
+LSORT_HD void unguarded_linear_insert(T* last, C comp) {
+  T val = *last;
+  T* next = last - 1;
+  while (comp(val, *next)) { *last = *next; last = next; --next; }
+  *last = val;
+}
+
+template <class T, class C>
+LSORT_HD void insertion_sort(T* first, T* last, C comp) {
+  if (first == last) return;
+  for (T* i = first + 1; i != last; ++i) {
+    if (comp(*i, *first)) {
+      T val = *i;
+      for (T* p = i; p != first; --p) *p = *(p - 1);  // move_backward(first, i, i + 1)
+      *first = val;
+    } else {
+      unguarded_linear_insert(i, comp);
+    }
+  }
+}
+
+template <class T, class C>
+LSORT_HD void push_heap_(T* first, long holeIndex, long topIndex, T value, C comp) {
+  long parent = (holeIndex - 1) / 2;
+  while (holeIndex > topIndex && comp(first[parent], value)) {
+    first[holeIndex] = first[parent];
+    holeIndex = parent;
+    parent = (holeIndex - 1) / 2;
+  }
+  first[holeIndex] = value;
+}
+
+template <class T, class C>
+LSORT_HD void adjust_heap(T* first, long holeIndex, long len, T value, C comp) {
+  const long topIndex = holeIndex;
+  long secondChild = holeIndex;
+  while (secondChild < (len - 1) / 2) {
+    secondChild = 2 * (secondChild + 1);
+    if (comp(first[secondChild], first[secondChild - 1])) secondChild--;
+    first[holeIndex] = first[secondChild];
+    holeIndex = secondChild;
+  }
+  if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+    secondChild = 2 * (secondChild + 1);
+    first[holeIndex] = first[secondChild - 1];
+    holeIndex = secondChild - 1;
+  }
+  push_heap_(first, holeIndex, topIndex, value, comp);
+}
+
+template <class T, class C>
+LSORT_HD void heap_sort_all(T* first, T* last, C comp) {  // __partial_sort(first, last, last)
+  long len = last - first;
+  if (len >= 2) {  // __make_heap
+    long parent = (len - 2) / 2;
+    while (true) {
+      T value = first[parent];
+      adjust_heap(first, parent, len, value, comp);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {  // __sort_heap / __pop_heap
+    --last;
+    T value = *last;
+    *last = *first;
+    adjust_heap(first, 0L, (long)(last - first), value, comp);
+  }
+}
+
+template <class T, class C>
+LSORT_HD void move_median_to_first(T* result, T* a, T* b, T* c, C comp) {
+  if (comp(*a, *b)) {
+    if (comp(*b, *c)) swp(result, b);
+    else if (comp(*a, *c)) swp(result, c);
+    else swp(result, a);
+  } else if (comp(*a, *c)) swp(result, a);
+  else if (comp(*b, *c)) swp(result, c);
+  else swp(result, b);
+}
+
+template <class T, class C>
+LSORT_HD T* unguarded_partition(T* first, T* last, T* pivot, C comp) {
+  while (true) {
+    while (comp(*first, *pivot)) ++first;
+    --last;
+    while (comp(*pivot, *last)) --last;
+    if (!(first < last)) return first;
+    swp(first, last);
+    ++first;
+  }
+}
+
+// std::sort(first, first + n, comp).  Recursion of __introsort_loop is unrolled with an explicit
+// stack of (first, last, depth) — the right part is pushed, the left part continues, exactly the
+// order in which libstdc++ recurses (right half first via recursion, then loops on the left).
+// NOTE the libstdc++ code recurses into [cut, last) BEFORE continuing with [first, cut); since the
+// two ranges are disjoint the visiting order does not change the result, only the stack shape.
+template <class T, class C>
+LSORT_HD void sort(T* first, long n, C comp) {
+  if (n <= 0) return;
+  T* last = first + n;
+  int lg = 0;
+  for (long m = n; m > 1; m >>= 1) lg++;
+  struct Frame { T* f; T* l; int d; };
+  Frame stack[64];
+  int sp = 0;
+  stack[sp++] = Frame{first, last, lg * 2};
+  while (sp > 0) {
+    Frame fr = stack[--sp];
+    T* f = fr.f; T* l = fr.l; int depth = fr.d;
+    while (l - f > 16) {
+      if (depth == 0) { heap_sort_all(f, l, comp); break; }
+      --depth;
+      T* mid = f + (l - f) / 2;
+      move_median_to_first(f, f + 1, mid, l - 1, comp);
+      T* cut = unguarded_partition(f + 1, l, f, comp);
+      stack[sp++] = Frame{cut, l, depth};
+      l = cut;
+    }
+  }
+  if (n > 16) {  // __final_insertion_sort
+    insertion_sort(first, first + 16, comp);
+    for (T* i = first + 16; i != last; ++i) unguarded_linear_insert(i, comp);
+  } else {
+    insertion_sort(first, last, comp);
+  }
+}
+
+}  // namespace lsort

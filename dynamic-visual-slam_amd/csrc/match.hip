@@ -1,0 +1,237 @@
+// match.hip — brute-force Hamming matcher (boundary B2, include/dvslam_hip.h).
+// Replaces cv::BFMatcher(cv::NORM_HAMMING[, false]).match(query, train, matches) at the reference's
+// call sites src/frontend.cpp:614, src/frontend.cpp:1123, src/backend.cpp:1072 (ctor frontend.cpp:220,
+// backend.cpp:222).  Semantics (OpenCV batchDistance, K = 1): per query the minimum popcount(q XOR t)
+// over train rows scanned in increasing index with a strict '<' update, i.e. lowest index on ties.
+//
+// Kernel shape: workgroup = 64 queries x 4 train quarters.  Each lane keeps its 256-bit query in 4
+// VGPR pairs; the train row index is wave-uniform, so the compiler fetches it with scalar loads and
+// the inner loop is 4 x (v_xor, v_bcnt) per pair.  The 4 waves scan disjoint, ordered quarters of the
+// train set and merge through LDS in quarter order (keeps the lowest-index tie-break exact).
+#include <limits.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "common.h"
+
+namespace dvs {
+
+typedef unsigned long long u64;
+
+__global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
+                                               const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
+                                               int* __restrict__ outIdx, int* __restrict__ outDist) {
+  __shared__ int sd[4][64];
+  __shared__ int si[4][64];
+  const int pair = blockIdx.y;
+  const int nq = nqArr ? nqArr[pair] : nqConst;
+  const int nt = ntArr ? ntArr[pair] : ntConst;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= nq) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = q0 + lane;
+  const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
+  const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  const int chunk = (nt + 3) >> 2;
+  const int jb = w * chunk, je = min(nt, jb + chunk);
+  const u64* tp = t + (size_t)pair * tStrideRows * 4;
+  int best = INT_MAX, bi = -1;
+  for (int j = jb; j < je; j++) {
+    const u64* r = tp + (size_t)j * 4;  // wave-uniform address -> s_load_dwordx8
+    const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
+    if (d < best) { best = d; bi = j; }
+  }
+  sd[w][lane] = best;
+  si[w][lane] = bi;
+  __syncthreads();
+  if (w == 0 && qi < nq) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const int d = sd[k][lane];
+      if (d < best) { best = d; bi = si[k][lane]; }
+    }
+    outIdx[(size_t)pair * qStrideRows + qi] = bi;
+    outDist[(size_t)pair * qStrideRows + qi] = best;
+  }
+}
+
+// threshold variant, pass 1: number of train rows with distance < maxDist per query
+__global__ __launch_bounds__(256) void k_thresh_count(const u64* __restrict__ q, int nq, const u64* __restrict__ t, int nt,
+                                                      int maxDist, int* __restrict__ counts) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  const u64* qp = q + (size_t)qi * 4;
+  const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  int c = 0;
+  for (int j = 0; j < nt; j++) {
+    const u64* r = t + (size_t)j * 4;
+    const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
+    c += d < maxDist ? 1 : 0;
+  }
+  counts[qi] = c;
+}
+// pass 2: write (q, t, dist) triplets at the query's exclusive offset (offsets computed between the passes)
+__global__ __launch_bounds__(256) void k_thresh_write(const u64* __restrict__ q, int nq, const u64* __restrict__ t, int nt,
+                                                      int maxDist, const long long* __restrict__ offs, int* __restrict__ pairs, long long cap) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  const u64* qp = q + (size_t)qi * 4;
+  const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  long long o = offs[qi];
+  for (int j = 0; j < nt; j++) {
+    const u64* r = t + (size_t)j * 4;
+    const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
+    if (d < maxDist) {
+      if (o < cap) { pairs[3 * o] = qi; pairs[3 * o + 1] = j; pairs[3 * o + 2] = d; }
+      o++;
+    }
+  }
+}
+// single-block exclusive scan of int counts into 64-bit offsets (+ total at offs[n])
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int n, long long* __restrict__ offs) {
+  __shared__ long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = tid * per, e = min(n, b + per);
+  long long s = 0;
+  for (int i = b; i < e; i++) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    long long run = 0;
+    for (int i = 0; i < 1024; i++) { long long v = part[i]; part[i] = run; run += v; }
+    offs[n] = run;
+  }
+  __syncthreads();
+  long long run = part[tid];
+  for (int i = b; i < e; i++) { offs[i] = run; run += counts[i]; }
+}
+
+}  // namespace dvs
+
+using namespace dvs;
+
+struct dvs_matcher {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // grow-only staging for the host entry points
+  void *d_q = nullptr, *d_t = nullptr, *d_idx = nullptr, *d_dist = nullptr, *d_counts = nullptr, *d_offs = nullptr, *d_pairs = nullptr;
+  size_t cq = 0, ct = 0, cidx = 0, ccounts = 0, cpairs = 0;
+};
+
+namespace {
+dvs_status grow(void** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return DVS_OK;
+  if (*p) DVS_HIP(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  DVS_HIP(hipMalloc(p, need ? need : 1));
+  *cap = need;
+  return DVS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out) {
+  DVS_ARG(out);
+  *out = nullptr;
+  DVS_TRY(check_device(device));
+  dvs_matcher* m = new (std::nothrow) dvs_matcher();
+  if (!m) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  m->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete m; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
+  m->stream = m->own_stream;
+  *out = m;
+  return DVS_OK;
+}
+
+void dvs_matcher_destroy(dvs_matcher* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipStreamSynchronize(m->stream);
+  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete m;
+}
+
+dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* s) {
+  DVS_ARG(m);
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  m->stream = s ? (hipStream_t)s : m->own_stream;
+  return DVS_OK;
+}
+dvs_status dvs_matcher_synchronize(dvs_matcher* m) {
+  DVS_ARG(m);
+  DVS_HIP(hipSetDevice(m->device));
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  return DVS_OK;
+}
+
+dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, const int32_t* d_nq, int32_t q_stride_rows,
+                                          const uint8_t* d_t, const int32_t* d_nt, int32_t t_stride_rows, int32_t npairs,
+                                          int32_t* d_idx, int32_t* d_dist) {
+  DVS_ARG(m && d_q && d_t && d_nq && d_nt && d_idx && d_dist && npairs >= 0 && q_stride_rows > 0 && t_stride_rows >= 0);
+  if (npairs == 0) return DVS_OK;
+  DVS_HIP(hipSetDevice(m->device));
+  dim3 grid((q_stride_rows + 63) / 64, npairs);
+  hipLaunchKernelGGL(k_match, grid, dim3(256), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
+                     t_stride_rows, d_idx, d_dist);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* train_idx,
+                             int32_t* dist) {
+  DVS_ARG(m && nq >= 0 && nt >= 0);
+  if (nq == 0) return DVS_OK;  // empty query -> empty result
+  DVS_ARG(q && train_idx && dist && (t || nt == 0));
+  DVS_HIP(hipSetDevice(m->device));
+  DVS_TRY(grow(&m->d_q, &m->cq, (size_t)nq * 32));
+  DVS_TRY(grow(&m->d_t, &m->ct, (size_t)std::max(nt, 1) * 32));
+  DVS_TRY(grow(&m->d_idx, &m->cidx, (size_t)nq * 8));
+  int* d_idx = (int*)m->d_idx;
+  int* d_dist = d_idx + nq;
+  DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+  if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+  hipLaunchKernelGGL(k_match, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
+                     (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
+  DVS_HIP(hipGetLastError());
+  DVS_HIP(hipMemcpyAsync(train_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+  DVS_HIP(hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  return DVS_OK;
+}
+
+dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t max_dist,
+                                    int32_t* pairs, int32_t cap, int32_t* n_pairs) {
+  DVS_ARG(m && n_pairs && nq >= 0 && nt >= 0 && cap >= 0);
+  *n_pairs = 0;
+  if (nq == 0 || nt == 0) return DVS_OK;
+  DVS_ARG(q && t && (pairs || cap == 0));
+  DVS_HIP(hipSetDevice(m->device));
+  DVS_TRY(grow(&m->d_q, &m->cq, (size_t)nq * 32));
+  DVS_TRY(grow(&m->d_t, &m->ct, (size_t)nt * 32));
+  DVS_TRY(grow(&m->d_counts, &m->ccounts, (size_t)nq * 4));
+  if (m->d_offs) { DVS_HIP(hipFree(m->d_offs)); m->d_offs = nullptr; }
+  DVS_HIP(hipMalloc(&m->d_offs, ((size_t)nq + 1) * 8));
+  DVS_TRY(grow(&m->d_pairs, &m->cpairs, (size_t)std::max(cap, 1) * 12));
+  DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+  DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+  const dim3 grid((nq + 255) / 256);
+  hipLaunchKernelGGL(k_thresh_count, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist, (int*)m->d_counts);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, m->stream, (const int*)m->d_counts, nq, (long long*)m->d_offs);
+  hipLaunchKernelGGL(k_thresh_write, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist,
+                     (const long long*)m->d_offs, (int*)m->d_pairs, (long long)cap);
+  DVS_HIP(hipGetLastError());
+  long long total = 0;
+  DVS_HIP(hipMemcpyAsync(&total, (long long*)m->d_offs + nq, 8, hipMemcpyDeviceToHost, m->stream));
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  const long long nw = std::min<long long>(total, cap);
+  if (nw) DVS_HIP(hipMemcpy(pairs, m->d_pairs, (size_t)nw * 12, hipMemcpyDeviceToHost));
+  *n_pairs = (int32_t)std::min<long long>(total, INT_MAX);
+  return DVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// orb.hip — host side + C-ABI of the ORB extractor (boundary B1, include/dvslam_hip.h).
+// Replaces ORB_SLAM3::ORBextractor (reference include/dynamic_visual_slam/ORBextractor.hpp:44-110,
+// src/ORBextractor.cpp:409-469 ctor, 1086-1194 operator()/ComputePyramid).  Host code only builds
+// tables and enqueues kernels; there is no CPU compute path.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "orb_kernels.h"
+
+namespace dvs {
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: round-half-even
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+static inline int cv_ceil_f(float v) { int i = (int)v; return i + (i < v); }
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace dvs
+
+using namespace dvs;
+
+struct dvs_orb {
+  dvs_orb_params prm;
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int max_batch = 1;
+  // ctor tables (ORBextractor.cpp:414-445)
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> feat_per_level;
+  int umax[16];
+  // per-resolution state
+  int rows = 0, cols = 0;
+  Geom geom;
+  Geom* d_geom = nullptr;
+  Cell* d_cells = nullptr;
+  BlurTile* d_tiles = nullptr;
+  int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
+  u8 *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
+  int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
+  dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
+  u8* d_desc = nullptr;
+  int* d_nout = nullptr;
+  dvs_keypoint* h_kps = nullptr;   // pinned
+  u8* h_desc = nullptr;
+  int* h_nout = nullptr;
+  size_t octree_smem = 0;
+  int octree_nmax = 0;
+  int last_nimg = 0;
+  ImgSrc last_src{};
+  StageTimer timer;
+};
+
+namespace {
+
+void free_workspace(dvs_orb* h) {
+  void* ptrs[] = {h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
+                  h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_kps) (void)hipHostFree(h->h_kps);
+  if (h->h_desc) (void)hipHostFree(h->h_desc);
+  if (h->h_nout) (void)hipHostFree(h->h_nout);
+  h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
+  h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
+  h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
+  h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
+  h->rows = h->cols = 0;
+}
+
+// ORBextractor ctor tables.  NOTE the member `scaleFactor` is a double holding the float argument
+// (ORBextractor.hpp:97), so products/quotients with it are formed in double and rounded to float once.
+void build_ctor_tables(dvs_orb* h) {
+  const int nl = h->prm.nlevels;
+  const double scaleFactor = (double)h->prm.scale_factor;
+  h->scale.assign(nl, 0.f); h->sigma2.assign(nl, 0.f); h->inv_scale.assign(nl, 0.f); h->inv_sigma2.assign(nl, 0.f);
+  h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; i++) {
+    h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+    h->sigma2[i] = h->scale[i] * h->scale[i];
+  }
+  for (int i = 0; i < nl; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+  h->feat_per_level.assign(nl, 0);
+  const float factor = (float)(1.0f / scaleFactor);
+  float desired = h->prm.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    h->feat_per_level[l] = cv_round_f(desired);
+    sum += h->feat_per_level[l];
+    desired *= factor;
+  }
+  h->feat_per_level[nl - 1] = std::max(h->prm.nfeatures - sum, 0);
+  // umax (ORBextractor.cpp:451-468)
+  int v, v0;
+  const int vmax = cv_floor_f(kHalfPatch * sqrtf(2.f) / 2 + 1);
+  const int vmin = cv_ceil_f(kHalfPatch * sqrtf(2.f) / 2);
+  const double hp2 = kHalfPatch * kHalfPatch;
+  for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round_d(sqrt(hp2 - v * v));
+  for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+    h->umax[v] = v0;
+    ++v0;
+  }
+}
+
+void level_size(const dvs_orb* h, int rows, int cols, int level, int& lr, int& lc) {
+  const float s = h->inv_scale[level];  // ORBextractor.cpp:1173-1174
+  lc = cv_round_f((float)cols * s);
+  lr = cv_round_f((float)rows * s);
+}
+
+// cv::resize INTER_LINEAR coefficient tables for one axis (imgproc/resize.cpp, 8UC1 fixed-point path)
+void build_axis_table(int ssize, int dsize, bool clamp_like_x, std::vector<int>& ofs, std::vector<int>& coef) {
+  const double inv_scale = (double)dsize / ssize;
+  const double scale = 1. / inv_scale;
+  for (int d = 0; d < dsize; d++) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= sx;
+    if (clamp_like_x) {
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= ssize - 1) { fx = 0; sx = ssize - 1; }
+    }
+    const short c0 = sat_short(cv_round_f((1.f - fx) * 2048));
+    const short c1 = sat_short(cv_round_f(fx * 2048));
+    ofs.push_back(sx);
+    coef.push_back((int)(uint16_t)c0 | ((int)c1 << 16));
+  }
+}
+
+dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<Cell>& cells, std::vector<BlurTile>& tiles,
+                          std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
+  memset(&G, 0, sizeof(G));
+  const int nl = h->prm.nlevels;
+  G.nlevels = nl; G.rows = rows; G.cols = cols;
+  G.iniTh = std::min(std::max(h->prm.ini_th_fast, 0), 255);  // cv::FAST clamps the threshold
+  G.minTh = std::min(std::max(h->prm.min_th_fast, 0), 255);
+  G.outCap = h->prm.nfeatures + 3 * nl;
+  memcpy(G.gk, h->prm.gauss_kernel, sizeof(G.gk));
+  memcpy(G.umax, h->umax, sizeof(G.umax));
+  uint64_t off = 0, candOff = 0, ptsOff = 0;
+  int kpOff = 0;
+  for (int l = 0; l < nl; l++) {
+    LevelGeom& L = G.lv[l];
+    level_size(h, rows, cols, l, L.h, L.w);
+    // ComputeKeyPointsOctTree cell grid (ORBextractor.cpp:789-803)
+    const int minBX = kMinBorder, minBY = kMinBorder;
+    const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+    const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+    if (width < 1 || height < 1) { set_error("level %d (%dx%d) is smaller than the 16-px borders", l, L.w, L.h); return DVS_ERR_UNSUPPORTED; }
+    const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
+    const int nIni = (int)round((double)(width / height));  // round(static_cast<float>(w)/(h)) (:559)
+    if (nCols < 1 || nRows < 1 || nIni < 1) {
+      set_error("level %d (%dx%d): the reference divides by zero here (nCols=%d nRows=%d nIni=%d)", l, L.w, L.h, nCols, nRows, nIni);
+      return DVS_ERR_UNSUPPORTED;
+    }
+    L.nCols = nCols; L.nRows = nRows;
+    L.wCell = (int)ceilf(width / nCols);
+    L.hCell = (int)ceilf(height / nRows);
+    L.regionW = maxBX - minBX; L.regionH = maxBY - minBY;
+    L.nIni = nIni;
+    L.hX = width / nIni;
+    L.N = h->feat_per_level[l];
+    L.scale = h->scale[l];
+    L.kpSize = (float)(int)(31 * h->scale[l]);  // PATCH_SIZE*mvScaleFactor[level] truncated (:880)
+    if (L.wCell + 6 > kMaxCellDim || L.hCell + 6 > kMaxCellDim || L.regionW > 4095 || L.regionH > 4095 || L.N > kMaxQuota) {
+      set_error("level %d: cell %dx%d / region %dx%d / quota %d exceeds the supported limits", l, L.wCell, L.hCell, L.regionW, L.regionH, L.N);
+      return DVS_ERR_UNSUPPORTED;
+    }
+    L.pitch = (int)align_up(L.w, 64);
+    L.off = off;
+    off += align_up((uint64_t)L.pitch * L.h, 256);
+    L.cellBase = (int)cells.size();
+    L.cellCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+    int slot = 0;
+    for (int i = 0; i < nRows; i++) {
+      const float iniY = (float)(minBY + i * L.hCell);
+      float maxY = iniY + L.hCell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = (float)maxBY;
+      for (int j = 0; j < nCols; j++) {
+        const float iniX = (float)(minBX + j * L.wCell);
+        float maxX = iniX + L.wCell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = (float)maxBX;
+        Cell c;
+        c.level = (int16_t)l; c.i = (int16_t)i; c.j = (int16_t)j; c.pad = 0;
+        c.x0 = (int16_t)(int)iniX; c.y0 = (int16_t)(int)iniY;
+        c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
+        c.slot = slot++;
+        cells.push_back(c);
+      }
+    }
+    L.nCells = slot;
+    L.ptsCap = L.nCells * L.cellCap;
+    if (L.ptsCap >= (1 << 24)) { set_error("level %d: candidate capacity too large", l); return DVS_ERR_UNSUPPORTED; }
+    L.candOff = candOff; candOff += (uint64_t)L.ptsCap;
+    L.ptsOff = ptsOff; ptsOff += (uint64_t)L.ptsCap;
+    L.kpOff = kpOff; kpOff += L.N + 4;
+    G.maxN = std::max(G.maxN, std::max(L.N + 3, 4 * nIni));
+    for (int ty = 0; ty < (L.h + 15) / 16; ty++)
+      for (int tx = 0; tx < (L.w + 63) / 64; tx++) tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+    if (l > 0) {
+      L.xtab = (int)xofs.size(); L.ytab = (int)yofs.size();
+      build_axis_table(G.lv[l - 1].w, L.w, true, xofs, alpha);
+      build_axis_table(G.lv[l - 1].h, L.h, false, yofs, beta);
+    }
+  }
+  G.frameBytes = off;
+  G.candPerFrame = candOff; G.ptsPerFrame = ptsOff;
+  G.totalCells = (int)cells.size();
+  G.kpBlock = kpOff;
+  G.blurTiles = (int)tiles.size();
+  return DVS_OK;
+}
+
+template <class T>
+dvs_status upload(T** dptr, const std::vector<T>& v) {
+  DVS_HIP(hipMalloc((void**)dptr, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) DVS_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return DVS_OK;
+}
+
+dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
+  if (h->rows == rows && h->cols == cols && h->d_geom) return DVS_OK;
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  free_workspace(h);
+  Geom G;
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<int> xofs, alpha, yofs, beta;
+  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, xofs, alpha, yofs, beta));
+  h->geom = G;
+  const size_t B = (size_t)h->max_batch;
+  DVS_HIP(hipMalloc((void**)&h->d_geom, sizeof(Geom)));
+  DVS_HIP(hipMemcpy(h->d_geom, &G, sizeof(Geom), hipMemcpyHostToDevice));
+  DVS_TRY(upload(&h->d_cells, cells));
+  DVS_TRY(upload(&h->d_tiles, tiles));
+  DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
+  DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
+  DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
+  DVS_HIP(hipMalloc((void**)&h->d_blur, B * G.frameBytes));
+  DVS_HIP(hipMalloc((void**)&h->d_cand, B * G.candPerFrame * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_pts, B * G.ptsPerFrame * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_nodeof, B * G.ptsPerFrame * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_cellcount, B * G.totalCells * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_celloff, B * G.totalCells * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_candtotal, B * G.nlevels * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_lvlcount, B * G.nlevels * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_lvlkp, B * (size_t)G.kpBlock * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
+  DVS_HIP(hipMalloc((void**)&h->d_desc, B * (size_t)G.outCap * 32));
+  DVS_HIP(hipMalloc((void**)&h->d_nout, B * 4));
+  DVS_HIP(hipHostMalloc((void**)&h->h_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
+  DVS_HIP(hipHostMalloc((void**)&h->h_desc, B * (size_t)G.outCap * 32));
+  DVS_HIP(hipHostMalloc((void**)&h->h_nout, B * 4));
+  h->octree_nmax = G.maxN + 8;
+  h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4);
+  DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
+  h->rows = rows; h->cols = cols;
+  return DVS_OK;
+}
+
+// enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`
+dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout) {
+  const Geom& G = h->geom;
+  hipStream_t st = h->stream;
+  src.pyr = h->d_pyr;
+  // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192)
+  h->timer.begin(DVS_STAGE_PYRAMID, st);
+  for (int l = 1; l < G.nlevels; l++) {
+    const LevelGeom& S = G.lv[l - 1];
+    const LevelGeom& D = G.lv[l];
+    const u8* sp = l == 1 ? src.img0 : h->d_pyr + S.off;
+    const uint64_t sfs = l == 1 ? src.fstride0 : G.frameBytes;
+    const int spitch = l == 1 ? (int)src.step0 : S.pitch;
+    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
+                       D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+  }
+  h->timer.end(st);
+  // 2. FAST per cell
+  h->timer.begin(DVS_STAGE_FAST, st);
+  hipLaunchKernelGGL(k_fast_cell, dim3(G.totalCells, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+  h->timer.end(st);
+  // 3. quad-tree
+  h->timer.begin(DVS_STAGE_OCTREE, st);
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(256), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax);
+  h->timer.end(st);
+  // 4. blur
+  h->timer.begin(DVS_STAGE_BLUR, st);
+  hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, st, h->d_geom, h->d_tiles, src, h->d_blur);
+  h->timer.end(st);
+  // 5. orientation + descriptors + output records
+  h->timer.begin(DVS_STAGE_DESCRIBE, st);
+  const int maxkp = std::min(capacity, G.kpBlock);
+  hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, nimg), dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp,
+                     h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
+  h->timer.end(st);
+  DVS_HIP(hipGetLastError());
+  h->last_nimg = nimg;
+  h->last_src = src;
+  return DVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) {
+  DVS_ARG(params && out);
+  *out = nullptr;
+  DVS_ARG(params->nlevels >= 1 && params->nlevels <= DVS_MAX_LEVELS);
+  DVS_ARG(params->nfeatures >= 0 && params->scale_factor > 1.0f && params->max_batch >= 0);
+  DVS_TRY(check_device(device));
+  dvs_orb* h = new (std::nothrow) dvs_orb();
+  if (!h) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  h->prm = *params;
+  bool allzero = true;
+  for (int i = 0; i < 7; i++) allzero = allzero && params->gauss_kernel[i] == 0;
+  if (allzero) { const int k[7] = {18, 34, 48, 56, 48, 34, 18}; memcpy(h->prm.gauss_kernel, k, sizeof(k)); }
+  int ksum = 0;
+  for (int i = 0; i < 7; i++) ksum += h->prm.gauss_kernel[i];
+  if (ksum > 257) { delete h; set_error("gauss_kernel sum %d would overflow the Q8.8 row buffer", ksum); return DVS_ERR_ARG; }
+  h->device = device;
+  h->max_batch = params->max_batch > 0 ? params->max_batch : 1;
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
+  h->stream = h->own_stream;
+  build_ctor_tables(h);
+  *out = h;
+  return DVS_OK;
+}
+
+void dvs_orb_destroy(dvs_orb* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->timer.resolve();
+  free_workspace(h);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int32_t dvs_orb_max_keypoints(const dvs_orb* h) { return h ? h->prm.nfeatures + 3 * h->prm.nlevels : 0; }
+
+dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
+  DVS_ARG(h);
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return DVS_OK;
+}
+void* dvs_orb_get_stream(dvs_orb* h) { return h ? (void*)h->stream : nullptr; }
+
+dvs_status dvs_orb_synchronize(dvs_orb* h) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_get_tables(const dvs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                              int32_t* features_per_level, int32_t* umax16) {
+  DVS_ARG(h);
+  const int nl = h->prm.nlevels;
+  if (scale) memcpy(scale, h->scale.data(), nl * 4);
+  if (inv_scale) memcpy(inv_scale, h->inv_scale.data(), nl * 4);
+  if (sigma2) memcpy(sigma2, h->sigma2.data(), nl * 4);
+  if (inv_sigma2) memcpy(inv_sigma2, h->inv_sigma2.data(), nl * 4);
+  if (features_per_level) memcpy(features_per_level, h->feat_per_level.data(), nl * 4);
+  if (umax16) memcpy(umax16, h->umax, 16 * 4);
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_level_size(const dvs_orb* h, int32_t rows, int32_t cols, int32_t level, int32_t* lr, int32_t* lc) {
+  DVS_ARG(h && lr && lc && level >= 0 && level < h->prm.nlevels);
+  int r, c;
+  level_size(h, rows, cols, level, r, c);
+  *lr = r; *lc = c;
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols,
+                                        size_t step, size_t frame_stride, dvs_keypoint* d_kps, uint8_t* d_desc,
+                                        int32_t capacity, int32_t* d_n_out) {
+  DVS_ARG(h && d_kps && d_desc && d_n_out && nimg >= 0);
+  if (!d_imgs || rows <= 0 || cols <= 0) { set_error("empty image"); return DVS_ERR_EMPTY; }
+  DVS_ARG(step >= (size_t)cols);
+  if (nimg > h->max_batch) { set_error("nimg %d exceeds max_batch %d", nimg, h->max_batch); return DVS_ERR_CAPACITY; }
+  if (capacity < dvs_orb_max_keypoints(h)) { set_error("capacity %d < %d", capacity, dvs_orb_max_keypoints(h)); return DVS_ERR_CAPACITY; }
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_TRY(ensure_workspace(h, rows, cols));
+  if (nimg == 0) return DVS_OK;
+  ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr};
+  return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out);
+}
+
+dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                 dvs_keypoint* kps, uint8_t* desc, int32_t capacity, int32_t* n_out) {
+  DVS_ARG(h && n_out && nimg >= 0);
+  for (int i = 0; i < nimg; i++) n_out[i] = 0;
+  if (!imgs || rows <= 0 || cols <= 0) { set_error("empty image"); return DVS_ERR_EMPTY; }
+  for (int i = 0; i < nimg; i++) if (!imgs[i]) { set_error("empty image %d", i); return DVS_ERR_EMPTY; }
+  DVS_ARG(kps && desc && step >= (size_t)cols);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_TRY(ensure_workspace(h, rows, cols));
+  const Geom& G = h->geom;
+  const int cap = G.outCap;
+  for (int b0 = 0; b0 < nimg; b0 += h->max_batch) {
+    const int nb = std::min(h->max_batch, nimg - b0);
+    // level 0 staged into the frame's pyramid block (the reference copies it too: copyMakeBorder, :1189)
+    for (int i = 0; i < nb; i++)
+      DVS_HIP(hipMemcpy2DAsync(h->d_pyr + (uint64_t)i * G.frameBytes + G.lv[0].off, G.lv[0].pitch, imgs[b0 + i], step, cols, rows,
+                               hipMemcpyHostToDevice, h->stream));
+    ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr};
+    DVS_TRY(enqueue_extract(h, src, nb, h->d_kps, h->d_desc, cap, h->d_nout));
+    DVS_HIP(hipMemcpyAsync(h->h_nout, h->d_nout, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nb * cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nb * cap * 32, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < nb; i++) {
+      const int n = h->h_nout[i];
+      if (n > capacity) { set_error("frame %d: %d keypoints > capacity %d", b0 + i, n, capacity); return DVS_ERR_CAPACITY; }
+      n_out[b0 + i] = n;
+      memcpy(kps + (size_t)(b0 + i) * capacity, h->h_kps + (size_t)i * cap, (size_t)n * sizeof(dvs_keypoint));
+      memcpy(desc + (size_t)(b0 + i) * capacity * 32, h->h_desc + (size_t)i * cap * 32, (size_t)n * 32);
+    }
+  }
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_extract(dvs_orb* h, const uint8_t* gray, int32_t rows, int32_t cols, size_t step, dvs_keypoint* kps,
+                           uint8_t* desc, int32_t capacity, int32_t* n_out) {
+  DVS_ARG(h && n_out);
+  *n_out = 0;
+  if (!gray || rows <= 0 || cols <= 0) { set_error("empty image"); return DVS_ERR_EMPTY; }
+  const uint8_t* one[1] = {gray};
+  return dvs_orb_extract_batch(h, one, 1, rows, cols, step, kps, desc, capacity, n_out);
+}
+
+dvs_status dvs_orb_get_level(dvs_orb* h, int32_t frame, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes) {
+  DVS_ARG(h && dst && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
+  const LevelGeom& L = h->geom.lv[level];
+  if ((int64_t)L.w * L.h > cap_bytes) return DVS_ERR_CAPACITY;
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  if (level == 0 && !blurred) {
+    DVS_HIP(hipMemcpy2D(dst, L.w, h->last_src.img0 + (uint64_t)frame * h->last_src.fstride0, h->last_src.step0, L.w, L.h, hipMemcpyDeviceToHost));
+  } else {
+    const u8* base = (blurred ? h->d_blur : h->d_pyr) + (uint64_t)frame * h->geom.frameBytes + L.off;
+    DVS_HIP(hipMemcpy2D(dst, L.w, base, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  }
+  return DVS_OK;
+}
+
+static dvs_status read_packed(dvs_orb* h, const uint32_t* dsrc, int n, int32_t* xys) {
+  std::vector<uint32_t> tmp(n);
+  if (n) DVS_HIP(hipMemcpy(tmp.data(), dsrc, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { xys[3 * i] = pt_x(tmp[i]); xys[3 * i + 1] = pt_y(tmp[i]); xys[3 * i + 2] = pt_s(tmp[i]); }
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
+  DVS_ARG(h && xys && n && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  int cnt = 0;
+  DVS_HIP(hipMemcpy(&cnt, h->d_candtotal + frame * h->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) return DVS_ERR_CAPACITY;
+  return read_packed(h, h->d_pts + (uint64_t)frame * h->geom.ptsPerFrame + h->geom.lv[level].ptsOff, cnt, xys);
+}
+
+dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
+  DVS_ARG(h && xys && n && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  int cnt = 0;
+  DVS_HIP(hipMemcpy(&cnt, h->d_lvlcount + frame * h->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) return DVS_ERR_CAPACITY;
+  return read_packed(h, h->d_lvlkp + (uint64_t)frame * h->geom.kpBlock + h->geom.lv[level].kpOff, cnt, xys);
+}
+
+dvs_status dvs_orb_enable_stage_timing(dvs_orb* h, int32_t on) {
+  DVS_ARG(h);
+  h->timer.resolve();
+  h->timer.on = on != 0;
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32_t reset) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  h->timer.resolve();
+  for (int i = 0; i < DVS_STAGE_COUNT; i++) { if (ms) ms[i] = h->timer.ms[i]; if (calls) calls[i] = h->timer.calls[i]; }
+  if (reset) h->timer.reset();
+  return DVS_OK;
+}
+
+// ---- host-logic test hooks (no GPU needed): the introsort replica and the glibc sincosf restatement
+void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm) {
+  std::vector<unsigned long long> v(n);
+  for (int i = 0; i < n; i++) v[i] = ((unsigned long long)(uint32_t)count[i] << 28) | ((unsigned long long)(uint16_t)ulx[i] << 12) | (unsigned long long)i;
+  lsort::sort(v.data(), (long)n, lsort::Less<12>());
+  for (int i = 0; i < n; i++) perm[i] = (int)(v[i] & 0xFFFull);
+}
+void dvs_test_sincosf(float a, float* s, float* c) { *s = gsc::sinf_(a); *c = gsc::cosf_(a); }
+// geometry without touching the GPU: fills level sizes / cell grid / quotas for a resolution
+dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
+                             int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell) {
+  DVS_ARG(params && params->nlevels >= 1 && params->nlevels <= DVS_MAX_LEVELS);
+  dvs_orb h;
+  h.prm = *params;
+  build_ctor_tables(&h);
+  Geom G;
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<int> xo, al, yo, be;
+  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, xo, al, yo, be));
+  for (int l = 0; l < G.nlevels; l++) {
+    if (level_w) level_w[l] = G.lv[l].w;
+    if (level_h) level_h[l] = G.lv[l].h;
+    if (ncells) ncells[l] = G.lv[l].nCells;
+    if (quota) quota[l] = G.lv[l].N;
+    if (wcell) wcell[l] = G.lv[l].wCell;
+    if (hcell) hcell[l] = G.lv[l].hCell;
+  }
+  return DVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// orb_geom.h — per-resolution geometry of the extractor, built once on the host (orb.hip) and read by
+// every kernel through scalar loads.  All formulas follow the reference lines cited in orb.hip.
+#pragma once
+#include <stdint.h>
+#include "../../include/dvslam_hip.h"
+
+namespace dvs {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD (ORBextractor.cpp:73)
+constexpr int kMinBorder = 16;   // EDGE_THRESHOLD - 3 (ORBextractor.cpp:789-790)
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE (ORBextractor.cpp:72)
+constexpr int kMaxCellDim = 76;  // wCell < 70 whenever nCols >= 1, +6 overlap
+constexpr int kTilePitch = 80;   // LDS row pitch of a FAST cell tile (bytes)
+constexpr int kMaxQuota = 1500;  // per-level keypoint quota supported by the LDS-resident quad-tree
+
+struct LevelGeom {
+  int32_t w, h, pitch;       // level image size, bytes between rows in the pyramid / blurred blocks
+  int32_t nCols, nRows, wCell, hCell;
+  int32_t cellBase, nCells;  // range of this level in the frame's flat cell table (non-skipped cells, row-major)
+  int32_t cellCap;           // candidate slots per cell = ceil(wCell/2) * ceil(hCell/2) (strict 3x3 maxima)
+  int32_t ptsCap;            // nCells * cellCap
+  int32_t N;                 // mnFeaturesPerLevel[level]
+  int32_t nIni;              // quad-tree roots
+  float hX;                  // root width (float, ORBextractor.cpp:561)
+  int32_t regionW, regionH;  // maxBorder - minBorder
+  int32_t kpOff;             // first slot of this level in the per-frame level-keypoint block (N + 4 slots)
+  int32_t xtab, ytab;        // offsets of this level's resize tables (level >= 1)
+  float scale;               // mvScaleFactor[level]
+  float kpSize;              // (float)(int)(31 * scale)
+  uint64_t off;              // byte offset of the level inside a frame's pyramid (and blurred) block
+  uint64_t candOff;          // uint32 index of the level's first cell slot inside a frame's candidate block
+  uint64_t ptsOff;           // uint32 index of the level's linear point list inside a frame's points block
+};
+
+struct Geom {
+  int32_t nlevels, rows, cols;
+  int32_t totalCells;   // over all levels
+  int32_t kpBlock;      // sum over levels of (N + 4)
+  int32_t outCap;       // nfeatures + 3 * nlevels
+  int32_t blurTiles;    // tiles of the blur launch over all levels
+  int32_t iniTh, minTh;
+  int32_t maxN;         // max quota over levels
+  int32_t gk[7];
+  int32_t umax[16];
+  uint64_t frameBytes;  // pyramid block per frame
+  uint64_t candPerFrame, ptsPerFrame;  // uint32 elements per frame
+  LevelGeom lv[DVS_MAX_LEVELS];
+};
+
+struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
+  int16_t level, i, j, pad;
+  int16_t x0, y0, cw, ch;  // sub-image origin and size in level pixels (rowRange/colRange)
+  int32_t slot;            // index among the level's cells (candidate order)
+};
+
+struct BlurTile { int16_t level, tx, ty, pad; };
+
+// packed candidate / keypoint: x (12 bits) | y (12 bits) << 12 | score << 24, region-relative coordinates
+__host__ __device__ inline uint32_t pack_pt(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }
+__host__ __device__ inline int pt_x(uint32_t p) { return (int)(p & 0xFFFu); }
+__host__ __device__ inline int pt_y(uint32_t p) { return (int)((p >> 12) & 0xFFFu); }
+__host__ __device__ inline int pt_s(uint32_t p) { return (int)(p >> 24); }
+
+}  // namespace dvs

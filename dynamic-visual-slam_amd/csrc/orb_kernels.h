@@ -1,0 +1,764 @@
+// orb_kernels.h — gfx950 kernels of the ORB extractor (included by orb.hip only).
+//
+// Launch sequence per batch of F frames (grid.z / grid.y = frame):
+//   k_resize        x (nlevels-1)  pyramid, level l from level l-1            ORBextractor.cpp:1169-1194
+//   k_fast_cell     1              FAST-9/16 score + per-cell NMS + fallback  ORBextractor.cpp:805-872
+//   k_octree        1              candidate gather + quad-tree distribution  ORBextractor.cpp:555-779, 874-890
+//   k_blur          1              7x7 fixed-point Gaussian of every level    ORBextractor.cpp:1132-1133
+//   k_describe      1              IC orientation + steered BRIEF + output    ORBextractor.cpp:76-146, 1142-1163
+//
+// Everything is integer or explicitly-rounded float32/float64 arithmetic; the file is compiled with
+// -ffp-contract=off so no mul/add pair is fused behind our back.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "glibc_sincosf.h"
+#include "lsort.h"
+#include "orb_geom.h"
+
+namespace dvs {
+
+typedef uint8_t u8;
+
+struct ImgSrc {
+  const u8* img0;     // level-0 frames (caller's buffer or our staging copy)
+  uint64_t step0;     // bytes between rows of level 0
+  uint64_t fstride0;  // bytes between frames of level 0
+  u8* pyr;            // levels >= 1: pyr + f * frameBytes + lv[l].off
+};
+
+__device__ __forceinline__ const u8* level_ptr(const Geom* g, const ImgSrc& s, int f, int l, int& pitch) {
+  if (l == 0) { pitch = (int)s.step0; return s.img0 + (uint64_t)f * s.fstride0; }
+  pitch = g->lv[l].pitch;
+  return s.pyr + (uint64_t)f * g->frameBytes + g->lv[l].off;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o);
+    if (lane_id() >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over the 256 threads of a block; wsum = 5 ints of LDS.  Contains two barriers.
+__device__ __forceinline__ int block_excl_scan256(int v, int* wsum, int& total) {
+  int incl = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane_id() == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { int s = wsum[i]; if (i < w) base += s; }
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
+// =============================================================================================
+// pyramid: cv::resize(prev, cur, sz, 0, 0, INTER_LINEAR) on 8UC1 with OpenCV's 11-bit fixed-point
+// coefficients (tables built on the host, orb.hip build_resize_tables).  4 output pixels / thread.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_resize(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
+                                                u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
+                                                const int* __restrict__ xofs, const int* __restrict__ alpha,
+                                                const int* __restrict__ yofs, const int* __restrict__ beta) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (x4 >= dw || y >= dh) return;
+  const u8* s = src + (uint64_t)f * sfs;
+  u8* d = dst + (uint64_t)f * dfs + (uint64_t)y * dp;
+  const int sy = yofs[y];
+  const int b = beta[y];
+  const int b0 = (int)(short)(b & 0xffff), b1 = b >> 16;
+  const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+  const u8* p0 = s + (uint64_t)r0 * sp;
+  const u8* p1 = s + (uint64_t)r1 * sp;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x4 + i;
+    if (x < dw) {
+      const int sx = xofs[x];
+      const int sx1 = min(sx + 1, sw - 1);
+      const int a = alpha[x];
+      const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
+      const int h0 = p0[sx] * a0 + p0[sx1] * a1;
+      const int h1 = p1[sx] * a0 + p1[sx1] * a1;
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * i);
+    }
+  }
+  if (x4 + 3 < dw) {
+    *reinterpret_cast<uint32_t*>(d + x4) = out;
+  } else {
+    for (int i = 0; i < 4 && x4 + i < dw; i++) d[x4 + i] = (u8)(out >> (8 * i));
+  }
+}
+
+// =============================================================================================
+// FAST-9/16 per reference cell.  One 256-thread workgroup = one cell of one frame:
+//   1. stage the (cw x ch) sub-image into LDS
+//   2. cheap opposite-pair rejection test at minTh for every interior pixel, survivors compacted into
+//      an LDS work list with a wave ballot (lanes stay dense for the expensive part)
+//   3. exact corner score S = max over 9-arcs (cornerScore<16>); a pixel is a FAST corner at threshold
+//      t  <=>  S >= t, so ONE score map serves both thresholds (20 and 7)
+//   4. 3x3 non-max suppression inside the cell interior (outside = 0, as cv::FAST on the sub-image),
+//      iniTh keypoints if any survive, otherwise minTh keypoints (ORBextractor.cpp:843-846),
+//      emitted row-major with a block scan so candidate order equals the reference's.
+// =============================================================================================
+__device__ __forceinline__ int fast_corner_score(const u8* c, int v) {
+  // ring offsets of cv::FAST pattern 16 (fast_score.cpp makeOffsets), k = 0..15
+  constexpr int P = kTilePitch;
+  const int o[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,  -P + 3,  -2 * P + 2,  -3 * P + 1,
+                     -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3,   2 * P - 2,   3 * P - 1};
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - (int)c[o[k]];
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+  }
+  int A = -1000, B = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    A = max(A, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));  // min of d[k..k+8]
+    B = min(B, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));  // max of d[k..k+8]
+  }
+  return max(A, -B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount) {
+  constexpr int P = kTilePitch;
+  __shared__ __attribute__((aligned(16))) u8 tile[kMaxCellDim * P];
+  __shared__ __attribute__((aligned(16))) u8 score[kMaxCellDim * P];
+  __shared__ uint16_t work[(kMaxCellDim - 6) * (kMaxCellDim - 6)];
+  __shared__ int nwork;
+  __shared__ int wsum[5];
+  __shared__ int any20;
+
+  const int tid = threadIdx.x;
+  const int f = blockIdx.y;
+  const Cell cell = cells[blockIdx.x];
+  const LevelGeom& L = g->lv[cell.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, cell.level, pitch);
+  const int cw = cell.cw, ch = cell.ch;
+  const int iw = cw - 6, ih = ch - 6;
+  int* countOut = cellCount + (uint64_t)f * g->totalCells + blockIdx.x;
+  if (iw <= 0 || ih <= 0) {  // cv::FAST finds nothing in a sub-image narrower than 7
+    if (tid == 0) *countOut = 0;
+    return;
+  }
+  if (tid == 0) { nwork = 0; any20 = 0; }
+  // 1. stage
+  {
+    const u8* base = img + (uint64_t)cell.y0 * pitch + cell.x0;
+    const int n = cw * ch;
+    const float inv = 1.0f / (float)cw;
+    for (int p = tid; p < n; p += 256) {
+      int y = (int)(((float)p + 0.5f) * inv);
+      int x = p - y * cw;
+      tile[y * P + x] = base[(uint64_t)y * pitch + x];
+    }
+    uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
+    for (int p = tid; p < ch * P / 4; p += 256) s32[p] = 0;
+  }
+  __syncthreads();
+  const int tmin = g->minTh, tini = g->iniTh;
+  const int npx = iw * ih;
+  const float invw = 1.0f / (float)iw;
+  // 2. rejection test + compaction
+  for (int p0 = 0; p0 < npx; p0 += 256) {
+    const int p = p0 + tid;
+    bool pass = false;
+    int c = 0;
+    if (p < npx) {
+      int y = (int)(((float)p + 0.5f) * invw);
+      int x = p - y * iw;
+      c = (y + 3) * P + (x + 3);
+      const int v = tile[c];
+      const int lo = v - tmin, hi = v + tmin;
+      auto cls = [&](int off) -> int { int r = tile[c + off]; return (r < lo ? 1 : 0) | (r > hi ? 2 : 0); };
+      int dbits = cls(3 * P) | cls(-3 * P);             // ring 0 / 8
+      dbits &= cls(3) | cls(-3);                        // ring 4 / 12
+      dbits &= cls(2 * P + 2) | cls(-2 * P - 2);        // ring 2 / 10
+      dbits &= cls(-2 * P + 2) | cls(2 * P - 2);        // ring 6 / 14
+      pass = dbits != 0;
+    }
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+      int base = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      if (lane_id() == leader) base = atomicAdd(&nwork, __popcll(m));
+      base = __shfl(base, leader);
+      if (pass) work[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = (uint16_t)c;
+    }
+  }
+  __syncthreads();
+  // 3. exact score for the survivors
+  const int nw = nwork;
+  for (int e = tid; e < nw; e += 256) {
+    const int c = work[e];
+    const int s = fast_corner_score(&tile[c], (int)tile[c]);
+    if (s >= tmin) score[c] = (u8)s;
+  }
+  __syncthreads();
+  // 4. NMS + ordered emission.  Thread t owns the contiguous row-major pixel range [t*k, (t+1)*k).
+  const int k = (npx + 255) >> 8;  // <= 19
+  uint32_t m20 = 0, m7 = 0;
+  const int pbeg = tid * k;
+  for (int i = 0; i < k; i++) {
+    const int p = pbeg + i;
+    if (p >= npx) break;
+    int y = (int)(((float)p + 0.5f) * invw);
+    int x = p - y * iw;
+    const int c = (y + 3) * P + (x + 3);
+    const int s = score[c];
+    if (s > 0) {
+      // pixels outside the interior were never written: they hold 0, exactly cv::FAST's zeroed buffers
+      const bool ismax = s > score[c - 1] && s > score[c + 1] && s > score[c - P - 1] && s > score[c - P] &&
+                         s > score[c - P + 1] && s > score[c + P - 1] && s > score[c + P] && s > score[c + P + 1];
+      if (ismax) { m7 |= 1u << i; if (s >= tini) m20 |= 1u << i; }
+    }
+  }
+  if (m20) any20 = 1;  // benign race: every writer stores 1
+  __syncthreads();
+  const uint32_t sel = any20 ? m20 : m7;
+  int total;
+  int rank = block_excl_scan256(__popc(sel), wsum, total);
+  uint32_t* out = cand + (uint64_t)f * g->candPerFrame + L.candOff + (uint64_t)cell.slot * L.cellCap;
+  const int cap = L.cellCap;
+  for (int i = 0; i < k; i++) {
+    if (sel & (1u << i)) {
+      const int p = pbeg + i;
+      int y = (int)(((float)p + 0.5f) * invw);
+      int x = p - y * iw;
+      const int c = (y + 3) * P + (x + 3);
+      // sub-image coords (x+3, y+3) shifted by j*wCell, i*hCell (ORBextractor.cpp:865-866)
+      if (rank < cap) out[rank] = pack_pt(x + 3 + cell.j * L.wCell, y + 3 + cell.i * L.hCell, score[c]);
+      rank++;
+    }
+  }
+  if (tid == 0) *countOut = min(total, cap);
+}
+
+// =============================================================================================
+// quad-tree distribution (DistributeOctTree).  One workgroup per (level, frame).  The reference's
+// std::list is kept as an ARRAY IN LIST ORDER that is rebuilt by prefix sums after every sweep:
+//   full sweep : every multi-point node is split; new list = reverse(children in creation order) ++
+//                surviving single-point nodes in old order           (push_front + erase, :622-681)
+//   ordered    : nodes sorted by (count, UL.x) with the libstdc++ introsort replica (ties!), split
+//                from the back until size >= N                        (:689-753)
+// Points never move: each keeps the list position of its node (nodeOf); a node's winner is the max
+// response with the lowest candidate index (:757-776), resolved with one atomicMax per point.
+// =============================================================================================
+struct QNode { int16_t ulx, uly, brx, bry; int32_t cnt; int32_t pt; };
+
+__device__ __forceinline__ int qt_quadrant(const QNode& nd, int x, int y) {
+  const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)   (:482)
+  const int my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
+  return (x < mx ? 0 : 1) | (y < my ? 0 : 2);  // 0:n1 1:n2 2:n3 3:n4  (:514-524)
+}
+__device__ __forceinline__ QNode qt_child(const QNode& nd, int q, int cnt) {
+  const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1);
+  const int my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
+  QNode c;
+  c.ulx = (int16_t)((q & 1) ? mx : nd.ulx);
+  c.brx = (int16_t)((q & 1) ? nd.brx : mx);
+  c.uly = (int16_t)((q & 2) ? my : nd.uly);
+  c.bry = (int16_t)((q & 2) ? nd.bry : my);
+  c.cnt = cnt;
+  c.pt = -1;
+  return c;
+}
+
+struct QtShared {
+  QNode* nodes[2];
+  int* childCnt;   // 4 per node
+  int* posArr;     // split node: first list position of its children; unsplit: -(newpos+1)
+  int* flag;       // per node: 1 = split in this pass
+  int* expl;       // multi-point nodes in creation order (list positions)
+  int* ecum;       // phase B: inclusive sum of non-empty children in processing order
+  unsigned long long* sortbuf;
+};
+
+// counts children of every multi-point node of the current list
+__device__ __forceinline__ void qt_count_children(const QNode* nodes, int S, int* childCnt, const uint32_t* pts,
+                                                  const int* nodeOf, int n) {
+  for (int k = threadIdx.x; k < 4 * S; k += 256) childCnt[k] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int k = nodeOf[i];
+    if (k >= 0) {
+      const uint32_t p = pts[i];
+      atomicAdd(&childCnt[4 * k + qt_quadrant(nodes[k], pt_x(p), pt_y(p))], 1);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int qt_mask(const int* childCnt, int k) {
+  return (childCnt[4 * k] > 0 ? 1 : 0) | (childCnt[4 * k + 1] > 0 ? 2 : 0) | (childCnt[4 * k + 2] > 0 ? 4 : 0) |
+         (childCnt[4 * k + 3] > 0 ? 8 : 0);
+}
+
+// After flag[]/posArr[] of split nodes are set (posArr = first child position) and T = number of new
+// children: place unsplit nodes behind the children in old order, write the new node array, re-point
+// the points.  Returns nothing; *pS updated by thread 0.
+__device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, uint32_t* pts, int* nodeOf, int n, int* wsum) {
+  const QNode* old = sh.nodes[cur];
+  QNode* nw = sh.nodes[cur ^ 1];
+  // unsplit nodes: stable compaction behind the children block
+  int carry = 0;
+  for (int b = 0; b < S; b += 256) {
+    const int k = b + threadIdx.x;
+    const int u = (k < S && !sh.flag[k]) ? 1 : 0;
+    int tot;
+    const int ex = block_excl_scan256(u, wsum, tot);
+    if (u) sh.posArr[k] = -((T + carry + ex) + 1);
+    carry += tot;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < S; k += 256) {
+    const QNode nd = old[k];
+    if (sh.flag[k]) {
+      const int base = sh.posArr[k];
+      const int mask = qt_mask(sh.childCnt, k);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (mask & (1 << q)) nw[base + __popc(mask >> (q + 1))] = qt_child(nd, q, sh.childCnt[4 * k + q]);
+    } else {
+      nw[-(sh.posArr[k] + 1)] = nd;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int k = nodeOf[i];
+    if (k < 0) continue;
+    const int pa = sh.posArr[k];
+    if (pa < 0) { nodeOf[i] = -(pa + 1); continue; }
+    const uint32_t p = pts[i];
+    const int q = qt_quadrant(old[k], pt_x(p), pt_y(p));
+    const int mask = qt_mask(sh.childCnt, k);
+    const int np = pa + __popc(mask >> (q + 1));
+    if (sh.childCnt[4 * k + q] == 1) { nw[np].pt = i; nodeOf[i] = -1; }
+    else nodeOf[i] = np;
+  }
+  __syncthreads();
+}
+
+// creation-ordered list of multi-point nodes among the T freshly created children (positions T-1..0)
+__device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T, int* wsum) {
+  const QNode* nodes = sh.nodes[cur];
+  int carry = 0;
+  for (int b = 0; b < T; b += 256) {
+    const int j = b + threadIdx.x;
+    const int pos = T - 1 - j;
+    const int fl = (j < T && nodes[pos].cnt > 1) ? 1 : 0;
+    int tot;
+    const int ex = block_excl_scan256(fl, wsum, tot);
+    if (fl) sh.expl[carry + ex] = pos;
+    carry += tot;
+  }
+  __syncthreads();
+  return carry;
+}
+
+__global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
+                                                const int* __restrict__ cellCount, int* __restrict__ cellOff,
+                                                uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
+                                                int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
+                                                int* __restrict__ lvlKpCount, int nmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wsum[5];
+  __shared__ int s_S, s_n, s_T, s_nexp, s_c;
+  const int tid = threadIdx.x;
+  const int level = blockIdx.x, f = blockIdx.y;
+  const LevelGeom& L = g->lv[level];
+
+  QtShared sh;
+  {
+    unsigned char* p = smem;
+    sh.nodes[0] = (QNode*)p; p += sizeof(QNode) * nmax;
+    sh.nodes[1] = (QNode*)p; p += sizeof(QNode) * nmax;
+    sh.sortbuf = (unsigned long long*)p; p += 8 * nmax;
+    sh.childCnt = (int*)p; p += 16 * nmax;
+    sh.posArr = (int*)p; p += 4 * nmax;
+    sh.flag = (int*)p; p += 4 * nmax;
+    sh.expl = (int*)p; p += 4 * nmax;
+    sh.ecum = (int*)p; p += 4 * nmax;
+  }
+  uint32_t* pts = ptsAll + (uint64_t)f * g->ptsPerFrame + L.ptsOff;
+  int* nodeOf = nodeOfAll + (uint64_t)f * g->ptsPerFrame + L.ptsOff;
+  const uint32_t* cnd = cand + (uint64_t)f * g->candPerFrame + L.candOff;
+  const int* cc = cellCount + (uint64_t)f * g->totalCells + L.cellBase;
+  int* co = cellOff + (uint64_t)f * g->totalCells + L.cellBase;
+
+  // ---- gather: candidate order = cells row-major, pixels row-major inside a cell -------------
+  {
+    int carry = 0;
+    for (int b = 0; b < L.nCells; b += 256) {
+      const int c = b + tid;
+      const int v = c < L.nCells ? cc[c] : 0;
+      int tot;
+      const int ex = block_excl_scan256(v, wsum, tot);
+      if (c < L.nCells) co[c] = carry + ex;
+      carry += tot;
+    }
+    if (tid == 0) { s_n = carry; candTotal[f * g->nlevels + level] = carry; }
+    __syncthreads();
+    const int w = tid >> 6;
+    for (int c = w; c < L.nCells; c += 4) {
+      const int cnt = cc[c], off = co[c];
+      for (int t = lane_id(); t < cnt; t += 64) pts[off + t] = cnd[(uint64_t)c * L.cellCap + t];
+    }
+    __syncthreads();
+  }
+  const int n = s_n;
+  const int N = L.N;
+  int cur = 0;
+
+  // ---- roots (:559-601) ------------------------------------------------------------------------
+  {
+    const int nIni = L.nIni;
+    for (int k = tid; k < nIni; k += 256) sh.childCnt[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int r = (int)__fdiv_rn((float)pt_x(pts[i]), L.hX);  // vpIniNodes[kp.pt.x/hX]
+      nodeOf[i] = r;  // root index for now
+      atomicAdd(&sh.childCnt[r], 1);
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int b = 0; b < nIni; b += 256) {
+      const int k = b + tid;
+      const int u = (k < nIni && sh.childCnt[k] > 0) ? 1 : 0;
+      int tot;
+      const int ex = block_excl_scan256(u, wsum, tot);
+      if (k < nIni) sh.posArr[k] = u ? carry + ex : -1;
+      if (u) {
+        QNode nd;
+        nd.ulx = (int16_t)(int)__fmul_rn(L.hX, (float)k);
+        nd.brx = (int16_t)(int)__fmul_rn(L.hX, (float)(k + 1));
+        nd.uly = 0; nd.bry = (int16_t)L.regionH;
+        nd.cnt = sh.childCnt[k]; nd.pt = -1;
+        sh.nodes[0][carry + ex] = nd;
+      }
+      carry += tot;
+    }
+    if (tid == 0) s_S = carry;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int pos = sh.posArr[nodeOf[i]];
+      if (sh.nodes[0][pos].cnt == 1) { sh.nodes[0][pos].pt = i; nodeOf[i] = -1; }
+      else nodeOf[i] = pos;
+    }
+    __syncthreads();
+  }
+
+  // ---- main loop ---------------------------------------------------------------------------------
+  bool finish = (n == 0);
+  while (!finish) {
+    const int S = s_S;
+    // full sweep: split every multi-point node (:622-681)
+    qt_count_children(sh.nodes[cur], S, sh.childCnt, pts, nodeOf, n);
+    int nExpandLocal = 0;
+    {
+      // children block: node k's children sit in front of the children of all earlier nodes
+      int carry = 0;
+      for (int b = 0; b < S; b += 256) {
+        const int k = b + tid;
+        int e = 0;
+        if (k < S) {
+          const bool split = sh.nodes[cur][k].cnt > 1;
+          sh.flag[k] = split ? 1 : 0;
+          if (split) {
+            e = __popc(qt_mask(sh.childCnt, k));
+#pragma unroll
+            for (int q = 0; q < 4; q++) nExpandLocal += sh.childCnt[4 * k + q] > 1 ? 1 : 0;
+          }
+        }
+        int tot;
+        const int ex = block_excl_scan256(e, wsum, tot);
+        if (k < S) sh.ecum[k] = carry + ex + e;  // inclusive
+        carry += tot;
+      }
+      if (tid == 0) { s_T = carry; s_nexp = 0; }
+      __syncthreads();
+      const int T = s_T;
+      for (int k = tid; k < S; k += 256)
+        if (sh.flag[k]) sh.posArr[k] = T - sh.ecum[k];
+      if (nExpandLocal) atomicAdd(&s_nexp, nExpandLocal);
+      __syncthreads();
+    }
+    const int T = s_T;
+    const int nToExpand = s_nexp;
+    int nUnsplit = 0;
+    {  // count unsplit nodes = S - (#split); derive from flags
+      int loc = 0;
+      for (int k = tid; k < S; k += 256) loc += sh.flag[k] ? 0 : 1;
+      if (tid == 0) s_c = 0;
+      __syncthreads();
+      if (loc) atomicAdd(&s_c, loc);
+      __syncthreads();
+      nUnsplit = s_c;
+    }
+    qt_rebuild(sh, cur, S, T, pts, nodeOf, n, wsum);
+    cur ^= 1;
+    int Snew = T + nUnsplit;
+    if (tid == 0) s_S = Snew;
+    __syncthreads();
+    if (Snew >= N || Snew == S) { finish = true; break; }
+    if (Snew + nToExpand * 3 <= N) continue;
+
+    // ordered phase (:692-753)
+    int m = qt_build_expand_list(sh, cur, T, wsum);
+    while (!finish) {
+      const int Sb = s_S;
+      if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
+      qt_count_children(sh.nodes[cur], Sb, sh.childCnt, pts, nodeOf, n);
+      for (int r = tid; r < m; r += 256) {
+        const QNode& nd = sh.nodes[cur][sh.expl[r]];
+        sh.sortbuf[r] = ((unsigned long long)(uint32_t)nd.cnt << 28) | ((unsigned long long)(uint16_t)nd.ulx << 12) |
+                        (unsigned long long)r;
+      }
+      for (int k = tid; k < Sb; k += 256) sh.flag[k] = 0;
+      __syncthreads();
+      if (tid == 0) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
+      __syncthreads();
+      // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
+      int carry = 0;
+      if (tid == 0) s_c = 0;
+      __syncthreads();
+      int below = 0;
+      for (int b = 0; b < m; b += 256) {
+        const int r = b + tid;
+        int e = 0;
+        if (r < m) e = __popc(qt_mask(sh.childCnt, sh.expl[(int)(sh.sortbuf[m - 1 - r] & 0xFFFull)]));
+        int tot;
+        const int ex = block_excl_scan256(e, wsum, tot);
+        if (r < m) {
+          const int incl = carry + ex + e;
+          sh.ecum[r] = incl;
+          // list size after processing r'+1 nodes = Sb + sum(e - 1)
+          if (Sb + incl - (r + 1) < N) below++;
+        }
+        carry += tot;
+      }
+      if (below) atomicAdd(&s_c, below);
+      __syncthreads();
+      const int c = s_c;
+      const int M = c < m ? c + 1 : m;  // break right after the split that reaches N (:746-747)
+      const int Tm = sh.ecum[M - 1];
+      __syncthreads();
+      for (int r = tid; r < M; r += 256) {
+        const int k = sh.expl[(int)(sh.sortbuf[m - 1 - r] & 0xFFFull)];
+        sh.flag[k] = 1;
+        sh.posArr[k] = Tm - sh.ecum[r];
+      }
+      __syncthreads();
+      qt_rebuild(sh, cur, Sb, Tm, pts, nodeOf, n, wsum);
+      cur ^= 1;
+      const int Sn = Tm + (Sb - M);
+      if (tid == 0) s_S = Sn;
+      __syncthreads();
+      if (Sn >= N || Sn == Sb) { finish = true; break; }
+      m = qt_build_expand_list(sh, cur, Tm, wsum);
+    }
+  }
+
+  // ---- best point per node (:757-776), list order = output order ----------------------------------
+  const int S = (n == 0) ? 0 : s_S;
+  QNode* nodes = sh.nodes[cur];
+  int* best = sh.childCnt;
+  for (int k = tid; k < S; k += 256) best[k] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int k = nodeOf[i];
+    if (k >= 0) atomicMax((unsigned int*)&best[k], ((uint32_t)pt_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i));
+  }
+  __syncthreads();
+  uint32_t* outp = lvlKp + (uint64_t)f * g->kpBlock + L.kpOff;
+  for (int k = tid; k < S; k += 256) {
+    const QNode nd = nodes[k];
+    const int i = nd.cnt == 1 ? nd.pt : (int)(0xFFFFFFu - ((uint32_t)best[k] & 0xFFFFFFu));
+    if (k < N + 4) outp[k] = pts[i];
+  }
+  if (tid == 0) lvlKpCount[f * g->nlevels + level] = min(S, N + 4);
+}
+
+// =============================================================================================
+// 7x7 Gaussian, sigma 2, BORDER_REFLECT_101 on the level itself — OpenCV's 8-bit fixed-point path:
+// horizontal Q8.8 (exact in u16), vertical Q16.16, (acc + 32768) >> 16.  Tile = 64 x 16 outputs.
+// =============================================================================================
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, const BlurTile* __restrict__ tiles, ImgSrc src,
+                                              u8* __restrict__ blur) {
+  __shared__ u8 in[22][72];
+  __shared__ uint16_t hb[22][64];
+  const BlurTile t = tiles[blockIdx.x];
+  const int f = blockIdx.y;
+  const LevelGeom& L = g->lv[t.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, t.level, pitch);
+  const int x0 = t.tx * 64, y0 = t.ty * 16;
+  const int tid = threadIdx.x;
+  for (int p = tid; p < 22 * 70; p += 256) {
+    const int r = p / 70, c = p - r * 70;
+    const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
+    in[r][c] = img[(uint64_t)sy * pitch + sx];
+  }
+  __syncthreads();
+  const int k0 = g->gk[0], k1 = g->gk[1], k2 = g->gk[2], k3 = g->gk[3], k4 = g->gk[4], k5 = g->gk[5], k6 = g->gk[6];
+  for (int p = tid; p < 22 * 64; p += 256) {
+    const int r = p >> 6, c = p & 63;
+    const u8* s = &in[r][c];
+    hb[r][c] = (uint16_t)(k0 * s[0] + k1 * s[1] + k2 * s[2] + k3 * s[3] + k4 * s[4] + k5 * s[5] + k6 * s[6]);
+  }
+  __syncthreads();
+  u8* dst = blur + (uint64_t)f * g->frameBytes + L.off;
+  const int c = tid & 63;
+  const int rq = tid >> 6;
+  if (x0 + c < L.w) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = rq * 4 + i;
+      if (y0 + r < L.h) {
+        const uint32_t acc = (uint32_t)k0 * hb[r][c] + (uint32_t)k1 * hb[r + 1][c] + (uint32_t)k2 * hb[r + 2][c] +
+                             (uint32_t)k3 * hb[r + 3][c] + (uint32_t)k4 * hb[r + 4][c] + (uint32_t)k5 * hb[r + 5][c] +
+                             (uint32_t)k6 * hb[r + 6][c];
+        dst[(uint64_t)(y0 + r) * L.pitch + x0 + c] = (u8)((acc + 32768u) >> 16);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// orientation + descriptor + final keypoint record.  One wavefront per keypoint.
+// =============================================================================================
+__constant__ int8_t c_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+
+// cv::fastAtan2 (atan_f32), float32 with individually rounded operations
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
+                                                  const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
+                                                  dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
+                                                  int* __restrict__ nOut, int capacity) {
+  const int f = blockIdx.y;
+  const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int nl = g->nlevels;
+  const int* cnt = lvlKpCount + f * nl;
+  int level = -1, off = 0, total = 0;
+  for (int l = 0; l < nl; l++) {
+    const int c = cnt[l];
+    if (level < 0 && gi < total + c) { level = l; off = total; }
+    total += c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) nOut[f] = min(total, capacity);
+  if (level < 0 || gi >= capacity) return;
+  const LevelGeom& L = g->lv[level];
+  const uint32_t pk = lvlKp[(uint64_t)f * g->kpBlock + L.kpOff + (gi - off)];
+  const int x = pt_x(pk) + kMinBorder, y = pt_y(pk) + kMinBorder;  // level pixel coordinates (:886-887)
+  int pitch;
+  const u8* img = level_ptr(g, src, f, level, pitch);
+
+  // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch (umax).  Two patch rows per
+  // iteration: lanes 0..30 take row v = it-15, lanes 32..62 take row v = it+1.
+  int m10 = 0, m01 = 0;
+  {
+    const int u = (lane & 31) - kHalfPatch;
+    const int half = lane >> 5;
+    const bool col_ok = (lane & 31) < 31;
+    const u8* center = img + (uint64_t)y * pitch + x;
+    for (int it = 0; it < 16; it++) {
+      const int v = it - kHalfPatch + 16 * half;
+      if (col_ok && v <= kHalfPatch) {
+        const int av = v < 0 ? -v : v;
+        const int au = u < 0 ? -u : u;
+        if (au <= g->umax[av]) {
+          const int I = center[(int64_t)v * pitch + u];
+          m10 += u * I;
+          m01 += v * I;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // steered BRIEF on the blurred level (:107-146)
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float arad = __fmul_rn(angle, factorPI);
+  const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
+  const u8* bc = blur + (uint64_t)f * g->frameBytes + L.off + (uint64_t)y * L.pitch + x;
+  const int bp = L.pitch;
+  unsigned long long words[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int p = 64 * r + lane;
+    const int pat = reinterpret_cast<const int*>(c_pattern)[p];
+    const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+    const int t0 = bc[(int64_t)r0 * bp + c0];
+    const int t1 = bc[(int64_t)r1 * bp + c1];
+    words[r] = __ballot(t0 < t1);
+  }
+  if (lane < 4) {
+    unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+    reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi) * 32)[lane] = w;
+  }
+  if (lane == 0) {
+    dvs_keypoint kp;
+    kp.x = (float)x; kp.y = (float)y;
+    if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
+    kp.size = L.kpSize;
+    kp.angle = angle;
+    kp.response = (float)pt_s(pk);
+    kp.octave = level;
+    kp.class_id = -1;
+    outKp[(uint64_t)f * capacity + gi] = kp;
+  }
+}
+
+}  // namespace dvs

@@ -1,0 +1,105 @@
+// util.hip — error text, device selection, raw device-memory helpers of the C-ABI
+#include <string.h>
+#include "common.h"
+
+namespace dvs {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+dvs_status check_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (%s); libdvslam_hip has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    (void)hipGetLastError();
+    return DVS_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return DVS_ERR_ARG; }
+  DVS_HIP(hipSetDevice(device));
+  return DVS_OK;
+}
+
+void StageTimer::begin(int stage, hipStream_t s) {
+  if (!on) return;
+  if (npending >= kMaxPending) resolve();
+  Pending& p = pending[npending];
+  if (npool < 2 * (npending + 1)) {
+    hipEventCreate(&pool[npool++]);
+    hipEventCreate(&pool[npool++]);
+  }
+  p.a = pool[2 * npending]; p.b = pool[2 * npending + 1]; p.stage = stage;
+  hipEventRecord(p.a, s);
+  cur = npending++;
+}
+void StageTimer::end(hipStream_t s) {
+  if (!on || cur < 0) return;
+  hipEventRecord(pending[cur].b, s);
+  cur = -1;
+}
+void StageTimer::resolve() {
+  for (int i = 0; i < npending; i++) {
+    hipEventSynchronize(pending[i].b);
+    float t = 0;
+    if (hipEventElapsedTime(&t, pending[i].a, pending[i].b) == hipSuccess) { ms[pending[i].stage] += t; calls[pending[i].stage]++; }
+  }
+  npending = 0;
+}
+void StageTimer::reset() { resolve(); memset(ms, 0, sizeof(ms)); memset(calls, 0, sizeof(calls)); }
+StageTimer::~StageTimer() { for (int i = 0; i < npool; i++) hipEventDestroy(pool[i]); }
+
+}  // namespace dvs
+
+extern "C" {
+
+const char* dvs_last_error(void) { return dvs::g_err; }
+
+int32_t dvs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap) {
+  DVS_ARG(buf && cap > 0);
+  buf[0] = 0;
+  DVS_TRY(dvs::check_device(device));
+  hipDeviceProp_t p;
+  DVS_HIP(hipGetDeviceProperties(&p, device));
+  snprintf(buf, cap, "%s", p.gcnArchName);
+  return DVS_OK;
+}
+
+dvs_status dvs_malloc(int32_t device, size_t bytes, void** out) {
+  DVS_ARG(out);
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return DVS_OK;
+}
+dvs_status dvs_free(int32_t device, void* p) {
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipFree(p));
+  return DVS_OK;
+}
+dvs_status dvs_memcpy_h2d(int32_t device, void* dst, const void* src, size_t bytes) {
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return DVS_OK;
+}
+dvs_status dvs_memcpy_d2h(int32_t device, void* dst, const void* src, size_t bytes) {
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return DVS_OK;
+}
+dvs_status dvs_memset(int32_t device, void* dst, int value, size_t bytes) {
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipMemset(dst, value, bytes));
+  return DVS_OK;
+}
+}

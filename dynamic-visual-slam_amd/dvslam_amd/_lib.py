@@ -1,0 +1,143 @@
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO_PATH = os.path.join(_PKG, "lib", "libdvslam_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+STATUS = {0: "DVS_OK", -1: "DVS_ERR_EMPTY", -2: "DVS_ERR_UNSUPPORTED", -3: "DVS_ERR_CAPACITY", -4: "DVS_ERR_HIP",
+          -5: "DVS_ERR_NO_DEVICE", -6: "DVS_ERR_ARG"}
+
+
+class DvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
+                ("min_th_fast", C.c_int32), ("gauss_kernel", C.c_int32 * 7), ("max_batch", C.c_int32)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("termination", C.c_int32), ("num_successful_steps", C.c_int32), ("num_iterations", C.c_int32),
+                ("reserved", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+def build_library():
+    """(re)build lib/libdvslam_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", _PKG])
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raise loudly if it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} not found: build it with `make -C {_PKG}` (hipcc --offload-arch=gfx950); "
+                           "dvslam_amd has no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    vp, i32, sz, dbl = C.c_void_p, C.c_int32, C.c_size_t, C.c_double
+    L.dvs_last_error.restype = C.c_char_p
+    L.dvs_device_count.restype = i32
+    L.dvs_device_arch.argtypes = [i32, C.c_char_p, i32]
+    L.dvs_malloc.argtypes = [i32, sz, C.POINTER(vp)]
+    L.dvs_free.argtypes = [i32, vp]
+    L.dvs_memcpy_h2d.argtypes = [i32, vp, vp, sz]
+    L.dvs_memcpy_d2h.argtypes = [i32, vp, vp, sz]
+    L.dvs_memset.argtypes = [i32, vp, C.c_int, sz]
+    L.dvs_orb_create.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
+    L.dvs_orb_destroy.argtypes = [vp]; L.dvs_orb_destroy.restype = None
+    L.dvs_orb_max_keypoints.argtypes = [vp]
+    L.dvs_orb_set_stream.argtypes = [vp, vp]
+    L.dvs_orb_get_stream.argtypes = [vp]; L.dvs_orb_get_stream.restype = vp
+    L.dvs_orb_synchronize.argtypes = [vp]
+    L.dvs_orb_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.dvs_orb_level_size.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.dvs_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
+    L.dvs_orb_extract_batch.argtypes = [vp, vp, i32, i32, i32, sz, vp, vp, i32, vp]
+    L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
+    L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
+    L.dvs_orb_get_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_orb_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_orb_enable_stage_timing.argtypes = [vp, i32]
+    L.dvs_orb_get_stage_times.argtypes = [vp, vp, vp, i32]
+    L.dvs_matcher_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_matcher_destroy.argtypes = [vp]; L.dvs_matcher_destroy.restype = None
+    L.dvs_matcher_set_stream.argtypes = [vp, vp]
+    L.dvs_matcher_synchronize.argtypes = [vp]
+    L.dvs_match_hamming.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.dvs_match_hamming_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
+    L.dvs_match_hamming_thresh.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
+    L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
+    L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "dvs_ba_create"):
+        L.dvs_ba_create.argtypes = [i32, C.POINTER(vp)]
+        L.dvs_ba_destroy.argtypes = [vp]; L.dvs_ba_destroy.restype = None
+        L.dvs_ba_set_stream.argtypes = [vp, vp]
+        L.dvs_ba_synchronize.argtypes = [vp]
+        L.dvs_ba_set_problem.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl]
+        L.dvs_ba_evaluate.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.dvs_ba_evaluate_raw.argtypes = [vp, vp, vp, vp, vp]
+        L.dvs_ba_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.dvs_ba_evaluate_device.argtypes = [vp, i32]
+        L.dvs_ba_solve.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(BaSummary)]
+        L.dvs_ba_get_parameters.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise DvsError(code, lib().dvs_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return lib().dvs_device_count()
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """Raw HBM allocation through the C-ABI (keeps tests/bench free of any torch dependency)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        check(lib().dvs_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib().dvs_memcpy_h2d(self.device, self.ptr, ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().dvs_memcpy_d2h(self.device, ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().dvs_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

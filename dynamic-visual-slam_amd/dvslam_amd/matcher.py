@@ -1,0 +1,53 @@
+import ctypes as C
+import numpy as np
+from ._lib import lib, check, ptr
+
+
+class BFMatcher:
+    """Python mirror of cv::BFMatcher(cv::NORM_HAMMING, crossCheck=false) as the reference uses it
+    (frontend.cpp:220,614,1123; backend.cpp:222,1072).  match(query, train) returns one
+    (queryIdx=i, trainIdx, distance) per query row as two int32 arrays (trainIdx, distance)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.dvs_matcher_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dvs_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        idx = np.zeros(len(q), np.int32); dist = np.zeros(len(q), np.int32)
+        if len(t) == 0:  # cv: empty train -> empty result
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        check(self._L.dvs_match_hamming(self._h, ptr(q), len(q), ptr(t), len(t), ptr(idx), ptr(dist)))
+        return idx, dist
+
+    def match_thresh(self, query, train, max_dist, cap=None):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        cap = cap if cap is not None else max(len(q) * len(t), 1)
+        pairs = np.zeros((cap, 3), np.int32)
+        n = C.c_int32()
+        check(self._L.dvs_match_hamming_thresh(self._h, ptr(q), len(q), ptr(t), len(t), max_dist, ptr(pairs), cap, C.byref(n)))
+        return n.value, pairs[:min(n.value, cap)].copy()
+
+    def match_batch_device(self, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows, npairs, d_idx, d_dist):
+        check(self._L.dvs_match_hamming_batch_device(self._h, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows, npairs, d_idx, d_dist))
+
+    def set_stream(self, stream_ptr):
+        check(self._L.dvs_matcher_set_stream(self._h, stream_ptr))
+
+    def synchronize(self):
+        check(self._L.dvs_matcher_synchronize(self._h))

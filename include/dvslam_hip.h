@@ -1,0 +1,184 @@
+/*
+ * dvslam_hip.h — C-ABI of libdvslam_hip.so: MI355X (gfx950) implementation of the data-parallel hot
+ * path of andrewkwolek/dynamic-visual-slam.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference has no FFI/plugin layer: its hot path is reached through three C++ call signatures
+ * (SURVEY.md §8b).  Each group of entry points below replaces one of them; header-only C++ adapters
+ * with the reference's own signatures live in include/dvslam/ (see INTEGRATION.md).
+ *
+ *   B1  ORB_SLAM3::ORBextractor::ORBextractor / operator()   include/dynamic_visual_slam/ORBextractor.hpp:50-60,
+ *                                                            src/ORBextractor.cpp:409-469, 1086-1167
+ *   B2  cv::BFMatcher(NORM_HAMMING).match call sites          src/frontend.cpp:220,614,1123; src/backend.cpp:222,1072
+ *   B3  SlidingWindowBA / WeightedSquaredReprojectionError    include/dynamic_visual_slam/bundle_adjustment.hpp:469-593, 652-904
+ *
+ * Conventions: every function returns a dvs_status (0 = ok, < 0 = error; dvs_last_error() gives text);
+ * nothing is allocated across the ABI — callers supply output buffers with explicit capacities;
+ * a handle owns one HIP stream and is not thread-safe, distinct handles are independent.
+ * "host" entry points take host pointers (they stage through pinned memory); "_device" entry points
+ * take pointers into the handle's GPU memory space and only enqueue work on the handle's stream.
+ */
+#ifndef DVSLAM_HIP_H
+#define DVSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t dvs_status;
+enum {
+  DVS_OK = 0,
+  DVS_ERR_EMPTY = -1,        /* empty image: ORBextractor::operator() returns -1 (ORBextractor.cpp:1090-1091) */
+  DVS_ERR_UNSUPPORTED = -2,  /* image size / parameters for which the reference divides by zero (nCols, nIni == 0) */
+  DVS_ERR_CAPACITY = -3,     /* caller buffer too small */
+  DVS_ERR_HIP = -4,          /* HIP runtime error (message in dvs_last_error) */
+  DVS_ERR_NO_DEVICE = -5,    /* no gfx950 device visible: there is NO CPU fallback */
+  DVS_ERR_ARG = -6           /* null pointer / negative size / bad enum */
+};
+
+const char* dvs_last_error(void);
+int32_t dvs_device_count(void);
+/* "gfx950" etc. for the given device, "" on error */
+dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap);
+
+/* ---- device memory / stream helpers so non-HIP hosts (tests, bench) can stay resident in HBM ---- */
+dvs_status dvs_malloc(int32_t device, size_t bytes, void** out);
+dvs_status dvs_free(int32_t device, void* p);
+dvs_status dvs_memcpy_h2d(int32_t device, void* dst, const void* src, size_t bytes);
+dvs_status dvs_memcpy_d2h(int32_t device, void* dst, const void* src, size_t bytes);
+dvs_status dvs_memset(int32_t device, void* dst, int value, size_t bytes);
+
+/* ======================================= B1: ORB extractor ===================================== */
+
+typedef struct dvs_orb dvs_orb;
+
+/* same field order and size (28 B) as cv::KeyPoint */
+typedef struct dvs_keypoint {
+  float x, y;       /* level-0 pixel coordinates (level coords * mvScaleFactor[octave], ORBextractor.cpp:1148-1150) */
+  float size;       /* (int)(31 * mvScaleFactor[octave]) (ORBextractor.cpp:880,889) */
+  float angle;      /* degrees in [0,360), intensity-centroid orientation (ORBextractor.cpp:76-103) */
+  float response;   /* FAST-9/16 corner score */
+  int32_t octave;   /* pyramid level */
+  int32_t class_id; /* -1 */
+} dvs_keypoint;
+
+typedef struct dvs_orb_params {
+  int32_t nfeatures;        /* ORBextractor ctor arg 1 (frontend.cpp:206: 1000) */
+  float scale_factor;       /* arg 2 (1.2f) */
+  int32_t nlevels;          /* arg 3 (8); 1..DVS_MAX_LEVELS */
+  int32_t ini_th_fast;      /* arg 4 (20) */
+  int32_t min_th_fast;      /* arg 5 (7) */
+  int32_t gauss_kernel[7];  /* Q8 7-tap kernel of cv::GaussianBlur(7x7, sigma 2); all zeros = {18,34,48,56,48,34,18} */
+  int32_t max_batch;        /* frames processed per launch sequence; 0 = 1 */
+} dvs_orb_params;
+
+#define DVS_MAX_LEVELS 16
+
+dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out);
+void dvs_orb_destroy(dvs_orb* h);
+/* capacity a caller must provide per frame: nfeatures + 3 * nlevels (a level may return quota + 2, ORBextractor.cpp:746-747) */
+int32_t dvs_orb_max_keypoints(const dvs_orb* h);
+/* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the handle's own; NULL restores it */
+dvs_status dvs_orb_set_stream(dvs_orb* h, void* hip_stream);
+void* dvs_orb_get_stream(dvs_orb* h);
+dvs_status dvs_orb_synchronize(dvs_orb* h);
+
+/* float tables of the ctor (ORBextractor.cpp:414-445, 451-468); arrays of nlevels (umax: 16) entries, any may be NULL */
+dvs_status dvs_orb_get_tables(const dvs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                              int32_t* features_per_level, int32_t* umax16);
+dvs_status dvs_orb_level_size(const dvs_orb* h, int32_t rows, int32_t cols, int32_t level, int32_t* level_rows, int32_t* level_cols);
+
+/* operator(): host image (8UC1, `step` bytes between rows) -> host keypoints + N x 32 descriptors.  *n_out = N. */
+dvs_status dvs_orb_extract(dvs_orb* h, const uint8_t* gray, int32_t rows, int32_t cols, size_t step,
+                           dvs_keypoint* kps, uint8_t* desc, int32_t capacity, int32_t* n_out);
+/* nimg host images of identical size; outputs are [nimg][capacity] blocks, n_out[nimg] */
+dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                 dvs_keypoint* kps, uint8_t* desc, int32_t capacity, int32_t* n_out);
+/* device-resident batch: frame f starts at d_imgs + f * frame_stride.  Asynchronous on the handle's stream. */
+dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols,
+                                        size_t step, size_t frame_stride, dvs_keypoint* d_kps, uint8_t* d_desc,
+                                        int32_t capacity, int32_t* d_n_out);
+
+/* parity introspection of the LAST extract call (mvImagePyramid is a public member, ORBextractor.hpp:84) */
+dvs_status dvs_orb_get_level(dvs_orb* h, int32_t frame, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes);
+/* FAST candidates handed to the quad-tree, in candidate order: int32 triplets (x, y, score), region-relative */
+dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n);
+/* per-level keypoints after the quad-tree, level coordinates: int32 triplets (x, y, score) in list order */
+dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n);
+
+/* per-stage GPU timing with hipEvents on the handle's stream (bench.py roofline).  Stage ids below. */
+enum { DVS_STAGE_PYRAMID = 0, DVS_STAGE_FAST = 1, DVS_STAGE_OCTREE = 2, DVS_STAGE_BLUR = 3, DVS_STAGE_DESCRIBE = 4, DVS_STAGE_COUNT = 5 };
+dvs_status dvs_orb_enable_stage_timing(dvs_orb* h, int32_t on);
+/* accumulated milliseconds and launch-sequence counts per stage since the last reset; synchronises the stream */
+dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32_t reset);
+
+/* ======================================= B2: Hamming matcher =================================== */
+
+typedef struct dvs_matcher dvs_matcher;
+dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out);
+void dvs_matcher_destroy(dvs_matcher* m);
+dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* hip_stream);
+dvs_status dvs_matcher_synchronize(dvs_matcher* m);
+
+/* BFMatcher(NORM_HAMMING).match(query, train): per query row the arg-min Hamming distance over train rows,
+ * lowest train index on ties; train_idx = -1 and dist = INT32_MAX when nt == 0.  Rows are 32 bytes. Host pointers. */
+dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,
+                             int32_t* train_idx, int32_t* dist);
+/* npairs independent jobs, device-resident: job p uses rows [0, d_nq[p]) of d_q + p*q_stride_rows*32 against rows
+ * [0, d_nt[p]) of d_t + p*t_stride_rows*32; outputs at d_idx/d_dist + p*q_stride_rows.  Asynchronous. */
+dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, const int32_t* d_nq, int32_t q_stride_rows,
+                                          const uint8_t* d_t, const int32_t* d_nt, int32_t t_stride_rows, int32_t npairs,
+                                          int32_t* d_idx, int32_t* d_dist);
+/* backend.cpp:1068-1077 shape: every (query, train) pair with distance < max_dist, (query, train)-ordered int32
+ * triplets (q, t, dist).  *n_pairs = total found (may exceed cap; only the first cap are written). Host pointers. */
+dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,
+                                    int32_t max_dist, int32_t* pairs, int32_t cap, int32_t* n_pairs);
+
+/* ======================================= B3: bundle adjustment ================================= */
+
+typedef struct dvs_ba dvs_ba;
+
+typedef struct dvs_ba_summary {
+  int32_t termination;          /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE (ceres::TerminationType order) */
+  int32_t num_successful_steps; /* OptimizationResult::iterations_completed (bundle_adjustment.hpp:862) */
+  int32_t num_iterations;
+  int32_t reserved;
+  double initial_cost, final_cost;
+} dvs_ba_summary;
+
+dvs_status dvs_ba_create(int32_t device, dvs_ba** out);
+void dvs_ba_destroy(dvs_ba* h);
+dvs_status dvs_ba_set_stream(dvs_ba* h, void* hip_stream);
+dvs_status dvs_ba_synchronize(dvs_ba* h);
+
+/* Problem in the optimiser's parameterisation (bundle_adjustment.hpp:92-165): K poses = world->camera quaternion
+ * (w,x,y,z) + translation, L landmarks, R observations (cam_idx, lm_idx, uv).  pose_fixed / lm_fixed: 1 = constant block
+ * (bundle_adjustment.hpp:781-785, 795-797).  Intrinsics and sigma exactly as passed (no sanity checks: backend.cpp:180). */
+dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const double* t, int32_t L, const double* X,
+                              int32_t R, const int32_t* cam_idx, const int32_t* lm_idx, const double* uv,
+                              const uint8_t* pose_fixed, const uint8_t* lm_fixed,
+                              double fx, double fy, double cx, double cy, double sigma_pixels, double huber_delta);
+/* one evaluation at the current parameters: robustified cost 0.5*sum(rho), and (each nullable) loss-corrected residuals
+ * R x 2, local pose Jacobians R x 2 x 6 (rotation tangent first, then translation), landmark Jacobians R x 2 x 3,
+ * gradient (6K + 3L, fixed blocks zero).  Host output pointers. */
+dvs_status dvs_ba_evaluate(dvs_ba* h, double* cost, double* residuals, double* J_pose, double* J_lm, double* grad);
+/* raw (un-robustified) functor outputs as ceres::CostFunction::Evaluate delivers them: residuals R x 2, jacobians
+ * wrt q (R x 2 x 4), t (R x 2 x 3), X (R x 2 x 3), row-major; any may be NULL. */
+dvs_status dvs_ba_evaluate_raw(dvs_ba* h, double* residuals, double* J_q, double* J_t, double* J_X);
+/* Gauss-Newton blocks: H_pp K x 6 x 6, H_ll L x 3 x 3, W R x 6 x 3 (pose-landmark block per observation), g (6K + 3L) */
+dvs_status dvs_ba_normal_equations(dvs_ba* h, double* H_pp, double* H_ll, double* W, double* g, double* cost);
+/* `iters` back-to-back evaluations (residuals + Jacobians + loss + reductions) with nothing copied to the host; for
+ * throughput measurement.  Asynchronous. */
+dvs_status dvs_ba_evaluate_device(dvs_ba* h, int32_t iters);
+/* Levenberg-Marquardt + Schur complement with the trust-region schedule of ceres::Solve as configured at
+ * bundle_adjustment.hpp:839-847.  Parameters are updated in place; read them back with dvs_ba_get_parameters. */
+dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double function_tolerance, double gradient_tolerance,
+                        double parameter_tolerance, dvs_ba_summary* summary);
+dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVSLAM_HIP_H */

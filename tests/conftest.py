@@ -1,0 +1,35 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamic-visual-slam_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_bindings
+    oracle_bindings.build()
+    return oracle_bindings
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    """The HIP library must exist and load; GPU tests additionally need a device (no fallback)."""
+    from dvslam_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build_library()
+    return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def gpu(hiplib):
+    from dvslam_amd import device_count
+    n = device_count()
+    assert n >= 1, "no HIP device visible: -m gpu tests must run on the MI355X box (there is no CPU fallback)"
+    return n

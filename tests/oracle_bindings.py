@@ -1,0 +1,137 @@
+"""ctypes bindings to oracle/_build/liboracle.so — the CPU restatement of the reference path.
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "_build", "liboracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def lib():
+    global _lib
+    try:
+        return _lib
+    except NameError:
+        pass
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orc_orb_create.restype = vp; L.orc_orb_create.argtypes = [i32, f32, i32, i32, i32]
+    L.orc_orb_destroy.argtypes = [vp]
+    L.orc_orb_set_gauss_kernel.argtypes = [vp, vp]
+    L.orc_orb_extract.restype = i32; L.orc_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32]
+    L.orc_orb_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orc_orb_level_size.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.orc_orb_get_level.restype = i32; L.orc_orb_get_level.argtypes = [vp, i32, i32, vp, i32]
+    L.orc_orb_get_candidates.restype = i32; L.orc_orb_get_candidates.argtypes = [vp, i32, vp, i32]
+    L.orc_orb_get_level_keypoints.restype = i32; L.orc_orb_get_level_keypoints.argtypes = [vp, i32, vp, i32]
+    L.orc_resize_linear_u8.argtypes = [vp, i32, i32, sz, vp, i32, i32, sz]
+    L.orc_fast.restype = i32; L.orc_fast.argtypes = [vp, i32, i32, sz, i32, vp, i32]
+    L.orc_gauss7.argtypes = [vp, i32, i32, vp, vp]
+    L.orc_fast_atan2.restype = f32; L.orc_fast_atan2.argtypes = [f32, f32]
+    L.orc_ic_angle.restype = f32; L.orc_ic_angle.argtypes = [vp, sz, f32, f32]
+    L.orc_descriptor.argtypes = [vp, sz, f32, f32, f32, vp]
+    L.orc_distribute.restype = i32; L.orc_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    L.orc_std_sort_nodes.argtypes = [vp, vp, i32, vp]
+    L.orc_brief_pattern.restype = C.POINTER(C.c_int8)
+    L.orc_sincosf.argtypes = [f32, vp, vp]
+    L.orc_match_hamming.argtypes = [vp, i32, vp, i32, i32, vp, vp]
+    L.orc_match_hamming256.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.orc_match_hamming_thresh.restype = i32; L.orc_match_hamming_thresh.argtypes = [vp, i32, vp, i32, i32, vp, i32]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleORB:
+    """Mirror of ORB_SLAM3::ORBextractor (ORBextractor.hpp:44-110) on the CPU oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.h = self.L.orc_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        try:
+            self.L.orc_orb_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_gauss_kernel(self, k7):
+        k = np.asarray(k7, dtype=np.int32); assert k.size == 7
+        self.L.orc_orb_set_gauss_kernel(self.h, _p(k))
+
+    def tables(self):
+        n = self.nlevels
+        s = np.zeros(n, np.float32); inv = np.zeros(n, np.float32); f = np.zeros(n, np.int32); um = np.zeros(16, np.int32)
+        self.L.orc_orb_tables(self.h, _p(s), _p(inv), _p(f), _p(um))
+        return s, inv, f, um
+
+    def level_size(self, cols, rows, level):
+        w = C.c_int(); h = C.c_int()
+        self.L.orc_orb_level_size(self.h, cols, rows, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def extract(self, img):
+        """returns (keypoints structured array, descriptors N x 32 uint8) or raises on error code"""
+        img = np.asarray(img)
+        rows, cols = (img.shape if img.size else (0, 0))
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        step = img.strides[0] if img.size else 0
+        n = self.L.orc_orb_extract(self.h, _p(img) if img.size else None, rows, cols, step, _p(kps), _p(desc), cap)
+        if n < 0:
+            return n, None, None
+        self._shape = (rows, cols)
+        return n, kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l, blurred=False):
+        rows, cols = self._shape
+        w, h = self.level_size(cols, rows, l)
+        buf = np.zeros((h, w), np.uint8)
+        n = self.L.orc_orb_get_level(self.h, l, int(blurred), _p(buf), buf.size)
+        return buf if n == buf.size else None
+
+    def candidates(self, l):
+        cap = 1 << 20
+        buf = np.zeros((cap, 3), np.int32)
+        n = self.L.orc_orb_get_candidates(self.h, l, _p(buf), cap)
+        assert n >= 0
+        return buf[:n].copy()
+
+    def level_keypoints(self, l):
+        cap = self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        n = self.L.orc_orb_get_level_keypoints(self.h, l, _p(kps), cap)
+        assert n >= 0
+        return kps[:n].copy()
+
+
+def match(q, t):
+    """cv::BFMatcher(NORM_HAMMING).match restatement -> (train_idx int32[nq], dist int32[nq])"""
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros(len(q), np.int32); d = np.zeros(len(q), np.int32)
+    lib().orc_match_hamming(_p(q), len(q), _p(t), len(t), q.shape[1] if q.ndim == 2 else 32, _p(idx), _p(d))
+    return idx, d
+
+
+def match_thresh(q, t, max_dist, cap=None):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    cap = cap if cap is not None else max(len(q) * len(t), 1)
+    pairs = np.zeros((cap, 3), np.int32)
+    n = lib().orc_match_hamming_thresh(_p(q), len(q), _p(t), len(t), max_dist, _p(pairs), cap)
+    return n, pairs[:min(n, cap)].copy()

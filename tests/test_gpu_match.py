@@ -1,0 +1,83 @@
+"""GPU parity: HIP Hamming matcher (C-ABI) vs the oracle restatement of cv::BFMatcher::match — bit exact."""
+import os
+import numpy as np
+import pytest
+from dvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 700), (63, 64), (64, 3), (65, 129), (300, 257), (2000, 2000), (2024, 1999), (5000, 4097)])
+def test_match_parity(gpu, oracle, nq, nt):
+    from dvslam_amd import BFMatcher
+    q = synth.make_descriptors(nq, 100 + nq); t = synth.make_descriptors(nt, 200 + nt)
+    if nt > 10 and nq > 3:                      # exact duplicates and near-duplicates: ties -> lowest train index
+        t[7] = q[2]; t[3] = q[2]; t[nt - 1] = q[2]
+        t[5] = q[1]; t[5, 0] ^= 1; t[9] = q[1]; t[9, 31] ^= 128
+    m = BFMatcher()
+    idx, d = m.match(q, t)
+    idx2, d2 = oracle.match(q, t)
+    assert (idx == idx2).all() and (d == d2).all()
+
+
+def test_golden_fixture(gpu):
+    from dvslam_amd import BFMatcher
+    g = np.load(os.path.join(GOLD, "match_300x257.npz"))
+    idx, d = BFMatcher().match(g["q"], g["t"])
+    assert (idx == g["idx"]).all() and (d == g["dist"]).all()
+    assert idx[3] == 5 and d[3] == 0            # duplicate rows 5 and 100 -> lowest index
+
+
+def test_empty_inputs(gpu):
+    from dvslam_amd import BFMatcher
+    m = BFMatcher()
+    q = synth.make_descriptors(10, 1)
+    idx, d = m.match(q, np.zeros((0, 32), np.uint8))
+    assert len(idx) == 0                         # empty train -> empty result (cv::BFMatcher)
+    idx, d = m.match(np.zeros((0, 32), np.uint8), q)
+    assert len(idx) == 0
+
+
+def test_properties_full_size(gpu):
+    from dvslam_amd import BFMatcher
+    m = BFMatcher()
+    q = synth.make_descriptors(2000, 11)
+    idx, d = m.match(q, q)                       # self match: identity, distance 0
+    assert (idx == np.arange(2000)).all() and (d == 0).all()
+    perm = np.random.default_rng(3).permutation(2000)
+    idx, d = m.match(q, q[perm])                 # permuted train: inverse permutation
+    assert (perm[idx] == np.arange(2000)).all() and (d == 0).all()
+    t = synth.make_descriptors(2000, 12)
+    idx, d = m.match(q, t)
+    x = np.unpackbits(q[:50, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    assert (d[:50] == x.min(axis=1)).all() and (idx[:50] == x.argmin(axis=1)).all()
+
+
+@pytest.mark.parametrize("nq,nt,thr", [(1, 1, 50), (40, 3000, 100), (500, 700, 110), (300, 300, 257)])
+def test_thresh_parity(gpu, oracle, nq, nt, thr):
+    """backend association shape (backend.cpp:1068-1077): all pairs with distance < thr"""
+    from dvslam_amd import BFMatcher
+    q = synth.make_descriptors(nq, 5); t = synth.make_descriptors(nt, 6)
+    t[0] = q[0]
+    n, pairs = BFMatcher().match_thresh(q, t, thr)
+    n2, pairs2 = oracle.match_thresh(q, t, thr)
+    assert n == n2 and (pairs == pairs2).all()
+
+
+def test_batch_device(gpu, oracle):
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    P, S = 4, 520
+    nq = np.array([500, 520, 1, 333], np.int32); nt = np.array([520, 17, 400, 333], np.int32)
+    Q = np.stack([synth.make_descriptors(S, 30 + p) for p in range(P)]); T = np.stack([synth.make_descriptors(S, 40 + p) for p in range(P)])
+    dq = DeviceBuffer(Q.nbytes).upload(Q); dt = DeviceBuffer(T.nbytes).upload(T)
+    dnq = DeviceBuffer(16).upload(nq); dnt = DeviceBuffer(16).upload(nt)
+    di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
+    m.match_batch_device(dq.ptr, dnq.ptr, S, dt.ptr, dnt.ptr, S, P, di.ptr, dd.ptr)
+    m.synchronize()
+    idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
+    for p in range(P):
+        i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
+        assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all()

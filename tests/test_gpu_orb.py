@@ -1,0 +1,143 @@
+"""GPU parity: HIP extractor (through the C-ABI) vs the CPU oracle, stage by stage and end to end.
+Bar: bit-exact — pyramid bytes, blurred bytes, candidate lists (order included), per-level quad-tree
+output (order included), final keypoints (all 7 fields, float bits) and 256-bit descriptors."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from dvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pair(oracle, nf, nl, **kw):
+    from dvslam_amd import ORBextractor
+    return ORBextractor(nf, 1.2, nl, 20, 7, **kw), oracle.OracleORB(nf, 1.2, nl, 20, 7)
+
+
+def _assert_same_result(n, kps, desc, n2, kps2, desc2):
+    assert n == n2
+    for f in kps.dtype.names:
+        assert (kps[f].view(np.uint32) == kps2[f].view(np.uint32)).all(), f"keypoint field {f} differs"
+    assert (desc == desc2).all()
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl,frame", [(240, 320, 300, 5, 0), (480, 640, 500, 8, 1), (720, 1280, 2000, 8, 0),
+                                                   (360, 1000, 700, 6, 3), (600, 400, 1000, 7, 2)])
+def test_stage_and_end_to_end_parity(gpu, oracle, rows, cols, nf, nl, frame):
+    img = synth.make_frame(frame, cols=cols, rows=rows)
+    g, o = _pair(oracle, nf, nl)
+    n, kps, desc = g(img)
+    n2, kps2, desc2 = o.extract(img)
+    for l in range(nl):
+        assert (g.level(l) == o.level(l)).all(), f"pyramid level {l}"
+        assert (g.candidates(l) == o.candidates(l)).all() if len(o.candidates(l)) == len(g.candidates(l)) else False, f"candidates level {l}"
+        lk = o.level_keypoints(l)
+        ref = np.stack([lk["x"].astype(np.int32) - 16, lk["y"].astype(np.int32) - 16, lk["response"].astype(np.int32)], axis=1)
+        got = g.level_keypoints(l)
+        assert got.shape == ref.shape and (got == ref).all(), f"quad-tree level {l}"
+        if len(lk):
+            assert (g.level(l, blurred=True) == o.level(l, blurred=True)).all(), f"blurred level {l}"
+    _assert_same_result(n, kps, desc, n2, kps2, desc2)
+    g.close()
+
+
+def test_reference_frontend_configuration(gpu, oracle):
+    """extractor exactly as the frontend builds it: (1000, 1.2f, 8, 20, 7) on 1280x720 (frontend.cpp:205-211)"""
+    img = synth.make_frame(5)
+    g, o = _pair(oracle, 1000, 8)
+    _assert_same_result(*g(img), *o.extract(img))
+
+
+def test_golden_fixture(gpu):
+    meta = json.load(open(os.path.join(GOLD, "orb_320x240.json")))
+    img = synth.make_frame(meta["frame"], cols=320, rows=240, seed=meta["seed"])
+    assert hashlib.sha256(img.tobytes()).hexdigest() == meta["image_sha256"]
+    from dvslam_amd import ORBextractor
+    g = ORBextractor(meta["nfeatures"], 1.2, meta["nlevels"], 20, 7)
+    n, kps, desc = g(img)
+    gold = np.load(os.path.join(GOLD, "orb_320x240.npz"))
+    assert n == int(gold["n"]) and kps.tobytes() == gold["kps"].tobytes() and (desc == gold["desc"]).all()
+    for l in range(meta["nlevels"]):
+        assert (g.candidates(l) == gold[f"cand{l}"]).all()
+
+
+def test_empty_flat_and_error_behaviour(gpu, oracle):
+    from dvslam_amd import ORBextractor, DvsError
+    g = ORBextractor(500, 1.2, 8, 20, 7)
+    assert g(np.zeros((0, 0), np.uint8))[0] == -1                       # ORBextractor.cpp:1090-1091
+    n, kps, desc = g(np.full((480, 640), 128, np.uint8))                 # flat image: zero keypoints, descriptors released
+    assert n == 0 and len(kps) == 0 and desc.shape == (0, 32)
+    with pytest.raises(DvsError) as e:                                   # sizes where the reference divides by zero
+        g(np.zeros((120, 160), np.uint8))
+    assert e.value.code == -2
+    img = synth.make_frame(0, cols=640, rows=480)                        # handle still usable afterwards
+    _assert_same_result(*g(img), *oracle.OracleORB(500, 1.2, 8, 20, 7).extract(img))
+
+
+def test_threshold_fallback_cells(gpu, oracle):
+    """low-contrast image: most cells have no corner at 20 and fall back to 7 (ORBextractor.cpp:843-846)"""
+    img = synth.make_frame(0, cols=640, rows=480)
+    low = (100 + (img.astype(np.int32) - 128) // 6).astype(np.uint8)
+    g, o = _pair(oracle, 800, 8)
+    r = g(low); r2 = o.extract(low)
+    _assert_same_result(*r, *r2)
+    assert (r[1]["response"] < 20).any() and r[0] > 100
+
+
+def test_noncontiguous_step_and_repeat_determinism(gpu, oracle):
+    big = np.zeros((480, 700), np.uint8)
+    img = synth.make_frame(2, cols=640, rows=480)
+    big[:, 13:653] = img
+    view = big[:, 13:653]                     # step 700, unaligned origin
+    g, o = _pair(oracle, 500, 8)
+    a = g(view); b = g(np.ascontiguousarray(view)); c = o.extract(img)
+    _assert_same_result(*a, *b)
+    _assert_same_result(*a, *c)
+
+
+def test_batch_and_device_resident_paths(gpu, oracle):
+    from dvslam_amd import ORBextractor
+    from dvslam_amd._lib import DeviceBuffer, KP_DTYPE
+    rows, cols, nf = 480, 640, 500
+    frames = [synth.make_frame(t, cols=cols, rows=rows) for t in range(5)]
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=3)          # 5 frames through batches of 3 + 2
+    nout, kps, desc = g.extract_batch(frames)
+    o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
+    refs = [o.extract(f) for f in frames]
+    for i, (n2, k2, d2) in enumerate(refs):
+        _assert_same_result(int(nout[i]), kps[i, :nout[i]], desc[i, :nout[i]], n2, k2, d2)
+    # device-resident: frames already in HBM, outputs stay in HBM
+    cap = g.capacity
+    d_img = DeviceBuffer(3 * rows * cols).upload(np.stack(frames[:3]))
+    d_k = DeviceBuffer(3 * cap * 28); d_d = DeviceBuffer(3 * cap * 32); d_n = DeviceBuffer(3 * 4)
+    g.extract_batch_device(d_img.ptr, 3, rows, cols, cols, rows * cols, d_k.ptr, d_d.ptr, cap, d_n.ptr)
+    g.synchronize()
+    n3 = d_n.download(np.int32, 3); k3 = d_k.download(KP_DTYPE, 3 * cap).reshape(3, cap); dd = d_d.download(np.uint8, 3 * cap * 32).reshape(3, cap, 32)
+    for i in range(3):
+        _assert_same_result(int(n3[i]), k3[i, :n3[i]], dd[i, :n3[i]], *refs[i])
+
+
+def test_full_size_properties(gpu):
+    """BASELINE config 2 (1280x720, 2000 kp) through size-independent properties."""
+    from dvslam_amd import ORBextractor
+    g = ORBextractor(2000, 1.2, 8, 20, 7)
+    img = synth.make_frame(7)
+    n, kps, desc = g(img)
+    quota = g.features_per_level()
+    assert 1900 <= n <= 2024
+    for l in range(8):
+        m = kps["octave"] == l
+        assert m.sum() <= quota[l] + 2
+        w, h = g.level_size(720, 1280, l)
+        s = g.GetScaleFactors()[l]
+        assert (kps["x"][m] >= 19 * s).all() and (kps["x"][m] < (w - 19) * s).all()
+        assert (kps["y"][m] >= 19 * s).all() and (kps["y"][m] < (h - 19) * s).all()
+    assert (np.diff(kps["octave"]) >= 0).all()
+    n2, kps2, desc2 = g(img)                      # idempotence
+    _assert_same_result(n, kps, desc, n2, kps2, desc2)
+    # keypoints are distinct pixels per level
+    key = np.stack([kps["octave"], kps["x"].view(np.int32), kps["y"].view(np.int32)], axis=1)
+    assert len(np.unique(key, axis=0)) == n
