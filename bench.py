@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of ORB extract + Hamming match at 1280x720 / 2000 keypoints (BASELINE.json
+configs[1]) on N MI355X, with the roofline of the dominant kernel and the CPU oracle timed beside it.
+
+A step = one pass of the hot path over one batch of B synthetic frames already resident in HBM:
+pyramid -> FAST cells -> quad-tree -> blur -> orientation + rBRIEF for B frames, then B brute-force
+match jobs (frame t vs t-1).  N > 1: one process per GPU (torchrun), frames sharded contiguously over
+ranks, one RCCL all_gather of the boundary descriptor block per step (dvslam_amd/dist.py).
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dynamic-visual-slam_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+# algorithmic HBM bytes per 1280x720 frame, per stage (SURVEY.md §8d / BASELINE.md §3)
+STAGE_BYTES = {
+    "pyramid": 2_781_331 + 1_931_488,   # reads L0-L6, writes L1-L7
+    "fast": 2_853_088,                  # reads L0-L7 once
+    "octree": 0,                        # candidate lists only (cache resident, excluded from the headline)
+    "blur": 2_853_088 + 2_853_088,      # reads + writes L0-L7
+    "describe": 2000 * (28 + 32),       # keypoint + descriptor records
+}
+READ_BYTES_PER_FRAME = 8_487_507        # headline "HBM-read roofline" numerator
+HBM_PEAK = 8.0e12
+
+
+def cpu_baseline(frames, nfeatures, budget_s=12.0):
+    """oracle (CPU restatement of the reference path) timed on the host, single thread, bounded sample"""
+    import oracle_bindings as ob
+    o = ob.OracleORB(nfeatures, 1.2, 8, 20, 7)
+    L = ob.lib()
+    n, k, d = o.extract(frames[0])          # warm-up, also gives the first "previous" descriptors
+    prev = d
+    t0 = time.perf_counter()
+    done = 0
+    for f in frames[1:]:
+        n, k, d = o.extract(f)
+        idx = np.zeros(len(d), np.int32); dist = np.zeros(len(d), np.int32)
+        L.orc_match_hamming256(d.ctypes.data, len(d), prev.ctypes.data, len(prev), idx.ctypes.data, dist.ctypes.data)
+        prev = d
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames 1280x720 extract(2000kp)+match vs previous frame, oracle/ C++ -O2, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dvslam_amd
+    from dvslam_amd import synth
+    from dvslam_amd import dist as dvdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, cols, B = 720, 1280, args.batch
+    # synthetic sequence: this rank's shard of one global batch (distinct frames per rank)
+    frames_idx = list(dvdist.shard_range(world, rank, B))
+    uniq = min(B, 16)   # 16 distinct frames tiled over the batch keep start-up short; every frame is processed in full
+    host = [synth.make_frame(frames_idx[i % uniq] % 64, cols, rows) for i in range(uniq)]
+    d_img = torch.empty((B, rows, cols), dtype=torch.uint8, device=dev)
+    for i in range(B):
+        d_img[i].copy_(torch.from_numpy(host[i % uniq]))
+
+    orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
+    mat = dvslam_amd.BFMatcher(device=local)
+    cap = orb.capacity
+    tstream = torch.cuda.Stream(device=dev)          # every kernel, copy and collective of a step is ordered on this stream
+    torch.cuda.set_stream(tstream)
+    orb.set_stream(tstream.cuda_stream); mat.set_stream(tstream.cuda_stream)
+    # slot 0 = last frame of the previous (rank's or neighbour's) batch, slots 1..B = this step's frames
+    d_kps = torch.empty((B + 1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_idx = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((B, cap), dtype=torch.int32, device=dev)
+
+    def step():
+        orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
+                                 cap, d_n[1:].data_ptr())
+        mat.match_batch_device(d_desc[1].data_ptr(), d_n[1:].data_ptr(), cap, d_desc[0].data_ptr(), d_n[0:].data_ptr(), cap, B,
+                               d_idx.data_ptr(), d_dist.data_ptr())
+        # boundary exchange for the next step's first match job
+        bd, bn = dvdist.exchange_boundary(d_desc[B], d_n[B], cap)
+        d_desc[0].copy_(bd); d_n[0].copy_(bn)
+
+    for _ in range(args.warmup):
+        step()
+    orb.enable_stage_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    stage_ms, stage_calls = orb.stage_times()
+    orb.enable_stage_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_host = d_n.cpu().numpy()
+    matched = int((d_dist[:, :].cpu().numpy()[0, :n_host[1]] < 50).sum())
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        fps = total_frames / elapsed
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        dom_ms = stage_ms[dom] / max(stage_calls[dom], 1)
+        achieved = STAGE_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec ORB+match @1280x720x2000kp", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame "
+                                   "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[1]),
+                       "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
+            "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
+            "stage_ms_per_step": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
+            "gpu_ms_per_step_rank0": round(gpu_ms / args.steps, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]
+            out["cpu_baseline"] = cpu_baseline(cb_frames, args.nfeatures)
+            out["speedup_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

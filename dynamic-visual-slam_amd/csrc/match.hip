@@ -159,7 +159,13 @@ void dvs_matcher_destroy(dvs_matcher* m) {
 dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* s) {
   DVS_ARG(m);
   DVS_HIP(hipStreamSynchronize(m->stream));
-  m->stream = s ? (hipStream_t)s : m->own_stream;
+  m->stream = (hipStream_t)s;  // NULL = HIP's legacy default stream
+  return DVS_OK;
+}
+dvs_status dvs_matcher_use_own_stream(dvs_matcher* m) {
+  DVS_ARG(m);
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  m->stream = m->own_stream;
   return DVS_OK;
 }
 dvs_status dvs_matcher_synchronize(dvs_matcher* m) {

@@ -350,7 +350,13 @@ int32_t dvs_orb_max_keypoints(const dvs_orb* h) { return h ? h->prm.nfeatures + 
 dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
   DVS_ARG(h);
   DVS_HIP(hipStreamSynchronize(h->stream));
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  h->stream = (hipStream_t)s;  // NULL is a real stream: HIP's legacy default stream
+  return DVS_OK;
+}
+dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
+  DVS_ARG(h);
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  h->stream = h->own_stream;
   return DVS_OK;
 }
 void* dvs_orb_get_stream(dvs_orb* h) { return h ? (void*)h->stream : nullptr; }

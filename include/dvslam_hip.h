@@ -80,8 +80,10 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
 void dvs_orb_destroy(dvs_orb* h);
 /* capacity a caller must provide per frame: nfeatures + 3 * nlevels (a level may return quota + 2, ORBextractor.cpp:746-747) */
 int32_t dvs_orb_max_keypoints(const dvs_orb* h);
-/* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the handle's own; NULL restores it */
+/* enqueue on a caller-owned hipStream_t (e.g. torch's current stream) instead of the handle's own non-blocking
+ * stream; NULL selects HIP's legacy default stream.  dvs_orb_use_own_stream() switches back. */
 dvs_status dvs_orb_set_stream(dvs_orb* h, void* hip_stream);
+dvs_status dvs_orb_use_own_stream(dvs_orb* h);
 void* dvs_orb_get_stream(dvs_orb* h);
 dvs_status dvs_orb_synchronize(dvs_orb* h);
 
@@ -120,6 +122,7 @@ typedef struct dvs_matcher dvs_matcher;
 dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out);
 void dvs_matcher_destroy(dvs_matcher* m);
 dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* hip_stream);
+dvs_status dvs_matcher_use_own_stream(dvs_matcher* m);
 dvs_status dvs_matcher_synchronize(dvs_matcher* m);
 
 /* BFMatcher(NORM_HAMMING).match(query, train): per query row the arg-min Hamming distance over train rows,
