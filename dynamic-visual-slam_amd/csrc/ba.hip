@@ -1,0 +1,764 @@
+// ba.hip — sliding-window bundle-adjustment evaluation + solve (boundary B3, include/dvslam_hip.h).
+// Replaces, for reference include/dynamic_visual_slam/bundle_adjustment.hpp:
+//   WeightedSquaredReprojectionError::operator() + ceres::AutoDiffCostFunction<.,2,4,3,3>   :469-593
+//   ceres::HuberLoss(1.345) + corrector, ceres::EigenQuaternionManifold tangent projection      :777, :818
+//   ceres::Solve(LEVENBERG_MARQUARDT, SPARSE_SCHUR, ...) as configured at                      :839-851
+//
+// Device work (FP64, nothing here is a dense contraction -> no MFMA):
+//   k_ba_eval    one thread per observation, observations grouped by camera in chunks of <= 256:
+//                analytic d r / d(q,t,X) including the quaternion normalisation inside
+//                ceres::QuaternionRotatePoint, x the 4x3 plus-Jacobian of EigenQuaternionManifold on the
+//                raw (w,x,y,z) memory, Huber corrector; per-chunk fixed-order reduction of the camera's
+//                H_pp (21 unique) / g_p (6) / cost through wave shuffles + LDS  -> partials
+//   k_ba_reduce  thread per landmark walks its observations in fixed order (H_ll, g_l); one extra block
+//                folds the chunk partials per camera and the total cost in chunk order.
+// Every reduction has a fixed order, so cost / gradient are bit-reproducible run to run.
+// The LM driver runs on the host around those two launches (reduced camera system <= 6K x 6K).
+#include <float.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "common.h"
+
+namespace dvs {
+
+struct BaChunk { int cam, start, count, pad; };
+
+struct BaDev {
+  const double *q, *t, *X, *uv;
+  const int *cam, *lm;
+  const unsigned char *pose_fixed, *lm_fixed;
+  double fx, fy, cx, cy, inv_sigma, huber_a;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// flags: 1 = store residuals/Jacobians (local, loss-corrected), 2 = store W, 4 = store raw functor outputs
+__global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restrict__ chunks, int flags,
+                                                 double* __restrict__ res, double* __restrict__ Jp, double* __restrict__ Jl,
+                                                 double* __restrict__ W, double* __restrict__ partial,
+                                                 double* __restrict__ rawRes, double* __restrict__ rawJq,
+                                                 double* __restrict__ rawJt, double* __restrict__ rawJX) {
+  __shared__ double wred[4][28];
+  const BaChunk ch = chunks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int c = ch.cam;
+  const bool act = tid < ch.count;
+  const int p = ch.start + (act ? tid : 0);
+  // camera block is uniform over the workgroup
+  const double q0 = P.q[4 * c], q1 = P.q[4 * c + 1], q2 = P.q[4 * c + 2], q3 = P.q[4 * c + 3];
+  const double t0 = P.t[3 * c], t1 = P.t[3 * c + 1], t2 = P.t[3 * c + 2];
+  const int l = P.lm[p];
+  const double X0 = P.X[3 * l], X1 = P.X[3 * l + 1], X2 = P.X[3 * l + 2];
+  // ceres::QuaternionRotatePoint: normalise, then p = X + u0*uv + u_v x uv with uv = 2 (u_v x X)
+  const double s = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  const double u0 = s * q0, u1 = s * q1, u2 = s * q2, u3 = s * q3;
+  double uv0 = u2 * X2 - u3 * X1, uv1 = u3 * X0 - u1 * X2, uv2 = u1 * X1 - u2 * X0;
+  uv0 += uv0; uv1 += uv1; uv2 += uv2;
+  double pc0 = X0 + u0 * uv0, pc1 = X1 + u0 * uv1, pc2 = X2 + u0 * uv2;
+  pc0 += u2 * uv2 - u3 * uv1; pc1 += u3 * uv0 - u1 * uv2; pc2 += u1 * uv1 - u2 * uv0;
+  pc0 += t0; pc1 += t1; pc2 += t2;
+
+  double r[2] = {0, 0};
+  double jq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, jt[6] = {0, 0, 0, 0, 0, 0}, jx[6] = {0, 0, 0, 0, 0, 0};
+  if (act && !(pc2 <= 0.1)) {  // bundle_adjustment.hpp:545-550: residual 0 and (autodiff) zero Jacobians otherwise
+    const double iz = 1.0 / pc2;
+    // ceres::Jet division is f.a * (1 / g.a); a cost-only evaluation (no Jacobians requested) runs the functor on plain
+    // doubles and divides.  The two differ in the last bit, and Ceres' step test compares exactly these two values.
+    const bool jets = flags != 0;
+    const double px = (jets ? (P.fx * pc0) * iz : P.fx * pc0 / pc2) + P.cx;
+    const double py = (jets ? (P.fy * pc1) * iz : P.fy * pc1 / pc2) + P.cy;
+    r[0] = P.inv_sigma * (px - P.uv[2 * p]);
+    r[1] = P.inv_sigma * (py - P.uv[2 * p + 1]);
+    // d r / d p_c
+    const double a00 = P.inv_sigma * P.fx * iz, a02 = -P.inv_sigma * P.fx * pc0 * iz * iz;
+    const double a11 = P.inv_sigma * P.fy * iz, a12 = -P.inv_sigma * P.fy * pc1 * iz * iz;
+    jt[0] = a00; jt[1] = 0; jt[2] = a02; jt[3] = 0; jt[4] = a11; jt[5] = a12;
+    // d p_c / d X = R(u)
+    const double R00 = 1 - 2 * (u2 * u2 + u3 * u3), R01 = 2 * (u1 * u2 - u0 * u3), R02 = 2 * (u1 * u3 + u0 * u2);
+    const double R10 = 2 * (u1 * u2 + u0 * u3), R11 = 1 - 2 * (u1 * u1 + u3 * u3), R12 = 2 * (u2 * u3 - u0 * u1);
+    const double R20 = 2 * (u1 * u3 - u0 * u2), R21 = 2 * (u2 * u3 + u0 * u1), R22 = 1 - 2 * (u1 * u1 + u2 * u2);
+    jx[0] = a00 * R00 + a02 * R20; jx[1] = a00 * R01 + a02 * R21; jx[2] = a00 * R02 + a02 * R22;
+    jx[3] = a11 * R10 + a12 * R20; jx[4] = a11 * R11 + a12 * R21; jx[5] = a11 * R12 + a12 * R22;
+    // d p_c / d u  (3 x 4): column 0 = uv ; columns 1..3 = -2 u0 [X]x + 2 (u_v . X) I + 2 u_v X^T - 4 X u_v^T
+    const double dX = u1 * X0 + u2 * X1 + u3 * X2;
+    double D[3][4];
+    D[0][0] = uv0; D[1][0] = uv1; D[2][0] = uv2;
+    const double uvv[3] = {u1, u2, u3}, Xv[3] = {X0, X1, X2};
+    // [X]x = [[0,-X2,X1],[X2,0,-X0],[-X1,X0,0]]
+    const double Xx[3][3] = {{0, -X2, X1}, {X2, 0, -X0}, {-X1, X0, 0}};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        D[i][1 + j] = -2 * u0 * Xx[i][j] + (i == j ? 2 * dX : 0.0) + 2 * uvv[i] * Xv[j] - 4 * Xv[i] * uvv[j];
+    // chain through u = q / |q| : d u / d q = s (I - u u^T)
+    const double uu[4] = {u0, u1, u2, u3};
+    double Dq[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double du = D[i][0] * u0 + D[i][1] * u1 + D[i][2] * u2 + D[i][3] * u3;
+#pragma unroll
+      for (int j = 0; j < 4; j++) Dq[i][j] = s * (D[i][j] - du * uu[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      jq[j] = a00 * Dq[0][j] + a02 * Dq[2][j];
+      jq[4 + j] = a11 * Dq[1][j] + a12 * Dq[2][j];
+    }
+  }
+  if (act && (flags & 4)) {
+    if (rawRes) { rawRes[2 * p] = r[0]; rawRes[2 * p + 1] = r[1]; }
+    if (rawJq) for (int i = 0; i < 8; i++) rawJq[8 * p + i] = jq[i];
+    if (rawJt) for (int i = 0; i < 6; i++) rawJt[6 * p + i] = jt[i];
+    if (rawJX) for (int i = 0; i < 6; i++) rawJX[6 * p + i] = jx[i];
+  }
+  // tangent projection: J_rot = J_q (2x4) * PlusJacobian(4x3) of EigenQuaternionManifold evaluated on raw memory
+  // x = (q0,q1,q2,q3) read as (x,y,z,w):  [ x3, x2,-x1; -x2, x3, x0; x1,-x0, x3; -x0,-x1,-x2 ]
+  double jp[12];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double* a = &jq[4 * k];
+    jp[6 * k + 0] = a[0] * q3 - a[1] * q2 + a[2] * q1 - a[3] * q0;
+    jp[6 * k + 1] = a[0] * q2 + a[1] * q3 - a[2] * q0 - a[3] * q1;
+    jp[6 * k + 2] = -a[0] * q1 + a[1] * q0 + a[2] * q3 - a[3] * q2;
+    jp[6 * k + 3] = jt[3 * k]; jp[6 * k + 4] = jt[3 * k + 1]; jp[6 * k + 5] = jt[3 * k + 2];
+  }
+  // Huber loss + corrector (rho'' <= 0  =>  r, J scaled by sqrt(rho'))
+  const double sq = r[0] * r[0] + r[1] * r[1];
+  const double b = P.huber_a * P.huber_a;
+  double rho0 = sq, rho1 = 1.0;
+  if (sq > b) {
+    const double rr = sqrt(sq);
+    rho0 = 2.0 * P.huber_a * rr - b;
+    rho1 = fmax(DBL_MIN, P.huber_a / rr);
+  }
+  const double sc = sqrt(rho1);
+  r[0] *= sc; r[1] *= sc;
+#pragma unroll
+  for (int i = 0; i < 12; i++) jp[i] *= sc;
+#pragma unroll
+  for (int i = 0; i < 6; i++) jx[i] *= sc;
+  if (act && (flags & 1)) {
+    res[2 * p] = r[0]; res[2 * p + 1] = r[1];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Jp[12 * p + i] = jp[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Jl[6 * p + i] = jx[i];
+  }
+  const bool pf = P.pose_fixed[c] != 0;
+  if (act && (flags & 2)) {
+    const bool zero = pf || P.lm_fixed[l] != 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int bb = 0; bb < 3; bb++) W[18 * p + 3 * a + bb] = zero ? 0.0 : jp[a] * jx[bb] + jp[6 + a] * jx[3 + bb];
+  }
+  // camera partials: 21 unique H_pp entries (row-major upper triangle), 6 gradient entries, cost
+  double v[28];
+  {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int bb = a; bb < 6; bb++) v[k++] = (act && !pf) ? jp[a] * jp[bb] + jp[6 + a] * jp[6 + bb] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) v[21 + a] = (act && !pf) ? jp[a] * r[0] + jp[6 + a] * r[1] : 0.0;
+    v[27] = act ? 0.5 * rho0 : 0.0;
+  }
+  const int w = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < 28; k++) {
+    const double sred = wave_sum(v[k]);
+    if (lane == 0) wred[w][k] = sred;
+  }
+  __syncthreads();
+  if (tid < 28) partial[(size_t)blockIdx.x * 28 + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
+}
+
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
+                                                   const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
+                                                   const int* __restrict__ lmObs, const double* __restrict__ res,
+                                                   const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
+                                                   int withLm, double* __restrict__ Hpp, double* __restrict__ Hll,
+                                                   double* __restrict__ g, double* __restrict__ cost) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < lmBlocks) {
+    if (!withLm) return;
+    const int l = blockIdx.x * 256 + tid;
+    if (l >= L) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+    if (!P.lm_fixed[l]) {
+      for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
+        const int p = lmObs[e];
+        const double* j = Jl + 6 * (size_t)p;
+        const double r0 = res[2 * p], r1 = res[2 * p + 1];
+        h[0] += j[0] * j[0] + j[3] * j[3]; h[1] += j[0] * j[1] + j[3] * j[4]; h[2] += j[0] * j[2] + j[3] * j[5];
+        h[3] += j[1] * j[1] + j[4] * j[4]; h[4] += j[1] * j[2] + j[4] * j[5]; h[5] += j[2] * j[2] + j[5] * j[5];
+        gl[0] += j[0] * r0 + j[3] * r1; gl[1] += j[1] * r0 + j[4] * r1; gl[2] += j[2] * r0 + j[5] * r1;
+      }
+    }
+    double* H = Hll + 9 * (size_t)l;
+    H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
+    g[6 * K + 3 * l] = gl[0]; g[6 * K + 3 * l + 1] = gl[1]; g[6 * K + 3 * l + 2] = gl[2];
+    return;
+  }
+  // camera fold: thread (c, k) sums the camera's chunk partials in chunk order
+  for (int idx = tid; idx < K * 28; idx += 256) {
+    const int c = idx / 28, k = idx - c * 28;
+    if (k == 27) continue;
+    double sacc = 0;
+    for (int ch = camChunkStart[c]; ch < camChunkStart[c + 1]; ch++) sacc += partial[(size_t)ch * 28 + k];
+    if (k < 21) {
+      int a = 0, rem = k;
+      while (rem >= 6 - a) { rem -= 6 - a; a++; }
+      const int bcol = a + rem;
+      Hpp[36 * (size_t)c + 6 * a + bcol] = sacc;
+      Hpp[36 * (size_t)c + 6 * bcol + a] = sacc;
+    } else {
+      g[6 * c + (k - 21)] = sacc;
+    }
+  }
+  if (tid == 0) {
+    double sacc = 0;
+    for (int ch = 0; ch < nChunks; ch++) sacc += partial[(size_t)ch * 28 + 27];
+    *cost = sacc;
+  }
+}
+
+}  // namespace dvs
+
+using namespace dvs;
+
+struct dvs_ba {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int K = 0, L = 0, R = 0, nChunks = 0, lmBlocks = 0;
+  double fx = 0, fy = 0, cx = 0, cy = 0, sigma = 1, huber = 1.345;
+  std::vector<double> q, t, X;            // host mirror of the parameters
+  std::vector<int> cam, lm, perm;         // camera-sorted observation arrays, perm[p] = original index
+  std::vector<int> lmStart, lmObs;
+  std::vector<unsigned char> pose_fixed, lm_fixed;
+  // device
+  double *d_q = nullptr, *d_t = nullptr, *d_X = nullptr, *d_uv = nullptr;
+  int *d_cam = nullptr, *d_lm = nullptr, *d_camChunkStart = nullptr, *d_lmStart = nullptr, *d_lmObs = nullptr;
+  unsigned char *d_pf = nullptr, *d_lf = nullptr;
+  BaChunk* d_chunks = nullptr;
+  double *d_res = nullptr, *d_Jp = nullptr, *d_Jl = nullptr, *d_W = nullptr, *d_partial = nullptr;
+  double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr;
+  double *d_raw = nullptr;  // R*(2+8+6+6)
+};
+
+namespace {
+
+void ba_free(dvs_ba* h) {
+  void* ptrs[] = {h->d_q, h->d_t, h->d_X, h->d_uv, h->d_cam, h->d_lm, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_pf,
+                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
+  h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
+  h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr;
+}
+
+template <class T>
+dvs_status up(T** d, const T* src, size_t n) {
+  DVS_HIP(hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) DVS_HIP(hipMemcpy(*d, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return DVS_OK;
+}
+
+BaDev dev_view(const dvs_ba* h) {
+  BaDev P;
+  P.q = h->d_q; P.t = h->d_t; P.X = h->d_X; P.uv = h->d_uv; P.cam = h->d_cam; P.lm = h->d_lm;
+  P.pose_fixed = h->d_pf; P.lm_fixed = h->d_lf;
+  P.fx = h->fx; P.fy = h->fy; P.cx = h->cx; P.cy = h->cy; P.inv_sigma = 1.0 / h->sigma; P.huber_a = h->huber;
+  return P;
+}
+
+// flags as k_ba_eval; withLm: also reduce landmark blocks
+dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
+  if (h->R == 0) return DVS_OK;
+  const BaDev P = dev_view(h);
+  double* raw = h->d_raw;
+  hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
+                     h->d_partial, raw, raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr,
+                     raw ? raw + 16 * (size_t)h->R : nullptr);
+  hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + 1), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
+                     h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_res, h->d_Jl, h->d_partial, h->lmBlocks, withLm ? 1 : 0,
+                     h->d_Hpp, h->d_Hll, h->d_g, h->d_cost);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status upload_params(dvs_ba* h, const std::vector<double>& q, const std::vector<double>& t, const std::vector<double>& X) {
+  DVS_HIP(hipMemcpyAsync(h->d_q, q.data(), q.size() * 8, hipMemcpyHostToDevice, h->stream));
+  DVS_HIP(hipMemcpyAsync(h->d_t, t.data(), t.size() * 8, hipMemcpyHostToDevice, h->stream));
+  DVS_HIP(hipMemcpyAsync(h->d_X, X.data(), X.size() * 8, hipMemcpyHostToDevice, h->stream));
+  return DVS_OK;
+}
+
+// ceres::EigenQuaternionManifold::Plus on the raw (w,x,y,z) memory read as Eigen (x,y,z,w)
+void quat_plus(const double* x, const double* d, double* o) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { for (int i = 0; i < 4; i++) o[i] = x[i]; return; }
+  const double sn = sin(nd) / nd;
+  const double dx = sn * d[0], dy = sn * d[1], dz = sn * d[2], dw = cos(nd);
+  o[3] = dw * x[3] - dx * x[0] - dy * x[1] - dz * x[2];
+  o[0] = dw * x[0] + dx * x[3] + dy * x[2] - dz * x[1];
+  o[1] = dw * x[1] + dy * x[3] + dz * x[0] - dx * x[2];
+  o[2] = dw * x[2] + dz * x[3] + dx * x[1] - dy * x[0];
+}
+
+bool chol_solve(std::vector<double>& A, int n, std::vector<double>& b) {
+  for (int j = 0; j < n; j++) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0)) return false;
+    d = sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+  return true;
+}
+
+bool inv3(const double* A, double* B) {
+  const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], hh = A[7], i = A[8];
+  const double det = a * (e * i - f * hh) - b * (d * i - f * g) + c * (d * hh - e * g);
+  if (det == 0 || !std::isfinite(det)) return false;
+  const double id = 1.0 / det;
+  B[0] = (e * i - f * hh) * id; B[1] = (c * hh - b * i) * id; B[2] = (b * f - c * e) * id;
+  B[3] = (f * g - d * i) * id; B[4] = (a * i - c * g) * id; B[5] = (c * d - a * f) * id;
+  B[6] = (d * hh - e * g) * id; B[7] = (b * g - a * hh) * id; B[8] = (a * e - b * d) * id;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+dvs_status dvs_ba_create(int32_t device, dvs_ba** out) {
+  DVS_ARG(out);
+  *out = nullptr;
+  DVS_TRY(check_device(device));
+  dvs_ba* h = new (std::nothrow) dvs_ba();
+  if (!h) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  h->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
+  h->stream = h->own_stream;
+  *out = h;
+  return DVS_OK;
+}
+
+void dvs_ba_destroy(dvs_ba* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  ba_free(h);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+dvs_status dvs_ba_set_stream(dvs_ba* h, void* s) {
+  DVS_ARG(h);
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  h->stream = (hipStream_t)s;
+  return DVS_OK;
+}
+dvs_status dvs_ba_synchronize(dvs_ba* h) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const double* t, int32_t L, const double* X, int32_t R,
+                              const int32_t* cam_idx, const int32_t* lm_idx, const double* uv, const uint8_t* pose_fixed,
+                              const uint8_t* lm_fixed, double fx, double fy, double cx, double cy, double sigma_pixels,
+                              double huber_delta) {
+  DVS_ARG(h && K >= 0 && L >= 0 && R >= 0);
+  DVS_ARG((q_wxyz && t) || K == 0);
+  DVS_ARG(X || L == 0);
+  DVS_ARG((cam_idx && lm_idx && uv) || R == 0);
+  for (int i = 0; i < R; i++) {
+    if (cam_idx[i] < 0 || cam_idx[i] >= K || lm_idx[i] < 0 || lm_idx[i] >= L) { set_error("observation %d references camera %d / landmark %d out of range", i, cam_idx[i], lm_idx[i]); return DVS_ERR_ARG; }
+  }
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  ba_free(h);
+  h->K = K; h->L = L; h->R = R;
+  h->fx = fx; h->fy = fy; h->cx = cx; h->cy = cy; h->sigma = sigma_pixels; h->huber = huber_delta;
+  h->q.assign(q_wxyz, q_wxyz + 4 * (size_t)K); h->t.assign(t, t + 3 * (size_t)K); h->X.assign(X, X + 3 * (size_t)L);
+  h->pose_fixed.assign(K, 0); h->lm_fixed.assign(L, 0);
+  if (pose_fixed) h->pose_fixed.assign(pose_fixed, pose_fixed + K);
+  if (lm_fixed) h->lm_fixed.assign(lm_fixed, lm_fixed + L);
+  // observations grouped by camera (stable), chunks of <= 256 per workgroup
+  std::vector<int> camCount(K + 1, 0);
+  for (int i = 0; i < R; i++) camCount[cam_idx[i] + 1]++;
+  for (int c = 0; c < K; c++) camCount[c + 1] += camCount[c];
+  h->perm.assign(R, 0);
+  {
+    std::vector<int> cur(camCount.begin(), camCount.end() - 1);
+    for (int i = 0; i < R; i++) h->perm[cur[cam_idx[i]]++] = i;
+  }
+  h->cam.resize(R); h->lm.resize(R);
+  std::vector<double> uvp(2 * (size_t)R);
+  for (int p = 0; p < R; p++) { const int i = h->perm[p]; h->cam[p] = cam_idx[i]; h->lm[p] = lm_idx[i]; uvp[2 * p] = uv[2 * i]; uvp[2 * p + 1] = uv[2 * i + 1]; }
+  std::vector<BaChunk> chunks;
+  std::vector<int> camChunkStart(K + 1, 0);
+  for (int c = 0; c < K; c++) {
+    camChunkStart[c] = (int)chunks.size();
+    for (int s = camCount[c]; s < camCount[c + 1]; s += 256) chunks.push_back(BaChunk{c, s, std::min(256, camCount[c + 1] - s), 0});
+  }
+  camChunkStart[K] = (int)chunks.size();
+  h->nChunks = (int)chunks.size();
+  h->lmStart.assign(L + 1, 0);
+  for (int p = 0; p < R; p++) h->lmStart[h->lm[p] + 1]++;
+  for (int l = 0; l < L; l++) h->lmStart[l + 1] += h->lmStart[l];
+  h->lmObs.assign(R, 0);
+  {
+    std::vector<int> cur(h->lmStart.begin(), h->lmStart.end() - 1);
+    for (int p = 0; p < R; p++) h->lmObs[cur[h->lm[p]]++] = p;
+  }
+  h->lmBlocks = (L + 255) / 256;
+  DVS_TRY(up(&h->d_q, h->q.data(), h->q.size())); DVS_TRY(up(&h->d_t, h->t.data(), h->t.size())); DVS_TRY(up(&h->d_X, h->X.data(), h->X.size()));
+  DVS_TRY(up(&h->d_uv, uvp.data(), uvp.size()));
+  DVS_TRY(up(&h->d_cam, h->cam.data(), h->cam.size())); DVS_TRY(up(&h->d_lm, h->lm.data(), h->lm.size()));
+  DVS_TRY(up(&h->d_camChunkStart, camChunkStart.data(), camChunkStart.size()));
+  DVS_TRY(up(&h->d_lmStart, h->lmStart.data(), h->lmStart.size())); DVS_TRY(up(&h->d_lmObs, h->lmObs.data(), h->lmObs.size()));
+  DVS_TRY(up(&h->d_pf, h->pose_fixed.data(), h->pose_fixed.size())); DVS_TRY(up(&h->d_lf, h->lm_fixed.data(), h->lm_fixed.size()));
+  DVS_TRY(up(&h->d_chunks, chunks.data(), chunks.size()));
+  const size_t Rz = std::max(R, 1);
+  DVS_HIP(hipMalloc((void**)&h->d_res, Rz * 2 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Jp, Rz * 12 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Jl, Rz * 6 * 8));
+  DVS_HIP(hipMalloc((void**)&h->d_W, Rz * 18 * 8)); DVS_HIP(hipMalloc((void**)&h->d_partial, (size_t)std::max(h->nChunks, 1) * 28 * 8));
+  DVS_HIP(hipMalloc((void**)&h->d_Hpp, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Hll, (size_t)std::max(L, 1) * 9 * 8));
+  DVS_HIP(hipMalloc((void**)&h->d_g, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMalloc((void**)&h->d_cost, 8));
+  DVS_HIP(hipMemset(h->d_Hpp, 0, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMemset(h->d_Hll, 0, (size_t)std::max(L, 1) * 9 * 8));
+  DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_evaluate(dvs_ba* h, double* cost, double* residuals, double* J_pose, double* J_lm, double* grad) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_TRY(enqueue_eval(h, 1, true));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  const int R = h->R;
+  if (cost) { *cost = 0; if (R) DVS_HIP(hipMemcpy(cost, h->d_cost, 8, hipMemcpyDeviceToHost)); }
+  auto unpermute = [&](double* dst, const double* dsrc, int width) -> dvs_status {
+    std::vector<double> tmp((size_t)R * width);
+    if (R) DVS_HIP(hipMemcpy(tmp.data(), dsrc, tmp.size() * 8, hipMemcpyDeviceToHost));
+    for (int p = 0; p < R; p++) memcpy(dst + (size_t)h->perm[p] * width, &tmp[(size_t)p * width], (size_t)width * 8);
+    return DVS_OK;
+  };
+  if (residuals) DVS_TRY(unpermute(residuals, h->d_res, 2));
+  if (J_pose) DVS_TRY(unpermute(J_pose, h->d_Jp, 12));
+  if (J_lm) DVS_TRY(unpermute(J_lm, h->d_Jl, 6));
+  if (grad) {
+    memset(grad, 0, (size_t)(6 * h->K + 3 * h->L) * 8);
+    if (R) DVS_HIP(hipMemcpy(grad, h->d_g, (size_t)(6 * h->K + 3 * h->L) * 8, hipMemcpyDeviceToHost));
+  }
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_evaluate_raw(dvs_ba* h, double* residuals, double* J_q, double* J_t, double* J_X) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  const int R = h->R;
+  if (R == 0) return DVS_OK;
+  if (!h->d_raw) DVS_HIP(hipMalloc((void**)&h->d_raw, (size_t)R * 22 * 8));
+  DVS_TRY(enqueue_eval(h, 4, false));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  std::vector<double> tmp((size_t)R * 22);
+  DVS_HIP(hipMemcpy(tmp.data(), h->d_raw, tmp.size() * 8, hipMemcpyDeviceToHost));
+  for (int p = 0; p < R; p++) {
+    const size_t i = h->perm[p];
+    if (residuals) memcpy(residuals + 2 * i, &tmp[2 * (size_t)p], 16);
+    if (J_q) memcpy(J_q + 8 * i, &tmp[2 * (size_t)R + 8 * (size_t)p], 64);
+    if (J_t) memcpy(J_t + 6 * i, &tmp[10 * (size_t)R + 6 * (size_t)p], 48);
+    if (J_X) memcpy(J_X + 6 * i, &tmp[16 * (size_t)R + 6 * (size_t)p], 48);
+  }
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_normal_equations(dvs_ba* h, double* H_pp, double* H_ll, double* W, double* g, double* cost) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_TRY(enqueue_eval(h, 1 | 2, true));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  const int R = h->R, K = h->K, L = h->L;
+  if (H_pp) DVS_HIP(hipMemcpy(H_pp, h->d_Hpp, (size_t)K * 36 * 8, hipMemcpyDeviceToHost));
+  if (H_ll) DVS_HIP(hipMemcpy(H_ll, h->d_Hll, (size_t)L * 9 * 8, hipMemcpyDeviceToHost));
+  if (g) DVS_HIP(hipMemcpy(g, h->d_g, (size_t)(6 * K + 3 * L) * 8, hipMemcpyDeviceToHost));
+  if (cost) DVS_HIP(hipMemcpy(cost, h->d_cost, 8, hipMemcpyDeviceToHost));
+  if (W && R) {
+    std::vector<double> tmp((size_t)R * 18);
+    DVS_HIP(hipMemcpy(tmp.data(), h->d_W, tmp.size() * 8, hipMemcpyDeviceToHost));
+    for (int p = 0; p < R; p++) memcpy(W + 18 * (size_t)h->perm[p], &tmp[18 * (size_t)p], 144);
+  }
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_evaluate_device(dvs_ba* h, int32_t iters) {
+  DVS_ARG(h && iters >= 0);
+  DVS_HIP(hipSetDevice(h->device));
+  for (int i = 0; i < iters; i++) DVS_TRY(enqueue_eval(h, 1, true));
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X) {
+  DVS_ARG(h);
+  if (q_wxyz) memcpy(q_wxyz, h->q.data(), h->q.size() * 8);
+  if (t) memcpy(t, h->t.data(), h->t.size() * 8);
+  if (X) memcpy(X, h->X.data(), h->X.size() * 8);
+  return DVS_OK;
+}
+
+// Levenberg-Marquardt with ceres::Solver defaults (trust_region_minimizer.cc / levenberg_marquardt_strategy.cc, Ceres 2.x):
+// initial radius 1e4, Jacobi column scaling fixed at the first Jacobian, LM diagonal clamped to [1e-6, 1e32], step
+// accepted when relative decrease > 1e-3, radius /= max(1/3, 1 - (2 rho - 1)^3) on success, /= 2,4,8.. on failure;
+// parameter / function tolerance tested on the candidate BEFORE acceptance; landmarks eliminated by a Schur complement.
+dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double gtol, double ptol, dvs_ba_summary* summary) {
+  DVS_ARG(h && summary && max_iterations >= 0);
+  memset(summary, 0, sizeof(*summary));
+  summary->termination = 2;
+  DVS_HIP(hipSetDevice(h->device));
+  const int K = h->K, L = h->L, R = h->R, NT = 6 * K + 3 * L;
+  if (R == 0) { set_error("no observations"); return DVS_ERR_ARG; }
+  std::vector<double> Hpp((size_t)K * 36), Hll((size_t)L * 9), W((size_t)R * 18), g(NT);
+  double x_cost = 0;
+  auto evaluate_full = [&]() -> dvs_status {
+    DVS_TRY(enqueue_eval(h, 1 | 2, true));
+    DVS_HIP(hipMemcpyAsync(Hpp.data(), h->d_Hpp, Hpp.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipMemcpyAsync(Hll.data(), h->d_Hll, Hll.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipMemcpyAsync(W.data(), h->d_W, W.size() * 8, hipMemcpyDeviceToHost, h->stream));  // camera-sorted order
+    DVS_HIP(hipMemcpyAsync(g.data(), h->d_g, g.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipMemcpyAsync(&x_cost, h->d_cost, 8, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipStreamSynchronize(h->stream));
+    return DVS_OK;
+  };
+  std::vector<double> q = h->q, t = h->t, X = h->X;
+  DVS_TRY(upload_params(h, q, t, X));
+  DVS_TRY(evaluate_full());
+  summary->initial_cost = x_cost;
+  double min_cost = x_cost;
+
+  std::vector<unsigned char> lmUsed(L, 0), camUsed(K, 0), active(NT, 0);
+  for (int p = 0; p < R; p++) { lmUsed[h->lm[p]] = 1; camUsed[h->cam[p]] = 1; }
+  std::vector<int> camSlot(K, -1);
+  int nc = 0;
+  for (int c = 0; c < K; c++) if (!h->pose_fixed[c] && camUsed[c]) { camSlot[c] = nc++; for (int a = 0; a < 6; a++) active[6 * c + a] = 1; }
+  for (int l = 0; l < L; l++) if (!h->lm_fixed[l] && lmUsed[l]) for (int a = 0; a < 3; a++) active[6 * K + 3 * l + a] = 1;
+  const int n = 6 * nc;
+  std::vector<double> scale(NT, 1.0), diagonal(NT, 0.0), step(NT, 0.0), Vinv((size_t)L * 9), Sm, rhs;
+  for (int c = 0; c < K; c++) for (int a = 0; a < 6; a++) scale[6 * c + a] = 1.0 / (1.0 + sqrt(Hpp[36 * (size_t)c + 7 * a]));
+  for (int l = 0; l < L; l++) for (int a = 0; a < 3; a++) scale[6 * K + 3 * l + a] = 1.0 / (1.0 + sqrt(Hll[9 * (size_t)l + 4 * a]));
+
+  auto grad_max_norm = [&]() {
+    double m = 0;
+    for (int c = 0; c < K; c++) if (camSlot[c] >= 0) {
+      const double d[3] = {-g[6 * c], -g[6 * c + 1], -g[6 * c + 2]};
+      double qp[4];
+      quat_plus(&q[4 * c], d, qp);
+      for (int i = 0; i < 4; i++) m = std::max(m, fabs(q[4 * c + i] - qp[i]));
+      for (int i = 0; i < 3; i++) m = std::max(m, fabs(g[6 * c + 3 + i]));
+    }
+    for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) m = std::max(m, fabs(g[6 * K + 3 * l + i]));
+    return m;
+  };
+  auto x_norm = [&]() {
+    double s = 0;
+    for (int c = 0; c < K; c++) if (camSlot[c] >= 0) { for (int i = 0; i < 4; i++) s += q[4 * c + i] * q[4 * c + i]; for (int i = 0; i < 3; i++) s += t[3 * c + i] * t[3 * c + i]; }
+    for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) s += X[3 * l + i] * X[3 * l + i];
+    return sqrt(s);
+  };
+
+  double radius = 1e4, decrease_factor = 2.0, gmax = grad_max_norm();
+  bool reuse_diagonal = false;
+  int iteration = 0, invalid = 0;
+  summary->termination = 1;
+  while (true) {
+    if (iteration >= max_iterations) { summary->termination = 1; break; }
+    if (gmax <= gtol) { summary->termination = 0; break; }
+    if (radius < 1e-32) { summary->termination = 0; break; }
+    iteration++;
+    if (!reuse_diagonal) {
+      for (int c = 0; c < K; c++) for (int a = 0; a < 6; a++) { const int j = 6 * c + a; diagonal[j] = std::min(std::max(Hpp[36 * (size_t)c + 7 * a] * scale[j] * scale[j], 1e-6), 1e32); }
+      for (int l = 0; l < L; l++) for (int a = 0; a < 3; a++) { const int j = 6 * K + 3 * l + a; diagonal[j] = std::min(std::max(Hll[9 * (size_t)l + 4 * a] * scale[j] * scale[j], 1e-6), 1e32); }
+    }
+    reuse_diagonal = true;
+    // reduced camera system S = (H_pp + D) - sum_l Wl (H_ll + D)^-1 Wl^T, on the Jacobi-scaled blocks
+    Sm.assign((size_t)n * n, 0.0); rhs.assign(n, 0.0);
+    for (int c = 0; c < K; c++) if (camSlot[c] >= 0) {
+      const int o = 6 * camSlot[c];
+      for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) Sm[(size_t)(o + a) * n + o + b] = Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + a] * scale[6 * c + b];
+        Sm[(size_t)(o + a) * n + o + a] += diagonal[6 * c + a] / radius;
+        rhs[o + a] = g[6 * c + a] * scale[6 * c + a];
+      }
+    }
+    bool ok = true;
+    double Ws[16][18], Y[16][18];
+    std::vector<double> Wbig, Ybig;
+    for (int l = 0; l < L && ok; l++) {
+      const int j0 = 6 * K + 3 * l;
+      if (!active[j0]) continue;
+      double V[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) V[3 * a + b] = Hll[9 * (size_t)l + 3 * a + b] * scale[j0 + a] * scale[j0 + b];
+      for (int a = 0; a < 3; a++) V[4 * a] += diagonal[j0 + a] / radius;
+      double* Vi = &Vinv[9 * (size_t)l];
+      if (!inv3(V, Vi)) { ok = false; break; }
+      const double gl[3] = {g[j0] * scale[j0], g[j0 + 1] * scale[j0 + 1], g[j0 + 2] * scale[j0 + 2]};
+      const int e0 = h->lmStart[l], ne = h->lmStart[l + 1] - e0;
+      double (*Wl)[18] = Ws; double (*Yl)[18] = Y;
+      if (ne > 16) { Wbig.resize((size_t)ne * 18); Ybig.resize((size_t)ne * 18); Wl = (double(*)[18])Wbig.data(); Yl = (double(*)[18])Ybig.data(); }
+      for (int e = 0; e < ne; e++) {
+        const int p = h->lmObs[e0 + e], c = h->cam[p];
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 3; b++) Wl[e][3 * a + b] = W[18 * (size_t)p + 3 * a + b] * scale[6 * c + a] * scale[j0 + b];
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 3; b++) Yl[e][3 * a + b] = Wl[e][3 * a] * Vi[b] + Wl[e][3 * a + 1] * Vi[3 + b] + Wl[e][3 * a + 2] * Vi[6 + b];
+      }
+      for (int e = 0; e < ne; e++) {
+        const int ci = camSlot[h->cam[h->lmObs[e0 + e]]];
+        if (ci < 0) continue;
+        for (int a = 0; a < 6; a++) rhs[6 * ci + a] -= Yl[e][3 * a] * gl[0] + Yl[e][3 * a + 1] * gl[1] + Yl[e][3 * a + 2] * gl[2];
+        for (int f = 0; f < ne; f++) {
+          const int ck = camSlot[h->cam[h->lmObs[e0 + f]]];
+          if (ck < 0) continue;
+          double* dst = &Sm[(size_t)(6 * ci) * n + 6 * ck];
+          for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
+            dst[(size_t)a * n + b] -= Yl[e][3 * a] * Wl[f][3 * b] + Yl[e][3 * a + 1] * Wl[f][3 * b + 1] + Yl[e][3 * a + 2] * Wl[f][3 * b + 2];
+        }
+      }
+    }
+    if (ok && n > 0) ok = chol_solve(Sm, n, rhs);
+    bool valid = ok;
+    double model_cost_change = 0;
+    if (ok) {
+      std::fill(step.begin(), step.end(), 0.0);
+      for (int c = 0; c < K; c++) if (camSlot[c] >= 0) for (int a = 0; a < 6; a++) step[6 * c + a] = rhs[6 * camSlot[c] + a];
+      for (int l = 0; l < L; l++) {
+        const int j0 = 6 * K + 3 * l;
+        if (!active[j0]) continue;
+        double b[3] = {g[j0] * scale[j0], g[j0 + 1] * scale[j0 + 1], g[j0 + 2] * scale[j0 + 2]};
+        for (int e = h->lmStart[l]; e < h->lmStart[l + 1]; e++) {
+          const int p = h->lmObs[e], c = h->cam[p];
+          if (camSlot[c] < 0) continue;
+          for (int m = 0; m < 3; m++) for (int a = 0; a < 6; a++) b[m] -= W[18 * (size_t)p + 3 * a + m] * scale[6 * c + a] * scale[j0 + m] * step[6 * c + a];
+        }
+        const double* Vi = &Vinv[9 * (size_t)l];
+        for (int a = 0; a < 3; a++) step[j0 + a] = Vi[3 * a] * b[0] + Vi[3 * a + 1] * b[1] + Vi[3 * a + 2] * b[2];
+      }
+      for (int j = 0; j < NT; j++) { step[j] = -step[j]; if (!std::isfinite(step[j])) valid = false; }
+      if (valid) {
+        double sg = 0, sHs = 0;
+        for (int j = 0; j < NT; j++) sg += step[j] * g[j] * scale[j];
+        for (int c = 0; c < K; c++) for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
+          sHs += step[6 * c + a] * scale[6 * c + a] * Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + b] * step[6 * c + b];
+        for (int l = 0; l < L; l++) { const int j0 = 6 * K + 3 * l; for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sHs += step[j0 + a] * scale[j0 + a] * Hll[9 * (size_t)l + 3 * a + b] * scale[j0 + b] * step[j0 + b]; }
+        for (int p = 0; p < R; p++) { const int c = h->cam[p], j0 = 6 * K + 3 * h->lm[p]; for (int a = 0; a < 6; a++) for (int b = 0; b < 3; b++) sHs += 2.0 * step[6 * c + a] * scale[6 * c + a] * W[18 * (size_t)p + 3 * a + b] * scale[j0 + b] * step[j0 + b]; }
+        model_cost_change = -(sg + 0.5 * sHs);
+        if (model_cost_change <= 0.0) valid = false;
+      }
+    }
+    if (!valid) {
+      if (++invalid >= 5) { summary->termination = 2; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;
+      continue;
+    }
+    invalid = 0;
+    std::vector<double> cq = q, ct = t, cX = X;
+    for (int c = 0; c < K; c++) if (camSlot[c] >= 0) {
+      const double d[3] = {step[6 * c] * scale[6 * c], step[6 * c + 1] * scale[6 * c + 1], step[6 * c + 2] * scale[6 * c + 2]};
+      quat_plus(&q[4 * c], d, &cq[4 * c]);
+      for (int i = 0; i < 3; i++) ct[3 * c + i] = t[3 * c + i] + step[6 * c + 3 + i] * scale[6 * c + 3 + i];
+    }
+    for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) cX[3 * l + i] = X[3 * l + i] + step[6 * K + 3 * l + i] * scale[6 * K + 3 * l + i];
+    DVS_TRY(upload_params(h, cq, ct, cX));
+    DVS_TRY(enqueue_eval(h, 0, false));  // cost only
+    double cand_cost = 0;
+    DVS_HIP(hipMemcpyAsync(&cand_cost, h->d_cost, 8, hipMemcpyDeviceToHost, h->stream));
+    DVS_HIP(hipStreamSynchronize(h->stream));
+    double sn = 0;
+    for (int c = 0; c < K; c++) if (camSlot[c] >= 0) { for (int i = 0; i < 4; i++) sn += (q[4 * c + i] - cq[4 * c + i]) * (q[4 * c + i] - cq[4 * c + i]); for (int i = 0; i < 3; i++) sn += (t[3 * c + i] - ct[3 * c + i]) * (t[3 * c + i] - ct[3 * c + i]); }
+    for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) sn += (X[3 * l + i] - cX[3 * l + i]) * (X[3 * l + i] - cX[3 * l + i]);
+    if (sqrt(sn) <= ptol * (x_norm() + ptol)) { summary->termination = 0; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= ftol * x_cost) { summary->termination = 0; break; }
+    const double rel = cost_change / model_cost_change;
+    if (rel > 1e-3) {
+      q = cq; t = ct; X = cX;
+      DVS_TRY(evaluate_full());  // parameters on the device already are the candidate
+      gmax = grad_max_norm();
+      summary->num_successful_steps++;
+      min_cost = std::min(min_cost, x_cost);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+    }
+  }
+  summary->num_iterations = iteration;
+  summary->final_cost = min_cost;
+  h->q = q; h->t = t; h->X = X;
+  DVS_TRY(upload_params(h, q, t, X));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  return DVS_OK;
+}
+
+// CameraPose::fromRt / toRt (bundle_adjustment.hpp:138-165, 192-212) with Eigen 3.4's Quaterniond(Matrix3d),
+// normalize() and toRotationMatrix() arithmetic.  R is row-major 3x3, poses in the caller's convention (the backend
+// passes camera-to-world; fromRt inverts).  Pure host arithmetic: part of the drop-in adapter, not of the hot path.
+dvs_status dvs_ba_pose_from_rt(const double* R_wc, const double* t_wc, double* q_wxyz, double* trans) {
+  DVS_ARG(R_wc && t_wc && q_wxyz && trans);
+  double m[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = R_wc[3 * j + i];  // R_camera_world = R^T
+  for (int i = 0; i < 3; i++) trans[i] = -(m[i][0] * t_wc[0] + m[i][1] * t_wc[1] + m[i][2] * t_wc[2]);
+  double qv[4];  // x, y, z, w
+  double tr = m[0][0] + m[1][1] + m[2][2];
+  if (tr > 0) {
+    tr = sqrt(tr + 1.0);
+    qv[3] = 0.5 * tr;
+    tr = 0.5 / tr;
+    qv[0] = (m[2][1] - m[1][2]) * tr; qv[1] = (m[0][2] - m[2][0]) * tr; qv[2] = (m[1][0] - m[0][1]) * tr;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    tr = sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    qv[i] = 0.5 * tr;
+    tr = 0.5 / tr;
+    qv[3] = (m[k][j] - m[j][k]) * tr;
+    qv[j] = (m[j][i] + m[i][j]) * tr;
+    qv[k] = (m[k][i] + m[i][k]) * tr;
+  }
+  const double nn = sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]);
+  q_wxyz[0] = qv[3] / nn; q_wxyz[1] = qv[0] / nn; q_wxyz[2] = qv[1] / nn; q_wxyz[3] = qv[2] / nn;
+  return DVS_OK;
+}
+
+dvs_status dvs_ba_pose_to_rt(const double* q_wxyz, const double* trans, double* R_wc, double* t_wc) {
+  DVS_ARG(q_wxyz && trans && R_wc && t_wc);
+  const double w = q_wxyz[0], x = q_wxyz[1], y = q_wxyz[2], z = q_wxyz[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double Rcw[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R_wc[3 * i + j] = Rcw[j][i];
+  for (int i = 0; i < 3; i++) t_wc[i] = -(R_wc[3 * i] * trans[0] + R_wc[3 * i + 1] * trans[1] + R_wc[3 * i + 2] * trans[2]);
+  return DVS_OK;
+}
+
+}  // extern "C"

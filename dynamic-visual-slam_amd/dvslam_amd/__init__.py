@@ -8,3 +8,4 @@ There is NO CPU fallback: every class raises if the library or a gfx950 device i
 from ._lib import lib, DvsError, KP_DTYPE, device_count, build_library  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
 from .matcher import BFMatcher  # noqa: F401
+from .ba import BAProblem, SlidingWindowBA  # noqa: F401

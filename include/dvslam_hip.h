@@ -180,6 +180,17 @@ dvs_status dvs_ba_evaluate_device(dvs_ba* h, int32_t iters);
 dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double function_tolerance, double gradient_tolerance,
                         double parameter_tolerance, dvs_ba_summary* summary);
 dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X);
+/* CameraPose::fromRt / toRt (bundle_adjustment.hpp:138-165, 192-212): caller-convention (R row-major 3x3, t) <->
+ * optimiser (q_wxyz, translation).  Host arithmetic used by the SlidingWindowBA adapter. */
+dvs_status dvs_ba_pose_from_rt(const double* R, const double* t, double* q_wxyz, double* trans);
+dvs_status dvs_ba_pose_to_rt(const double* q_wxyz, const double* trans, double* R, double* t);
+
+/* ======================================= host-logic test hooks ================================= */
+/* (no GPU needed) libstdc++ std::sort replica used by the quad-tree, glibc sinf/cosf restatement, geometry tables */
+void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
+void dvs_test_sincosf(float a, float* s, float* c);
+dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
+                             int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);
 
 #ifdef __cplusplus
 }

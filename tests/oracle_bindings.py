@@ -135,3 +135,66 @@ def match_thresh(q, t, max_dist, cap=None):
     pairs = np.zeros((cap, 3), np.int32)
     n = lib().orc_match_hamming_thresh(_p(q), len(q), _p(t), len(t), max_dist, _p(pairs), cap)
     return n, pairs[:min(n, cap)].copy()
+
+
+# ------------------------------------------------ bundle adjustment oracle ----------------------------------------------
+class BaSummary(C.Structure):
+    _fields_ = [("termination", C.c_int32), ("num_successful_steps", C.c_int32), ("num_iterations", C.c_int32),
+                ("reserved", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+class OracleBA:
+    """CPU restatement of WeightedSquaredReprojectionError + Ceres autodiff/Huber/manifold/LM (oracle/ba_oracle.cpp)"""
+
+    def __init__(self, prob):
+        L = lib()
+        vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+        L.orc_ba_create.restype = vp
+        L.orc_ba_create.argtypes = [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl]
+        L.orc_ba_destroy.argtypes = [vp]
+        L.orc_ba_evaluate_raw.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_ba_evaluate.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_ba_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_ba_solve.argtypes = [vp, i32, dbl, dbl, dbl, vp]
+        L.orc_ba_get_parameters.argtypes = [vp, vp, vp, vp]
+        self.L = L
+        self.K, self.Ln, self.R = prob["K"], prob["L"], len(prob["cam_idx"])
+        self._keep = [np.ascontiguousarray(prob[k]) for k in ("q", "t", "X", "cam_idx", "lm_idx", "uv", "pose_fixed", "lm_fixed")]
+        q, t, X, cam, lm, uv, pf, lf = self._keep
+        self.h = L.orc_ba_create(self.K, _p(q), _p(t), self.Ln, _p(X), self.R, _p(cam.astype(np.int32)), _p(lm.astype(np.int32)), _p(uv),
+                                 _p(pf.astype(np.uint8)), _p(lf.astype(np.uint8)), prob["fx"], prob["fy"], prob["cx"], prob["cy"],
+                                 prob["sigma"], prob["huber"])
+
+    def __del__(self):
+        try:
+            self.L.orc_ba_destroy(self.h)
+        except Exception:
+            pass
+
+    def evaluate_raw(self):
+        R = self.R
+        r = np.zeros((R, 2)); jq = np.zeros((R, 2, 4)); jt = np.zeros((R, 2, 3)); jx = np.zeros((R, 2, 3))
+        self.L.orc_ba_evaluate_raw(self.h, _p(r), _p(jq), _p(jt), _p(jx))
+        return r, jq, jt, jx
+
+    def evaluate(self):
+        R = self.R
+        cost = C.c_double(); r = np.zeros((R, 2)); jp = np.zeros((R, 2, 6)); jl = np.zeros((R, 2, 3)); g = np.zeros(6 * self.K + 3 * self.Ln)
+        self.L.orc_ba_evaluate(self.h, C.byref(cost), _p(r), _p(jp), _p(jl), _p(g))
+        return cost.value, r, jp, jl, g
+
+    def normal_equations(self):
+        hpp = np.zeros((self.K, 6, 6)); hll = np.zeros((self.Ln, 3, 3)); w = np.zeros((self.R, 6, 3)); g = np.zeros(6 * self.K + 3 * self.Ln)
+        cost = C.c_double()
+        self.L.orc_ba_normal_equations(self.h, _p(hpp), _p(hll), _p(w), _p(g), C.byref(cost))
+        return hpp, hll, w, g, cost.value
+
+    def solve(self, max_iterations=10, ftol=1e-6, gtol=1e-10, ptol=1e-8):
+        s = BaSummary()
+        self.L.orc_ba_solve(self.h, max_iterations, ftol, gtol, ptol, C.byref(s))
+        return s
+
+    def parameters(self):
+        q = np.zeros((self.K, 4)); t = np.zeros((self.K, 3)); X = np.zeros((self.Ln, 3))
+        self.L.orc_ba_get_parameters(self.h, _p(q), _p(t), _p(X))
+        return q, t, X

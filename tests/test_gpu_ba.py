@@ -1,0 +1,119 @@
+"""GPU parity: HIP bundle-adjustment evaluation / normal equations / LM solve (C-ABI) vs the oracle
+(Ceres autodiff restated with dual numbers).  Tolerances (floating point, stated per assertion):
+residuals bit-exact (same operation order, no FMA), analytic vs autodiff Jacobians and all reductions
+1e-12 relative to the largest magnitude, LM final cost 1e-6 relative."""
+import numpy as np
+import pytest
+from dvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+def _close(a, b, rtol=RTOL):
+    a = np.asarray(a); b = np.asarray(b)
+    scale = max(np.abs(b).max(), 1e-300) if b.size else 1.0
+    return np.abs(a - b).max() <= rtol * scale if b.size else True
+
+
+def _problems():
+    yield "window 3x40", synth.make_ba_problem(K=3, L=40, seed=11)
+    P = synth.make_ba_problem(K=4, L=300, seed=12, visibility=0.7)
+    P["q"] = P["q"] * np.linspace(0.5, 2.0, 4)[:, None]             # un-normalised quaternions
+    P["sigma"] = 2.5; P["lm_fixed"][::7] = 1
+    yield "ragged, fixed landmarks, sigma 2.5", P
+    P = synth.make_ba_problem(K=2, L=30, seed=13)
+    P["X"][4] = [0, 0, -20.0]; P["X"][9] = [0.0, 0.0, P["X"][9][2] * 0 + 0.05]   # behind / too close: z_c <= 0.1
+    yield "points behind the camera", P
+    yield "full window 10x2000 (BASELINE config 3)", synth.make_ba_problem(K=10, L=2000, seed=42)
+    P = synth.make_ba_problem(K=3, L=20, seed=14)                   # backend.cpp:180 shifted intrinsics: (10, fx, fy, cx, sigma=cy)
+    P["fx"], P["fy"], P["cx"], P["cy"], P["sigma"] = 10.0, 900.0, 900.0, 640.0, 360.0
+    yield "shifted intrinsics as the backend passes them", P
+
+
+@pytest.mark.parametrize("name,P", list(_problems()), ids=[n for n, _ in _problems()])
+def test_evaluation_parity(gpu, oracle, name, P):
+    from dvslam_amd import BAProblem
+    g = BAProblem(P); o = oracle.OracleBA(P)
+    r, jq, jt, jx = g.evaluate_raw(); r2, jq2, jt2, jx2 = o.evaluate_raw()
+    assert (r == r2).all(), "raw residuals must be bit-identical"
+    assert _close(jq, jq2) and _close(jt, jt2) and _close(jx, jx2)
+    z = (r2 == 0).all(axis=1)
+    assert (jq[z] == 0).all() and (jt[z] == 0).all() and (jx[z] == 0).all()
+    cost, rr, jp, jl, grad = g.evaluate(); cost2, rr2, jp2, jl2, grad2 = o.evaluate()
+    assert abs(cost - cost2) <= RTOL * abs(cost2)
+    assert _close(rr, rr2) and _close(jp, jp2) and _close(jl, jl2) and _close(grad, grad2)
+    hpp, hll, w, g3, c3 = g.normal_equations(); hpp2, hll2, w2, g4, c4 = o.normal_equations()
+    assert _close(hpp, hpp2) and _close(hll, hll2) and _close(w, w2) and _close(g3, g4) and abs(c3 - c4) <= RTOL * abs(c4)
+    cost_b = g.evaluate()[0]
+    assert cost_b == cost, "fixed-order reductions: repeated evaluation is bit-reproducible"
+
+
+def test_empty_and_degenerate_inputs(gpu, oracle):
+    from dvslam_amd import BAProblem, SlidingWindowBA
+    P = synth.make_ba_problem(K=2, L=5, seed=1)
+    for k in ("cam_idx", "lm_idx"):
+        P[k] = P[k][:0]
+    P["uv"] = P["uv"][:0]
+    g = BAProblem(P)
+    assert g.evaluate()[0] == 0.0
+    ba = SlidingWindowBA(900, 900, 640, 360)
+    assert ba.optimize([], [], [])["message"] == "Insufficient input data for optimization"
+    kf = [(0, np.eye(3), np.zeros(3))]
+    lm = [(5, "unlabeled", (0, 0, 3.0), False)]
+    out = ba.optimize(kf, lm, [((640.0, 360.0), 99, "unlabeled", 0)])             # unknown landmark id -> no valid constraints
+    assert out["message"] == "No valid observation constraints" and not out["success"]
+
+
+@pytest.mark.parametrize("K,L,seed,iters", [(5, 200, 7, 60), (10, 2000, 42, 20), (3, 60, 9, 10)])
+def test_lm_solve_parity(gpu, oracle, K, L, seed, iters):
+    from dvslam_amd import BAProblem
+    P = synth.make_ba_problem(K=K, L=L, seed=seed)
+    g = BAProblem(P); o = oracle.OracleBA(P)
+    s = g.solve(iters); s2 = o.solve(iters)
+    assert s.termination == s2.termination and s.num_successful_steps == s2.num_successful_steps and s.num_iterations == s2.num_iterations
+    assert abs(s.initial_cost - s2.initial_cost) <= RTOL * s2.initial_cost
+    assert abs(s.final_cost - s2.final_cost) <= 1e-6 * s2.final_cost, "BA final cost within relative 1e-6 (BASELINE.md §4)"
+    q, t, X = g.parameters(); q2, t2, X2 = o.parameters()
+    # parameters: fixing one pose leaves the global SCALE of a monocular window unconstrained (a null direction of the
+    # cost), so the two solvers' rounding differences may drift along it: rotations agree tightly, translations and
+    # landmarks only up to that gauge -> loose bound here, the binding parity statement is the cost above.
+    assert np.abs(q - q2).max() < 1e-7 and np.abs(t - t2).max() < 5e-3 and np.abs(X - X2).max() < 5e-2
+    assert (q[0] == P["q"][0]).all() and (t[0] == P["t"][0]).all()               # gauge pose untouched
+
+
+def test_noise_free_fixed_point(gpu):
+    from dvslam_amd import BAProblem
+    P = synth.make_ba_problem(K=4, L=50, seed=6, pixel_noise=0.0, outlier_frac=0.0, pose_noise=(0.0, 0.0), lm_noise=0.0)
+    g = BAProblem(P)
+    assert g.evaluate()[0] < 1e-18
+    s = g.solve(10)
+    assert s.termination == 0 and s.final_cost < 1e-18
+
+
+def test_sliding_window_adapter_round_trip(gpu, oracle):
+    """SlidingWindowBA.optimize mirror: camera-to-world inputs are inverted by fromRt and re-inverted by toRt"""
+    from dvslam_amd import SlidingWindowBA
+    P = synth.make_ba_problem(K=4, L=80, seed=21, outlier_frac=0.0)
+    kfs = []
+    for k in range(P["K"]):
+        q = P["q"][k]; w, x, y, z = q
+        Rcw = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Rwc = Rcw.T; twc = -Rwc @ P["t"][k]
+        kfs.append((100 + k, Rwc, twc))
+    lms = [(1000 + l, "unlabeled", tuple(P["X"][l]), False) for l in range(P["L"])]
+    obs = [((P["uv"][i][0], P["uv"][i][1]), 1000 + int(P["lm_idx"][i]), "unlabeled", 100 + int(P["cam_idx"][i])) for i in range(len(P["uv"]))]
+    obs.append(((1.0, 2.0), 424242, "unlabeled", 100))                            # unknown landmark: skipped (:805-809)
+    out = SlidingWindowBA(P["fx"], P["fy"], P["cx"], P["cy"]).optimize(kfs, lms, obs, 60)
+    assert out["frames_optimized"] == 4 and out["landmarks_optimized"] == 80
+    assert out["success"] and out["message"] == "Bundle adjustment converged successfully"
+    R0, t0 = out["optimized_poses"][100]
+    assert np.allclose(R0, kfs[0][1], atol=1e-12) and np.allclose(t0, kfs[0][2], atol=1e-12)   # gauge pose round-trips
+    assert set(out["optimized_landmarks"].keys()) == {(1000 + l, "unlabeled") for l in range(80)}
+    # same problem through the oracle's pose conversion gives the same optimiser input
+    q = np.zeros(4); tr = np.zeros(3)
+    oracle.lib().orc_ba_from_rt.argtypes = [oracle.C.c_void_p] * 4
+    oracle.lib().orc_ba_from_rt(np.ascontiguousarray(kfs[2][1]).ctypes.data, np.ascontiguousarray(kfs[2][2]).ctypes.data, q.ctypes.data, tr.ctypes.data)
+    assert np.allclose(q, P["q"][2] if P["q"][2][0] * q[0] > 0 else -P["q"][2], atol=1e-12) and np.allclose(tr, P["t"][2], atol=1e-12)
