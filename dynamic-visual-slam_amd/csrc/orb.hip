@@ -27,6 +27,9 @@ struct dvs_orb {
   dvs_orb_params prm;
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+  bool overlap = true;
   int max_batch = 1;
   // ctor tables (ORBextractor.cpp:414-445)
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -38,6 +41,7 @@ struct dvs_orb {
   Geom* d_geom = nullptr;
   Cell* d_cells = nullptr;
   BlurTile* d_tiles = nullptr;
+  BlurStrip* d_strips = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
   u8 *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -58,13 +62,14 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
-  void* ptrs[] = {h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
+  void* ptrs[] = {h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
                   h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
+  h->d_strips = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
@@ -133,7 +138,7 @@ void build_axis_table(int ssize, int dsize, bool clamp_like_x, std::vector<int>&
 }
 
 dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<Cell>& cells, std::vector<BlurTile>& tiles,
-                          std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
+                          std::vector<BlurStrip>& strips, std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
   memset(&G, 0, sizeof(G));
   const int nl = h->prm.nlevels;
   G.nlevels = nl; G.rows = rows; G.cols = cols;
@@ -204,6 +209,12 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     G.maxN = std::max(G.maxN, std::max(L.N + 3, 4 * nIni));
     for (int ty = 0; ty < (L.h + 15) / 16; ty++)
       for (int tx = 0; tx < (L.w + 63) / 64; tx++) tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+    {  // streaming blur: equal-width strips of <= 256 columns (multiples of 4), bands of kBlurBand rows
+      const int ns = (L.w + 255) / 256;
+      const int sw = ((L.w + ns - 1) / ns + 3) / 4 * 4;
+      for (int y0 = 0; y0 < L.h; y0 += kBlurBand)
+        for (int x0 = 0; x0 < L.w; x0 += sw) strips.push_back(BlurStrip{(int16_t)l, (int16_t)x0, (int16_t)std::min(sw, L.w - x0), (int16_t)y0});
+    }
     if (l > 0) {
       L.xtab = (int)xofs.size(); L.ytab = (int)yofs.size();
       build_axis_table(G.lv[l - 1].w, L.w, true, xofs, alpha);
@@ -215,6 +226,15 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
   G.totalCells = (int)cells.size();
   G.kpBlock = kpOff;
   G.blurTiles = (int)tiles.size();
+  G.blurStrips = (int)strips.size();
+  {  // wave-per-cell FAST: LDS tile geometry (pitch keeps the <= 3 byte phase of the aligned staging)
+    int maxw = 0, maxh = 0;
+    for (const Cell& c : cells) { maxw = std::max<int>(maxw, c.cw); maxh = std::max<int>(maxh, c.ch); }
+    G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
+    G.fastRows = maxh;
+    const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
+    G.fastWaveLds = (int)align_up(2 * (size_t)G.fastRows * G.fastP + listBytes, 16);
+  }
   return DVS_OK;
 }
 
@@ -230,14 +250,15 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   free_workspace(h);
   Geom G;
-  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<int> xofs, alpha, yofs, beta;
-  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, xofs, alpha, yofs, beta));
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<int> xofs, alpha, yofs, beta;
+  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, strips, xofs, alpha, yofs, beta));
   h->geom = G;
   const size_t B = (size_t)h->max_batch;
   DVS_HIP(hipMalloc((void**)&h->d_geom, sizeof(Geom)));
   DVS_HIP(hipMemcpy(h->d_geom, &G, sizeof(Geom), hipMemcpyHostToDevice));
   DVS_TRY(upload(&h->d_cells, cells));
   DVS_TRY(upload(&h->d_tiles, tiles));
+  DVS_TRY(upload(&h->d_strips, strips));
   DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
   DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
@@ -259,6 +280,9 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   h->octree_nmax = G.maxN + 8;
   h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4);
   DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   h->rows = rows; h->cols = cols;
   return DVS_OK;
 }
@@ -281,19 +305,39 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
                        D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
   }
   h->timer.end(st);
+  // blur only depends on the pyramid: fork it onto the auxiliary stream so it overlaps FAST + quad-tree
+  hipStream_t bst = st;
+  if (h->overlap) {
+    bst = h->aux_stream;
+    DVS_HIP(hipEventRecord(h->ev_pyr, st));
+    DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
+  }
+  h->timer.begin(DVS_STAGE_BLUR, bst);
+  // streaming kernel needs dword-aligned level-0 rows; our own pyramid levels always are
+  if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0)
+    hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
+  else
+    hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
+  h->timer.end(bst);
+  if (bst != st) DVS_HIP(hipEventRecord(h->ev_blur, bst));
   // 2. FAST per cell
   h->timer.begin(DVS_STAGE_FAST, st);
-  hipLaunchKernelGGL(k_fast_cell, dim3(G.totalCells, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+  if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0) {
+    const dim3 grid((G.totalCells + 3) / 4, nimg);
+    const size_t lds = 4 * (size_t)G.fastWaveLds;
+    if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+    else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+    else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+  } else {
+    hipLaunchKernelGGL(k_fast_cell, dim3(G.totalCells, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+  }
   h->timer.end(st);
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
   hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(256), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax);
   h->timer.end(st);
-  // 4. blur
-  h->timer.begin(DVS_STAGE_BLUR, st);
-  hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, st, h->d_geom, h->d_tiles, src, h->d_blur);
-  h->timer.end(st);
+  if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
   // 5. orientation + descriptors + output records
   h->timer.begin(DVS_STAGE_DESCRIBE, st);
   const int maxkp = std::min(capacity, G.kpBlock);
@@ -323,13 +367,23 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   for (int i = 0; i < 7; i++) allzero = allzero && params->gauss_kernel[i] == 0;
   if (allzero) { const int k[7] = {18, 34, 48, 56, 48, 34, 18}; memcpy(h->prm.gauss_kernel, k, sizeof(k)); }
   int ksum = 0;
-  for (int i = 0; i < 7; i++) ksum += h->prm.gauss_kernel[i];
+  for (int i = 0; i < 7; i++) {
+    ksum += h->prm.gauss_kernel[i];
+    if (h->prm.gauss_kernel[i] < 0 || h->prm.gauss_kernel[i] > 255) ksum = 1 << 20;
+  }
   if (ksum > 257) { delete h; set_error("gauss_kernel sum %d would overflow the Q8.8 row buffer", ksum); return DVS_ERR_ARG; }
   h->device = device;
   h->max_batch = params->max_batch > 0 ? params->max_batch : 1;
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
+  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
+    dvs_orb_destroy(h);
+    set_error("aux stream / event creation failed");
+    return DVS_ERR_HIP;
+  }
   build_ctor_tables(h);
   *out = h;
   return DVS_OK;
@@ -341,6 +395,9 @@ void dvs_orb_destroy(dvs_orb* h) {
   (void)hipStreamSynchronize(h->stream);
   h->timer.resolve();
   free_workspace(h);
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
+  if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -524,8 +581,8 @@ dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t
   h.prm = *params;
   build_ctor_tables(&h);
   Geom G;
-  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<int> xo, al, yo, be;
-  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, xo, al, yo, be));
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<int> xo, al, yo, be;
+  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, strips, xo, al, yo, be));
   for (int l = 0; l < G.nlevels; l++) {
     if (level_w) level_w[l] = G.lv[l].w;
     if (level_h) level_h[l] = G.lv[l].h;

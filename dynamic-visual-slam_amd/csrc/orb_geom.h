@@ -37,7 +37,11 @@ struct Geom {
   int32_t totalCells;   // over all levels
   int32_t kpBlock;      // sum over levels of (N + 4)
   int32_t outCap;       // nfeatures + 3 * nlevels
-  int32_t blurTiles;    // tiles of the blur launch over all levels
+  int32_t blurTiles;    // tiles of the (generic) blur launch over all levels
+  int32_t blurStrips;   // wave work items of the streaming blur
+  int32_t fastP;        // LDS tile pitch of the wave-per-cell FAST kernel (48 / 64 / 80)
+  int32_t fastRows;     // max cell height (rows of the LDS tile)
+  int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
   int32_t gk[7];
@@ -54,6 +58,10 @@ struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
 };
 
 struct BlurTile { int16_t level, tx, ty, pad; };
+
+// streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
+constexpr int kBlurBand = 32;
+struct BlurStrip { int16_t level, x0, w, y0; };
 
 // packed candidate / keypoint: x (12 bits) | y (12 bits) << 12 | score << 24, region-relative coordinates
 __host__ __device__ inline uint32_t pack_pt(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }

@@ -249,6 +249,182 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
   if (tid == 0) *countOut = min(total, cap);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-per-cell variant (used whenever level rows are dword aligned).  Same results as k_fast_cell,
+// restructured for the instruction-issue bound the first version hit:
+//   * one WAVEFRONT per cell, four independent cells per workgroup -> no workgroup barriers at all;
+//     LDS operations of one wave execute in issue order, phases are separated by wave-level fences
+//   * the cell is staged with aligned dword loads and kept at the same byte phase in LDS
+//   * rejection test on 4 pixels per lane: 11 aligned LDS dword reads + v_alignbyte windows replace
+//     36 byte reads; "every opposite pair has a darker (brighter) sample" is evaluated as
+//     max_pairs(min(d_k, d_k+8)) < -t  (min_pairs(max(..)) > t): 4 ops per pair, no per-sample classes
+//   * survivors (~17 % of pixels) are compacted IN ORDER by ballots, scored exactly, and the corners
+//     (~3 %) compacted again; NMS and the threshold fallback then touch only that short list.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ int fast_corner_score_p(const u8* c, int v) {
+  const int o[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,  -P + 3,  -2 * P + 2,  -3 * P + 1,
+                     -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3,   2 * P - 2,   3 * P - 1};
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - (int)c[o[k]];
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+  }
+  int A = -1000, B = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    A = max(A, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));
+    B = min(B, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));
+  }
+  return max(A, -B) - 1;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int lane = lane_id();
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ci >= g->totalCells) return;
+  const int f = blockIdx.y;
+  unsigned char* base = fsm + (threadIdx.x >> 6) * g->fastWaveLds;
+  const int tileBytes = g->fastRows * P;
+  u8* tile = base;
+  u8* score = base + tileBytes;
+  uint16_t* work = reinterpret_cast<uint16_t*>(base + 2 * tileBytes);
+  const Cell cell = cells[ci];
+  const LevelGeom& L = g->lv[cell.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, cell.level, pitch);
+  const int cw = cell.cw, ch = cell.ch;
+  const int iw = cw - 6, ih = ch - 6;
+  int* countOut = cellCount + (uint64_t)f * g->totalCells + ci;
+  if (iw <= 0 || ih <= 0) { if (lane == 0) *countOut = 0; return; }
+  const int xa = cell.x0 & ~3, ox = cell.x0 - xa;
+  // 1. stage (dword granularity, byte phase preserved) + clear the score tile
+  {
+    const int wpr = (ox + cw + 3) >> 2;  // <= P/4
+    const int kr = 64 / wpr;
+    const int myr = lane / wpr, myc = lane - myr * wpr;
+    const u8* rb = img + (uint64_t)cell.y0 * pitch + xa;
+    uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+    if (myr < kr)
+      for (int r = myr; r < ch; r += kr) t32[r * (P / 4) + myc] = *reinterpret_cast<const uint32_t*>(rb + (uint64_t)r * pitch + 4 * myc);
+    uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
+    for (int i = lane; i < ch * (P / 4); i += 64) s32[i] = 0;
+  }
+  wave_lds_fence();
+  const int tmin = g->minTh, tini = g->iniTh;
+  const unsigned long long ltmask = (1ull << lane) - 1ull;
+  // 2. rejection test, 4 pixels per lane
+  const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
+  const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
+  const int total = ng * ih;
+  const float invng = 1.0f / (float)ng;
+  int nwork = 0;
+  const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
+  for (int i0 = 0; i0 < total; i0 += 64) {
+    const int idx = i0 + lane;
+    const bool valid = idx < total;
+    const int row = valid ? (int)(((float)idx + 0.5f) * invng) : 0;
+    const int gi = valid ? idx - row * ng : 0;
+    const int y = row + 3;
+    const int wcol = g0 + gi;  // word column
+    const uint32_t* rp = t32 + y * (P / 4) + wcol;
+    const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
+    const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
+    const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
+    const uint32_t Lp2 = rp[2 * (P / 4) - 1], Op2 = rp[2 * (P / 4)], Rp2 = rp[2 * (P / 4) + 1];
+    const uint32_t s4 = __builtin_amdgcn_alignbyte(R0, O0, 3);    // ring 4  ( 3, 0)
+    const uint32_t s12 = __builtin_amdgcn_alignbyte(O0, L0, 1);   // ring 12 (-3, 0)
+    const uint32_t s2 = __builtin_amdgcn_alignbyte(Rp2, Op2, 2);  // ring 2  ( 2, 2)
+    const uint32_t s14 = __builtin_amdgcn_alignbyte(Op2, Lp2, 2); // ring 14 (-2, 2)
+    const uint32_t s6 = __builtin_amdgcn_alignbyte(Rm2, Om2, 2);  // ring 6  ( 2,-2)
+    const uint32_t s10 = __builtin_amdgcn_alignbyte(Om2, Lm2, 2); // ring 10 (-2,-2)
+    bool pass[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = wcol * 4 + j;
+      const int v = (int)((O0 >> (8 * j)) & 0xff);
+      const int d0 = (int)((Op3 >> (8 * j)) & 0xff) - v, d8 = (int)((Om3 >> (8 * j)) & 0xff) - v;
+      const int d4 = (int)((s4 >> (8 * j)) & 0xff) - v, d12 = (int)((s12 >> (8 * j)) & 0xff) - v;
+      const int d2 = (int)((s2 >> (8 * j)) & 0xff) - v, d10 = (int)((s10 >> (8 * j)) & 0xff) - v;
+      const int d6 = (int)((s6 >> (8 * j)) & 0xff) - v, d14 = (int)((s14 >> (8 * j)) & 0xff) - v;
+      const int mn = max(max(min(d0, d8), min(d4, d12)), max(min(d2, d10), min(d6, d14)));
+      const int mx = min(min(max(d0, d8), max(d4, d12)), min(max(d2, d10), max(d6, d14)));
+      pass[j] = valid && col >= cx0 && col < cx1 && (mn < -tmin || mx > tmin);
+    }
+    const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
+    int pos = nwork + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+    const int cbase = y * P + wcol * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (pass[j]) work[pos++] = (uint16_t)(cbase + j);
+    nwork += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+  }
+  wave_lds_fence();
+  // 3. exact score for the survivors; corners (score >= minTh) are re-compacted in place, still row-major
+  int ncorner = 0;
+  for (int e0 = 0; e0 < nwork; e0 += 64) {
+    const int e = e0 + lane;
+    const bool valid = e < nwork;
+    const int c = valid ? work[e] : 0;
+    int sc = 0;
+    if (valid) sc = fast_corner_score_p<P>(tile + c, (int)tile[c]);
+    const bool isc = valid && sc >= tmin;
+    if (isc) score[c] = (u8)sc;
+    const unsigned long long b = __ballot(isc);
+    wave_lds_fence();
+    if (isc) work[ncorner + __popcll(b & ltmask)] = (uint16_t)c;
+    ncorner += __popcll(b);
+  }
+  wave_lds_fence();
+  // 4. NMS on the corner list: bit 14 = strict 3x3 maximum, bit 15 = ... and score >= iniTh
+  bool any20 = false;
+  for (int e0 = 0; e0 < ncorner; e0 += 64) {
+    const int e = e0 + lane;
+    bool hi = false;
+    if (e < ncorner) {
+      const int c = work[e];
+      const int sc = score[c];
+      const bool ismax = sc > score[c - 1] && sc > score[c + 1] && sc > score[c - P - 1] && sc > score[c - P] && sc > score[c - P + 1] &&
+                         sc > score[c + P - 1] && sc > score[c + P] && sc > score[c + P + 1];
+      hi = ismax && sc >= tini;
+      work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0) | (hi ? 0x8000 : 0));
+    }
+    any20 = any20 || (__ballot(hi) != 0ull);
+  }
+  wave_lds_fence();
+  // 5. ordered emission
+  uint32_t* out = cand + (uint64_t)f * g->candPerFrame + L.candOff + (uint64_t)cell.slot * L.cellCap;
+  const int cap = L.cellCap;
+  const int selbit = any20 ? 0x8000 : 0x4000;
+  int nout = 0;
+  for (int e0 = 0; e0 < ncorner; e0 += 64) {
+    const int e = e0 + lane;
+    const int w = e < ncorner ? work[e] : 0;
+    const bool sel = (w & selbit) != 0;
+    const unsigned long long b = __ballot(sel);
+    if (sel) {
+      const int c = w & 0x3fff;
+      const int yy = c / P, xx = c - yy * P - ox;  // sub-image coordinates
+      const int rank = nout + __popcll(b & ltmask);
+      if (rank < cap) out[rank] = pack_pt(xx + cell.j * L.wCell, yy + cell.i * L.hCell, score[c]);
+    }
+    nout += __popcll(b);
+  }
+  if (lane == 0) *countOut = min(nout, cap);
+}
+
 // =============================================================================================
 // quad-tree distribution (DistributeOctTree).  One workgroup per (level, frame).  The reference's
 // std::list is kept as an ARRAY IN LIST ORDER that is rebuilt by prefix sums after every sweep:
@@ -640,6 +816,97 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, const 
                              (uint32_t)k3 * hb[r + 3][c] + (uint32_t)k4 * hb[r + 4][c] + (uint32_t)k5 * hb[r + 5][c] +
                              (uint32_t)k6 * hb[r + 6][c];
         dst[(uint64_t)(y0 + r) * L.pitch + x0 + c] = (u8)((acc + 32768u) >> 16);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant of the same filter (used whenever rows are 4-byte aligned): no LDS.  One wavefront
+// owns a strip of <= 256 columns (4 per lane, one aligned dword) and walks kBlurBand rows downwards:
+//   horizontal: the 12-byte window [left | own | right] comes from the neighbour lanes; every output
+//               is two v_dot4_u32_u8 against the packed kernel bytes (exact: Q8.8 sum <= 65 280)
+//   vertical  : the last 7 horizontal rows live in registers (ring of 7 x 4 values); one output row per
+//               step with v_mad_u32_u24 in Q16.16, (acc + 32768) >> 16, one coalesced dword store.
+// Image edges use BORDER_REFLECT_101 on the level itself: rows by (wave-uniform) index reflection,
+// columns by a per-byte reflected gather that only the first / last lane of an edge strip executes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t blur_word_reflect(const u8* row, int xw, int w) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v |= (uint32_t)row[reflect101(xw + i, w)] << (8 * i);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g, const BlurStrip* __restrict__ strips, int nstrips,
+                                                     ImgSrc src, u8* __restrict__ blur) {
+  const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= nstrips) return;
+  const BlurStrip s = strips[wi];
+  const int lane = lane_id();
+  const int f = blockIdx.y;
+  const LevelGeom& L = g->lv[s.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, s.level, pitch);
+  u8* dst = blur + (uint64_t)f * g->frameBytes + L.off;
+  const int W = L.w, H = L.h;
+  const int nl = (s.w + 3) >> 2;
+  const int x = s.x0 + lane * 4;
+  const bool act = lane < nl;
+  const bool full = x + 3 < W;
+  const uint32_t w0 = (uint32_t)g->gk[0] | ((uint32_t)g->gk[1] << 8) | ((uint32_t)g->gk[2] << 16) | ((uint32_t)g->gk[3] << 24);
+  const uint32_t w1 = (uint32_t)g->gk[4] | ((uint32_t)g->gk[5] << 8) | ((uint32_t)g->gk[6] << 16);
+  const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
+                          (uint32_t)g->gk[4], (uint32_t)g->gk[5], (uint32_t)g->gk[6]};
+  const int rows = min(kBlurBand, H - s.y0);
+  const int T = rows + 6;
+
+  auto load_own = [&](int k) -> uint32_t {
+    const u8* row = img + (uint64_t)reflect101(s.y0 + k - 3, H) * pitch;
+    if (!act) return 0u;
+    return full ? *reinterpret_cast<const uint32_t*>(row + x) : blur_word_reflect(row, x, W);
+  };
+  uint32_t ring[7][4];
+#pragma unroll
+  for (int a = 0; a < 7; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) ring[a][b] = 0;
+
+  uint32_t own = load_own(0);
+  for (int k0 = 0; k0 < T; k0 += 7) {
+#pragma unroll
+    for (int kk = 0; kk < 7; kk++) {
+      const int k = k0 + kk;
+      if (k < T) {
+        const u8* row = img + (uint64_t)reflect101(s.y0 + k - 3, H) * pitch;
+        const uint32_t nxt = (k + 1 < T) ? load_own(k + 1) : 0u;
+        uint32_t left = __shfl_up(own, 1);
+        uint32_t right = __shfl_down(own, 1);
+        if (act && lane == 0) left = (x - 4 >= 0) ? *reinterpret_cast<const uint32_t*>(row + x - 4) : blur_word_reflect(row, x - 4, W);
+        if (act && lane == nl - 1) right = (x + 7 < W) ? *reinterpret_cast<const uint32_t*>(row + x + 4) : blur_word_reflect(row, x + 4, W);
+        // px x+j: bytes x+j-3 .. x+j  = window offset j+1 ; bytes x+j+1 .. x+j+4 = window offset j+5
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(own, left, 1), a1 = __builtin_amdgcn_alignbyte(own, left, 2),
+                       a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
+        const uint32_t b0 = __builtin_amdgcn_alignbyte(right, own, 1), b1 = __builtin_amdgcn_alignbyte(right, own, 2),
+                       b2 = __builtin_amdgcn_alignbyte(right, own, 3), b3 = right;
+        ring[kk][0] = __builtin_amdgcn_udot4(b0, w1, __builtin_amdgcn_udot4(a0, w0, 0u, false), false);
+        ring[kk][1] = __builtin_amdgcn_udot4(b1, w1, __builtin_amdgcn_udot4(a1, w0, 0u, false), false);
+        ring[kk][2] = __builtin_amdgcn_udot4(b2, w1, __builtin_amdgcn_udot4(a2, w0, 0u, false), false);
+        ring[kk][3] = __builtin_amdgcn_udot4(b3, w1, __builtin_amdgcn_udot4(a3, w0, 0u, false), false);
+        if (k >= 6 && act) {
+          uint32_t o = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t acc = 32768u;
+#pragma unroll
+            for (int i = 0; i < 7; i++) acc = __umul24(ring[(kk + 1 + i) % 7][j], kv[i]) + acc;  // row k-6+i, weight i
+            o |= ((acc >> 16) & 0xffu) << (8 * j);
+          }
+          u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
+          if (full) *reinterpret_cast<uint32_t*>(orow) = o;
+          else for (int j = 0; j < 4 && x + j < W; j++) orow[j] = (u8)(o >> (8 * j));
+        }
+        own = nxt;
       }
     }
   }
