@@ -3,6 +3,7 @@
 // src/ORBextractor.cpp:409-469 ctor, 1086-1194 operator()/ComputePyramid).  Host code only builds
 // tables and enqueues kernels; there is no CPU compute path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <new>
@@ -377,6 +378,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
+  if (const char* e2 = getenv("DVS_NO_OVERLAP")) h->overlap = !(e2[0] == '1');  // diagnostics: serialise blur behind FAST
   if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
