@@ -113,7 +113,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    orb.enable_stage_timing(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -130,6 +129,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
+    # per-kernel durations: the same K steps again with hipEvents around every stage launch (the events themselves
+    # cost ~10 us of stream time per stage, so they are kept out of the whole-job timing above)
+    orb.enable_stage_timing(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
     stage_ms, stage_calls = orb.stage_times()
     orb.enable_stage_timing(False)
     if world > 1:

@@ -43,6 +43,7 @@ struct dvs_orb {
   Cell* d_cells = nullptr;
   BlurTile* d_tiles = nullptr;
   BlurStrip* d_strips = nullptr;
+  ResizeGroup* d_rgroups = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
   u8 *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -54,7 +55,7 @@ struct dvs_orb {
   u8* h_desc = nullptr;
   int* h_nout = nullptr;
   size_t octree_smem = 0;
-  int octree_nmax = 0;
+  int octree_nmax = 0, octree_ptscap = 0;
   int last_nimg = 0;
   ImgSrc last_src{};
   StageTimer timer;
@@ -63,14 +64,14 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
-  void* ptrs[] = {h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
+  void* ptrs[] = {h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
                   h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
-  h->d_strips = nullptr;
+  h->d_strips = nullptr; h->d_rgroups = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
@@ -139,13 +140,14 @@ void build_axis_table(int ssize, int dsize, bool clamp_like_x, std::vector<int>&
 }
 
 dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<Cell>& cells, std::vector<BlurTile>& tiles,
-                          std::vector<BlurStrip>& strips, std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
+                          std::vector<BlurStrip>& strips, std::vector<ResizeGroup>& rgroups, std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
   memset(&G, 0, sizeof(G));
   const int nl = h->prm.nlevels;
   G.nlevels = nl; G.rows = rows; G.cols = cols;
   G.iniTh = std::min(std::max(h->prm.ini_th_fast, 0), 255);  // cv::FAST clamps the threshold
   G.minTh = std::min(std::max(h->prm.min_th_fast, 0), 255);
   G.outCap = h->prm.nfeatures + 3 * nl;
+  if (const char* dbg = getenv("DVS_DEBUG")) G.debug = atoi(dbg);
   memcpy(G.gk, h->prm.gauss_kernel, sizeof(G.gk));
   memcpy(G.umax, h->umax, sizeof(G.umax));
   uint64_t off = 0, candOff = 0, ptsOff = 0;
@@ -210,8 +212,8 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     G.maxN = std::max(G.maxN, std::max(L.N + 3, 4 * nIni));
     for (int ty = 0; ty < (L.h + 15) / 16; ty++)
       for (int tx = 0; tx < (L.w + 63) / 64; tx++) tiles.push_back(BlurTile{(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
-    {  // streaming blur: equal-width strips of <= 256 columns (multiples of 4), bands of kBlurBand rows
-      const int ns = (L.w + 255) / 256;
+    {  // streaming blur: equal-width strips of <= 248 columns (multiples of 4), bands of kBlurBand rows
+      const int ns = (L.w + 247) / 248;  // 62 output lanes + 2 halo lanes per wavefront
       const int sw = ((L.w + ns - 1) / ns + 3) / 4 * 4;
       for (int y0 = 0; y0 < L.h; y0 += kBlurBand)
         for (int x0 = 0; x0 < L.w; x0 += sw) strips.push_back(BlurStrip{(int16_t)l, (int16_t)x0, (int16_t)std::min(sw, L.w - x0), (int16_t)y0});
@@ -220,6 +222,22 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
       L.xtab = (int)xofs.size(); L.ytab = (int)yofs.size();
       build_axis_table(G.lv[l - 1].w, L.w, true, xofs, alpha);
       build_axis_table(G.lv[l - 1].h, L.h, false, yofs, beta);
+      // 4-column groups for k_resize4 (valid while the four left taps span <= 8 bytes, i.e. scale factor <= 2)
+      L.gtab = (int)rgroups.size();
+      bool fits = true;
+      for (int x4 = 0; x4 < L.w; x4 += 4) {
+        ResizeGroup rg{};
+        rg.base = xofs[L.xtab + x4] & ~3;
+        for (int i = 0; i < 4; i++) {
+          const int x = std::min(x4 + i, L.w - 1);
+          const int o = xofs[L.xtab + x] - rg.base;
+          if (o < 0 || o > 7) fits = false;  // both taps must lie inside the 12-byte window handled by k_resize4
+          rg.offs |= (uint32_t)(o & 15) << (4 * i);
+          rg.alpha[i] = alpha[L.xtab + x];
+        }
+        rgroups.push_back(rg);
+      }
+      if (!fits) L.gtab = -1;
     }
   }
   G.frameBytes = off;
@@ -251,8 +269,9 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   free_workspace(h);
   Geom G;
-  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<int> xofs, alpha, yofs, beta;
-  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, strips, xofs, alpha, yofs, beta));
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
+  std::vector<int> xofs, alpha, yofs, beta;
+  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, strips, rgroups, xofs, alpha, yofs, beta));
   h->geom = G;
   const size_t B = (size_t)h->max_batch;
   DVS_HIP(hipMalloc((void**)&h->d_geom, sizeof(Geom)));
@@ -260,6 +279,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_TRY(upload(&h->d_cells, cells));
   DVS_TRY(upload(&h->d_tiles, tiles));
   DVS_TRY(upload(&h->d_strips, strips));
+  DVS_TRY(upload(&h->d_rgroups, rgroups));
   DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
   DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
@@ -279,7 +299,12 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipHostMalloc((void**)&h->h_desc, B * (size_t)G.outCap * 32));
   DVS_HIP(hipHostMalloc((void**)&h->h_nout, B * 4));
   h->octree_nmax = G.maxN + 8;
-  h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4);
+  {
+    int maxPts = 0;
+    for (int l = 0; l < G.nlevels; l++) maxPts = std::max(maxPts, G.lv[l].ptsCap);
+    h->octree_ptscap = std::min(6144, maxPts);
+  }
+  h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4) + (size_t)h->octree_ptscap * 8;
   DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
@@ -302,8 +327,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     const uint64_t sfs = l == 1 ? src.fstride0 : G.frameBytes;
     const int spitch = l == 1 ? (int)src.step0 : S.pitch;
     dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
-                       D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+    const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
+    if (aligned && D.gtab >= 0)
+      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h, D.pitch,
+                         h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+    else
+      hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
+                         D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
   }
   h->timer.end(st);
   // blur only depends on the pyramid: fork it onto the auxiliary stream so it overlaps FAST + quad-tree
@@ -336,7 +366,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
   hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(256), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
-                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax);
+                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
   if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
   // 5. orientation + descriptors + output records
@@ -583,8 +613,8 @@ dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t
   h.prm = *params;
   build_ctor_tables(&h);
   Geom G;
-  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<int> xo, al, yo, be;
-  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, strips, xo, al, yo, be));
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rg; std::vector<int> xo, al, yo, be;
+  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, strips, rg, xo, al, yo, be));
   for (int l = 0; l < G.nlevels; l++) {
     if (level_w) level_w[l] = G.lv[l].w;
     if (level_h) level_h[l] = G.lv[l].h;

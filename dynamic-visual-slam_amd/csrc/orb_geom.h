@@ -25,6 +25,7 @@ struct LevelGeom {
   int32_t regionW, regionH;  // maxBorder - minBorder
   int32_t kpOff;             // first slot of this level in the per-frame level-keypoint block (N + 4 slots)
   int32_t xtab, ytab;        // offsets of this level's resize tables (level >= 1)
+  int32_t gtab;              // offset of this level's ResizeGroup table
   float scale;               // mvScaleFactor[level]
   float kpSize;              // (float)(int)(31 * scale)
   uint64_t off;              // byte offset of the level inside a frame's pyramid (and blurred) block
@@ -44,6 +45,7 @@ struct Geom {
   int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
+  int32_t debug;        // diagnostics only (DVS_DEBUG env): bit 0 = skip the quad-tree sort (results invalid)
   int32_t gk[7];
   int32_t umax[16];
   uint64_t frameBytes;  // pyramid block per frame
@@ -58,6 +60,10 @@ struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
 };
 
 struct BlurTile { int16_t level, tx, ty, pad; };
+
+// resize: one entry per group of 4 output columns — aligned source byte `base`, 4-bit offsets of the four left taps
+// relative to base (each <= 7, right tap = +1), and the Q11 coefficient pairs (a0 | a1 << 16)
+struct ResizeGroup { int32_t base; uint32_t offs; int32_t alpha[4]; };
 
 // streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
 constexpr int kBlurBand = 32;

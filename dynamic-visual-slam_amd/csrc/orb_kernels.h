@@ -99,6 +99,68 @@ __global__ __launch_bounds__(256) void k_resize(const u8* __restrict__ src, uint
   }
 }
 
+// Same arithmetic, 4 output pixels per thread from TWO 12-byte source windows (dword loads) instead of 16 byte
+// gathers: the 4 left taps of a group lie within 8 bytes of the aligned `base` (scale <= 2), the right tap is the next
+// byte, and whenever the reference clamps the right tap (last column) its coefficient is 0.
+__global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
+                                                 u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
+                                                 const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
+                                                 const int* __restrict__ beta) {
+  const int gx = blockIdx.x * 64 + threadIdx.x;
+  const int x4 = gx * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (x4 >= dw || y >= dh) return;
+  const ResizeGroup t = xt[gx];
+  const u8* s = src + (uint64_t)f * sfs;
+  u8* d = dst + (uint64_t)f * dfs + (uint64_t)y * dp;
+  const int sy = yofs[y];
+  const int b = beta[y];
+  const int b0 = (int)(short)(b & 0xffff), b1 = b >> 16;
+  const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+  const u8* p0 = s + (uint64_t)r0 * sp + t.base;
+  const u8* p1 = s + (uint64_t)r1 * sp + t.base;
+  uint32_t w0[3], w1[3];
+  if (t.base + 12 <= sw) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p0);
+    const uint2 c = *reinterpret_cast<const uint2*>(p1);
+    w0[0] = a.x; w0[1] = a.y; w0[2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
+    w1[0] = c.x; w1[1] = c.y; w1[2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
+  } else {  // row tail: bytewise, never past the last valid pixel
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      uint32_t u = 0, v = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int o = min(4 * k + i, sw - 1 - t.base);
+        u |= (uint32_t)p0[o] << (8 * i);
+        v |= (uint32_t)p1[o] << (8 * i);
+      }
+      w0[k] = u; w1[k] = v;
+    }
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int o = (int)((t.offs >> (4 * i)) & 15u);
+    const bool hi = o >= 4;
+    const uint32_t sh8 = (uint32_t)(o & 3) * 8u;
+    const uint32_t pa = __builtin_amdgcn_alignbit(hi ? w0[2] : w0[1], hi ? w0[1] : w0[0], sh8);
+    const uint32_t pb = __builtin_amdgcn_alignbit(hi ? w1[2] : w1[1], hi ? w1[1] : w1[0], sh8);
+    const int a = t.alpha[i];
+    const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
+    const int h0 = (int)(pa & 0xff) * a0 + (int)((pa >> 8) & 0xff) * a1;
+    const int h1 = (int)(pb & 0xff) * a0 + (int)((pb >> 8) & 0xff) * a1;
+    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    out |= (uint32_t)(v & 0xff) << (8 * i);
+  }
+  if (x4 + 3 < dw) {
+    *reinterpret_cast<uint32_t*>(d + x4) = out;
+  } else {
+    for (int i = 0; i < 4 && x4 + i < dw; i++) d[x4 + i] = (u8)(out >> (8 * i));
+  }
+}
+
 // =============================================================================================
 // FAST-9/16 per reference cell.  One 256-thread workgroup = one cell of one frame:
 //   1. stage the (cw x ch) sub-image into LDS
@@ -551,7 +613,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
                                                 const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
-                                                int* __restrict__ lvlKpCount, int nmax) {
+                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int wsum[5];
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
@@ -571,7 +633,11 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
     sh.expl = (int*)p; p += 4 * nmax;
     sh.ecum = (int*)p; p += 4 * nmax;
   }
-  uint32_t* pts = ptsAll + (uint64_t)f * g->ptsPerFrame + L.ptsOff;
+  // point list + node-of-point: LDS when the level's candidates fit (the sweeps read them ~20 times), HBM otherwise
+  uint32_t* ldsPts = (uint32_t*)(smem + (size_t)nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4));
+  int* ldsNodeOf = (int*)(ldsPts + ptsLdsCap);
+  uint32_t* gpts = ptsAll + (uint64_t)f * g->ptsPerFrame + L.ptsOff;
+  uint32_t* pts = gpts;
   int* nodeOf = nodeOfAll + (uint64_t)f * g->ptsPerFrame + L.ptsOff;
   const uint32_t* cnd = cand + (uint64_t)f * g->candPerFrame + L.candOff;
   const int* cc = cellCount + (uint64_t)f * g->totalCells + L.cellBase;
@@ -590,10 +656,23 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
     }
     if (tid == 0) { s_n = carry; candTotal[f * g->nlevels + level] = carry; }
     __syncthreads();
-    const int w = tid >> 6;
-    for (int c = w; c < L.nCells; c += 4) {
-      const int cnt = cc[c], off = co[c];
-      for (int t = lane_id(); t < cnt; t += 64) pts[off + t] = cnd[(uint64_t)c * L.cellCap + t];
+    const bool inLds = s_n <= ptsLdsCap;
+    if (inLds) { pts = ldsPts; nodeOf = ldsNodeOf; }
+    // cell of candidate i = last cell whose offset is <= i (binary search; offsets in LDS when they fit).  One
+    // independent lookup per candidate instead of a serial per-cell copy chain.
+    const bool coLds = L.nCells <= 4 * nmax;
+    int* lco = sh.childCnt;
+    if (coLds) for (int c = tid; c < L.nCells; c += 256) lco[c] = co[c];
+    __syncthreads();
+    const int* cof = coLds ? lco : co;
+    const int total = s_n;
+    for (int i = tid; i < total; i += 256) {
+      int lo = 0, hi = L.nCells;  // first cell with offset > i
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cof[mid] <= i) lo = mid + 1; else hi = mid; }
+      const int c = lo - 1;
+      const uint32_t v = cnd[(uint64_t)c * L.cellCap + (i - cof[c])];
+      gpts[i] = v;                      // kept in HBM too: dvs_orb_get_candidates reads it
+      if (inLds) ldsPts[i] = v;
     }
     __syncthreads();
   }
@@ -707,7 +786,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
       }
       for (int k = tid; k < Sb; k += 256) sh.flag[k] = 0;
       __syncthreads();
-      if (tid == 0) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
+      if (tid == 0 && !(g->debug & 1)) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
       __syncthreads();
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
@@ -850,10 +929,11 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const u8* img = level_ptr(g, src, f, s.level, pitch);
   u8* dst = blur + (uint64_t)f * g->frameBytes + L.off;
   const int W = L.w, H = L.h;
-  const int nl = (s.w + 3) >> 2;
-  const int x = s.x0 + lane * 4;
-  const bool act = lane < nl;
-  const bool full = x + 3 < W;
+  const int nlo = (s.w + 3) >> 2;          // output lanes 1..nlo; lanes 0 and nlo+1 only supply the halo words
+  const int x = s.x0 - 4 + lane * 4;       // first pixel of this lane's word
+  const bool ld = lane <= nlo + 1;
+  const bool outl = lane >= 1 && lane <= nlo;
+  const bool inside = x >= 0 && x + 3 < W;
   const uint32_t w0 = (uint32_t)g->gk[0] | ((uint32_t)g->gk[1] << 8) | ((uint32_t)g->gk[2] << 16) | ((uint32_t)g->gk[3] << 24);
   const uint32_t w1 = (uint32_t)g->gk[4] | ((uint32_t)g->gk[5] << 8) | ((uint32_t)g->gk[6] << 16);
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
@@ -862,9 +942,12 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const int T = rows + 6;
 
   auto load_own = [&](int k) -> uint32_t {
-    const u8* row = img + (uint64_t)reflect101(s.y0 + k - 3, H) * pitch;
-    if (!act) return 0u;
-    return full ? *reinterpret_cast<const uint32_t*>(row + x) : blur_word_reflect(row, x, W);
+    int sy = s.y0 + k - 3;                 // BORDER_REFLECT_101 on rows (H >= 7 always holds for a level)
+    sy = sy < 0 ? -sy : sy;
+    sy = sy >= H ? 2 * H - 2 - sy : sy;
+    const u8* row = img + (uint64_t)sy * pitch;
+    if (!ld) return 0u;
+    return inside ? *reinterpret_cast<const uint32_t*>(row + x) : blur_word_reflect(row, x, W);
   };
   uint32_t ring[7][4];
 #pragma unroll
@@ -873,17 +956,15 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
     for (int b = 0; b < 4; b++) ring[a][b] = 0;
 
   uint32_t own = load_own(0);
+  uint32_t nxt = T > 1 ? load_own(1) : 0u;
   for (int k0 = 0; k0 < T; k0 += 7) {
 #pragma unroll
     for (int kk = 0; kk < 7; kk++) {
       const int k = k0 + kk;
       if (k < T) {
-        const u8* row = img + (uint64_t)reflect101(s.y0 + k - 3, H) * pitch;
-        const uint32_t nxt = (k + 1 < T) ? load_own(k + 1) : 0u;
-        uint32_t left = __shfl_up(own, 1);
-        uint32_t right = __shfl_down(own, 1);
-        if (act && lane == 0) left = (x - 4 >= 0) ? *reinterpret_cast<const uint32_t*>(row + x - 4) : blur_word_reflect(row, x - 4, W);
-        if (act && lane == nl - 1) right = (x + 7 < W) ? *reinterpret_cast<const uint32_t*>(row + x + 4) : blur_word_reflect(row, x + 4, W);
+        const uint32_t nn = (k + 2 < T) ? load_own(k + 2) : 0u;  // two rows in flight
+        const uint32_t left = __shfl_up(own, 1);
+        const uint32_t right = __shfl_down(own, 1);
         // px x+j: bytes x+j-3 .. x+j  = window offset j+1 ; bytes x+j+1 .. x+j+4 = window offset j+5
         const uint32_t a0 = __builtin_amdgcn_alignbyte(own, left, 1), a1 = __builtin_amdgcn_alignbyte(own, left, 2),
                        a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
@@ -893,7 +974,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
         ring[kk][1] = __builtin_amdgcn_udot4(b1, w1, __builtin_amdgcn_udot4(a1, w0, 0u, false), false);
         ring[kk][2] = __builtin_amdgcn_udot4(b2, w1, __builtin_amdgcn_udot4(a2, w0, 0u, false), false);
         ring[kk][3] = __builtin_amdgcn_udot4(b3, w1, __builtin_amdgcn_udot4(a3, w0, 0u, false), false);
-        if (k >= 6 && act) {
+        if (k >= 6 && outl) {
           uint32_t o = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -903,10 +984,11 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
             o |= ((acc >> 16) & 0xffu) << (8 * j);
           }
           u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
-          if (full) *reinterpret_cast<uint32_t*>(orow) = o;
+          if (x + 3 < W) *reinterpret_cast<uint32_t*>(orow) = o;
           else for (int j = 0; j < 4 && x + j < W; j++) orow[j] = (u8)(o >> (8 * j));
         }
         own = nxt;
+        nxt = nn;
       }
     }
   }
