@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const 
   const int nt = ntArr ? ntArr[pair] : ntConst;
   const int q0 = blockIdx.x * 64;
   if (q0 >= nq) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: train addresses become scalar
   const int qi = q0 + lane;
   const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
   const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
@@ -36,8 +37,30 @@ __global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const 
   const int jb = w * chunk, je = min(nt, jb + chunk);
   const u64* tp = t + (size_t)pair * tStrideRows * 4;
   int best = INT_MAX, bi = -1;
-  for (int j = jb; j < je; j++) {
-    const u64* r = tp + (size_t)j * 4;  // wave-uniform address -> s_load_dwordx8
+  int j = jb;
+  if (j + 4 <= je) {  // software pipeline: the scalar loads of trip i+1 are issued before the popcounts of trip i
+    u64 rr[16], nx[16];
+    {
+      const u64* r = tp + (size_t)j * 4;
+#pragma unroll
+      for (int k = 0; k < 16; k++) rr[k] = r[k];
+    }
+    for (; j + 4 <= je; j += 4) {
+      const bool more = j + 8 <= je;
+      const u64* r = tp + (size_t)(more ? j + 4 : j) * 4;
+#pragma unroll
+      for (int k = 0; k < 16; k++) nx[k] = r[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int d = __popcll(a0 ^ rr[4 * k]) + __popcll(a1 ^ rr[4 * k + 1]) + __popcll(a2 ^ rr[4 * k + 2]) + __popcll(a3 ^ rr[4 * k + 3]);
+        if (d < best) { best = d; bi = j + k; }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) rr[k] = nx[k];
+    }
+  }
+  for (; j < je; j++) {
+    const u64* r = tp + (size_t)j * 4;
     const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
     if (d < best) { best = d; bi = j; }
   }

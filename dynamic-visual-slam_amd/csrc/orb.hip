@@ -150,6 +150,17 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
   if (const char* dbg = getenv("DVS_DEBUG")) G.debug = atoi(dbg);
   memcpy(G.gk, h->prm.gauss_kernel, sizeof(G.gk));
   memcpy(G.umax, h->umax, sizeof(G.umax));
+  for (int lane = 0; lane < 64; lane++) {
+    const int row = lane >> 1, half = lane & 1, v = row - kHalfPatch;
+    for (int i = 0; i < 16; i++) {
+      const int u = half ? 1 + i : -kHalfPatch + i;
+      const bool in = row <= 2 * kHalfPatch && std::abs(u) <= kHalfPatch && std::abs(u) <= h->umax[std::abs(v)];
+      if (in) {
+        G.icw[lane][i >> 2] |= (uint32_t)(u + kHalfPatch) << (8 * (i & 3));
+        G.icw[lane][4 + (i >> 2)] |= 1u << (8 * (i & 3));
+      }
+    }
+  }
   uint64_t off = 0, candOff = 0, ptsOff = 0;
   int kpOff = 0;
   for (int l = 0; l < nl; l++) {
@@ -179,7 +190,7 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
       set_error("level %d: cell %dx%d / region %dx%d / quota %d exceeds the supported limits", l, L.wCell, L.hCell, L.regionW, L.regionH, L.N);
       return DVS_ERR_UNSUPPORTED;
     }
-    L.pitch = (int)align_up(L.w, 64);
+    L.pitch = (int)align_up(L.w + 8, 64);  // >= 8 spare columns: k_resize4 writes the REFLECT_101 continuation there
     L.off = off;
     off += align_up((uint64_t)L.pitch * L.h, 256);
     L.cellBase = (int)cells.size();
@@ -225,15 +236,21 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
       // 4-column groups for k_resize4 (valid while the four left taps span <= 8 bytes, i.e. scale factor <= 2)
       L.gtab = (int)rgroups.size();
       bool fits = true;
-      for (int x4 = 0; x4 < L.w; x4 += 4) {
+      for (int x4 = 0; x4 < L.w + 8; x4 += 4) {  // 2 extra groups: columns >= w mirror column 2w-2-x (blur border)
         ResizeGroup rg{};
-        rg.base = xofs[L.xtab + x4] & ~3;
+        int cols4[4], mn = 1 << 30;
         for (int i = 0; i < 4; i++) {
-          const int x = std::min(x4 + i, L.w - 1);
-          const int o = xofs[L.xtab + x] - rg.base;
+          int x = x4 + i;
+          if (x >= L.w) x = std::max(0, 2 * L.w - 2 - x);
+          cols4[i] = x;
+          mn = std::min(mn, xofs[L.xtab + x]);
+        }
+        rg.base = mn & ~3;
+        for (int i = 0; i < 4; i++) {
+          const int o = xofs[L.xtab + cols4[i]] - rg.base;
           if (o < 0 || o > 7) fits = false;  // both taps must lie inside the 12-byte window handled by k_resize4
           rg.offs |= (uint32_t)(o & 15) << (4 * i);
-          rg.alpha[i] = alpha[L.xtab + x];
+          rg.alpha[i] = alpha[L.xtab + cols4[i]];
         }
         rgroups.push_back(rg);
       }
@@ -326,10 +343,10 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     const u8* sp = l == 1 ? src.img0 : h->d_pyr + S.off;
     const uint64_t sfs = l == 1 ? src.fstride0 : G.frameBytes;
     const int spitch = l == 1 ? (int)src.step0 : S.pitch;
-    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
+    dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
     const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
     if (aligned && D.gtab >= 0)
-      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h, D.pitch,
+      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
@@ -344,8 +361,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
   }
   h->timer.begin(DVS_STAGE_BLUR, bst);
-  // streaming kernel needs dword-aligned level-0 rows; our own pyramid levels always are
-  if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0)
+  // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
+  // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
+  bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
+  for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && G.lv[l].gtab >= 0;
+  if (stream_ok)
     hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
   else
     hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);

@@ -48,6 +48,9 @@ struct Geom {
   int32_t debug;        // diagnostics only (DVS_DEBUG env): bit 0 = skip the quad-tree sort (results invalid)
   int32_t gk[7];
   int32_t umax[16];
+  // intensity-centroid patch as per-lane byte weights: lane = 2*row + half covers 16 bytes of one patch row;
+  // [0..3] = (u + 15) where the pixel is inside the circular patch else 0, [4..7] = 1 / 0 membership
+  uint32_t icw[64][8];
   uint64_t frameBytes;  // pyramid block per frame
   uint64_t candPerFrame, ptsPerFrame;  // uint32 elements per frame
   LevelGeom lv[DVS_MAX_LEVELS];

@@ -154,11 +154,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
     out |= (uint32_t)(v & 0xff) << (8 * i);
   }
-  if (x4 + 3 < dw) {
-    *reinterpret_cast<uint32_t*>(d + x4) = out;
-  } else {
-    for (int i = 0; i < 4 && x4 + i < dw; i++) d[x4 + i] = (u8)(out >> (8 * i));
-  }
+  *reinterpret_cast<uint32_t*>(d + x4) = out;  // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
 }
 
 // =============================================================================================
@@ -931,9 +927,13 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const int W = L.w, H = L.h;
   const int nlo = (s.w + 3) >> 2;          // output lanes 1..nlo; lanes 0 and nlo+1 only supply the halo words
   const int x = s.x0 - 4 + lane * 4;       // first pixel of this lane's word
-  const bool ld = lane <= nlo + 1;
   const bool outl = lane >= 1 && lane <= nlo;
-  const bool inside = x >= 0 && x + 3 < W;
+  // Columns: levels >= 1 carry >= 8 reflected columns right of the image (written by k_resize4), so plain loads work
+  // there; the left border of every level and the right border of level 0 (width % 4 == 0, no padding in a caller's
+  // buffer) are byte permutations of the edge lane's own word.  No branches, no byte gathers in the row loop.
+  const int xmax = s.level == 0 ? W - 4 : ((W + 8) & ~3) - 4;  // last loadable word start (levels >= 1: padded width)
+  const int xl = min(max(x, 0), xmax);
+  const bool left_edge = x == 0, right_edge = s.level == 0 && x + 4 == W;
   const uint32_t w0 = (uint32_t)g->gk[0] | ((uint32_t)g->gk[1] << 8) | ((uint32_t)g->gk[2] << 16) | ((uint32_t)g->gk[3] << 24);
   const uint32_t w1 = (uint32_t)g->gk[4] | ((uint32_t)g->gk[5] << 8) | ((uint32_t)g->gk[6] << 16);
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
@@ -945,9 +945,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
     int sy = s.y0 + k - 3;                 // BORDER_REFLECT_101 on rows (H >= 7 always holds for a level)
     sy = sy < 0 ? -sy : sy;
     sy = sy >= H ? 2 * H - 2 - sy : sy;
-    const u8* row = img + (uint64_t)sy * pitch;
-    if (!ld) return 0u;
-    return inside ? *reinterpret_cast<const uint32_t*>(row + x) : blur_word_reflect(row, x, W);
+    return *reinterpret_cast<const uint32_t*>(img + (uint64_t)sy * pitch + xl);
   };
   uint32_t ring[7][4];
 #pragma unroll
@@ -955,16 +953,24 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
 #pragma unroll
     for (int b = 0; b < 4; b++) ring[a][b] = 0;
 
-  uint32_t own = load_own(0);
-  uint32_t nxt = T > 1 ? load_own(1) : 0u;
+  // rows are fetched a whole group of 7 ahead: 7..14 independent 256-byte row loads in flight per wavefront keep
+  // enough bytes outstanding for HBM latency (with 1-2 in flight the kernel ran latency-bound at ~1.5 TB/s)
+  uint32_t cur[7], nxt[7];
+#pragma unroll
+  for (int kk = 0; kk < 7; kk++) cur[kk] = kk < T ? load_own(kk) : 0u;
   for (int k0 = 0; k0 < T; k0 += 7) {
+#pragma unroll
+    for (int kk = 0; kk < 7; kk++) nxt[kk] = (k0 + 7 + kk < T) ? load_own(k0 + 7 + kk) : 0u;
 #pragma unroll
     for (int kk = 0; kk < 7; kk++) {
       const int k = k0 + kk;
       if (k < T) {
-        const uint32_t nn = (k + 2 < T) ? load_own(k + 2) : 0u;  // two rows in flight
-        const uint32_t left = __shfl_up(own, 1);
-        const uint32_t right = __shfl_down(own, 1);
+        const uint32_t own = cur[kk];
+        uint32_t left = __shfl_up(own, 1);
+        uint32_t right = __shfl_down(own, 1);
+        // px -3,-2,-1 = px 3,2,1 ; px W,W+1,W+2 = px W-2,W-3,W-4
+        if (left_edge) left = ((own >> 24) << 8) | (((own >> 16) & 0xffu) << 16) | (((own >> 8) & 0xffu) << 24);
+        if (right_edge) right = ((own >> 16) & 0xffu) | (((own >> 8) & 0xffu) << 8) | ((own & 0xffu) << 16);
         // px x+j: bytes x+j-3 .. x+j  = window offset j+1 ; bytes x+j+1 .. x+j+4 = window offset j+5
         const uint32_t a0 = __builtin_amdgcn_alignbyte(own, left, 1), a1 = __builtin_amdgcn_alignbyte(own, left, 2),
                        a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
@@ -984,13 +990,12 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
             o |= ((acc >> 16) & 0xffu) << (8 * j);
           }
           u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
-          if (x + 3 < W) *reinterpret_cast<uint32_t*>(orow) = o;
-          else for (int j = 0; j < 4 && x + j < W; j++) orow[j] = (u8)(o >> (8 * j));
+          *reinterpret_cast<uint32_t*>(orow) = o;  // the blurred block has the padded pitch too: a tail word may spill into it
         }
-        own = nxt;
-        nxt = nn;
       }
     }
+#pragma unroll
+    for (int kk = 0; kk < 7; kk++) cur[kk] = nxt[kk];
   }
 }
 
@@ -1047,26 +1052,28 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   int pitch;
   const u8* img = level_ptr(g, src, f, level, pitch);
 
-  // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch (umax).  Two patch rows per
-  // iteration: lanes 0..30 take row v = it-15, lanes 32..62 take row v = it+1.
+  // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch (umax).  Lane = 2*row + half owns 16 bytes of
+  // one patch row (4 unaligned dword loads); membership and the u weights are per-lane byte tables (Geom::icw), so the
+  // sums are 8 v_dot4_u32_u8:  sum u*I = sum (u+15)*I - 15 * sum I.  Exact integer arithmetic, order independent.
   int m10 = 0, m01 = 0;
   {
-    const int u = (lane & 31) - kHalfPatch;
-    const int half = lane >> 5;
-    const bool col_ok = (lane & 31) < 31;
-    const u8* center = img + (uint64_t)y * pitch + x;
-    for (int it = 0; it < 16; it++) {
-      const int v = it - kHalfPatch + 16 * half;
-      if (col_ok && v <= kHalfPatch) {
-        const int av = v < 0 ? -v : v;
-        const int au = u < 0 ? -u : u;
-        if (au <= g->umax[av]) {
-          const int I = center[(int64_t)v * pitch + u];
-          m10 += u * I;
-          m01 += v * I;
-        }
-      }
-    }
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    const int row = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
+    const int v = row - kHalfPatch;
+    const u8* p = img + (int64_t)(y + v) * pitch + x + (half ? 1 : -kHalfPatch);
+    const uint32_t d0 = *reinterpret_cast<const u32u*>(p), d1 = *reinterpret_cast<const u32u*>(p + 4),
+                   d2 = *reinterpret_cast<const u32u*>(p + 8), d3 = *reinterpret_cast<const u32u*>(p + 12);
+    const uint32_t* wt = g->icw[lane];
+    uint32_t su = __builtin_amdgcn_udot4(d0, wt[0], 0u, false);
+    su = __builtin_amdgcn_udot4(d1, wt[1], su, false);
+    su = __builtin_amdgcn_udot4(d2, wt[2], su, false);
+    su = __builtin_amdgcn_udot4(d3, wt[3], su, false);
+    uint32_t sm = __builtin_amdgcn_udot4(d0, wt[4], 0u, false);
+    sm = __builtin_amdgcn_udot4(d1, wt[5], sm, false);
+    sm = __builtin_amdgcn_udot4(d2, wt[6], sm, false);
+    sm = __builtin_amdgcn_udot4(d3, wt[7], sm, false);
+    m10 = (int)su - kHalfPatch * (int)sm;
+    m01 = v * (int)sm;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
   }
