@@ -53,6 +53,31 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0):
             "sample": f"{done} frames 1280x720 extract(2000kp)+match vs previous frame, oracle/ C++ -O2, 1 thread"}
 
 
+def ba_bench(dvslam_amd, synth, device, iters=200):
+    """second half of BASELINE.json's metric: BA residual-evaluations/s on the 10 KF x 2000 LM window (config 3).
+    One evaluation = all 20 000 residual blocks with local Jacobians, Huber corrector, cost and the H_pp / H_ll / g
+    reductions (k_ba_eval + k_ba_reduce), parameters and outputs resident in HBM."""
+    import oracle_bindings as ob
+    P = synth.make_ba_problem(K=10, L=2000, seed=42)
+    g = dvslam_amd.BAProblem(P, device=device)
+    g.evaluate_device(20); g.synchronize()
+    t0 = time.perf_counter(); g.evaluate_device(iters); g.synchronize(); dt = time.perf_counter() - t0
+    R = len(P["cam_idx"])
+    out = {"metric": "BA residual-eval/sec 10KF x 2000LM", "evals_per_s": round(iters / dt, 1), "residual_blocks_per_s": round(iters * R / dt, 1),
+           "us_per_eval": round(1e6 * dt / iters, 2), "residual_blocks": R, "dtype": "f64",
+           "algorithmic_bytes_per_eval": 528_560 + R * 160, "achieved_GBps": round((528_560 + R * 160) * iters / dt / 1e9, 2)}
+    s = g.solve(20)
+    out["lm_solve"] = {"iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "initial_cost": s.initial_cost, "final_cost": s.final_cost}
+    o = ob.OracleBA(P)
+    o.evaluate()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 3.0:
+        o.evaluate(); n += 1
+    out["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 2), "unit": "evals/s", "cores": 1, "kind": "port",
+                           "sample": f"{n} evaluations of the same window with the oracle (Jet<double,10> autodiff as Ceres does), 1 thread"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +194,7 @@ def main():
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]
             out["cpu_baseline"] = cpu_baseline(cb_frames, args.nfeatures)
             out["speedup_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1)
+            out["ba"] = ba_bench(dvslam_amd, synth, local)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -98,8 +98,8 @@ void resizeLinearU8(const u8* src, int sw, int sh, size_t sstep, u8* dst, int dw
     beta[2 * dy + 1] = satShort(cvRoundF(fy * COEF_SCALE));
   }
   std::vector<int> r0(dw), r1(dw);
+  int have0 = -1, have1 = -1;  // source rows currently held in r0 / r1 (resize.cpp keeps its row buffers the same way)
   auto hline = [&](int sy, std::vector<int>& D) {
-    sy = std::min(std::max(sy, 0), sh - 1);  // clip(sy, 0, ssize.height)
     const u8* S = src + (size_t)sy * sstep;
     int dx = 0;
     for (; dx < xmax; dx++) {
@@ -109,12 +109,17 @@ void resizeLinearU8(const u8* src, int sw, int sh, size_t sstep, u8* dst, int dw
     for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * COEF_SCALE;
   };
   for (int dy = 0; dy < dh; dy++) {
-    hline(yofs[dy], r0);
-    hline(yofs[dy] + 1, r1);
+    const int s0 = std::min(std::max(yofs[dy], 0), sh - 1), s1 = std::min(std::max(yofs[dy] + 1, 0), sh - 1);  // clip(sy, 0, ssize.height)
+    if (have0 != s0) {
+      if (have1 == s0) { r0.swap(r1); std::swap(have0, have1); }
+      else { hline(s0, r0); have0 = s0; }
+    }
+    if (have1 != s1) { hline(s1, r1); have1 = s1; }
     int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
     u8* D = dst + (size_t)dy * dstep;
+    const int* R0 = r0.data(); const int* R1 = r1.data();
     for (int x = 0; x < dw; x++)
-      D[x] = (u8)((((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2);
+      D[x] = (u8)((((b0 * (R0[x] >> 4)) >> 16) + ((b1 * (R1[x] >> 4)) >> 16) + 2) >> 2);
   }
 }
 
@@ -168,14 +173,30 @@ void fast9_16(const u8* img, int cols, int rows, size_t step, int threshold, std
   for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
   threshold = std::min(std::max(threshold, 0), 255);
   // score buffer for the whole sub-image (the reference keeps a 3-row ring; same values)
-  std::vector<u8> sc((size_t)cols * rows, 0);
-  std::vector<u8> iscorner((size_t)cols * rows, 0);
+  static thread_local std::vector<u8> sc, iscorner;
+  sc.assign((size_t)cols * rows, 0);
+  iscorner.assign((size_t)cols * rows, 0);
+  // threshold_tab of fast.cpp: 1 = darker than v - t, 2 = brighter than v + t
+  u8 threshold_tab[512];
+  for (int i = -255; i <= 255; i++) threshold_tab[i + 255] = (u8)(i < -threshold ? 1 : i > threshold ? 2 : 0);
   for (int i = 3; i < rows - 3; i++) {
     const u8* ptr = img + (size_t)i * step + 3;
     for (int j = 3; j < cols - 3; j++, ptr++) {
       int v = ptr[0];
+      // high-speed rejection exactly as FAST_t<16> does it: every opposite pair needs a darker (brighter) sample
+      const u8* tab = &threshold_tab[0] - v + 255;
+      int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+      if (d == 0) continue;
+      d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+      d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+      d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+      if (d == 0) continue;
+      d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+      d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+      d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+      d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
       bool corner = false;
-      {  // darker arc: x < v - threshold
+      if (d & 1) {  // darker arc: x < v - threshold
         int vt = v - threshold, count = 0;
         for (int k = 0; k < N; k++) {
           int x = ptr[pixel[k]];
@@ -183,7 +204,7 @@ void fast9_16(const u8* img, int cols, int rows, size_t step, int threshold, std
           else count = 0;
         }
       }
-      if (!corner) {  // brighter arc
+      if (!corner && (d & 2)) {  // brighter arc
         int vt = v + threshold, count = 0;
         for (int k = 0; k < N; k++) {
           int x = ptr[pixel[k]];
@@ -283,20 +304,29 @@ inline int reflect101(int p, int len) {
 }
 void gaussBlur7(const Image& src, Image& dst, const int k[7]) {
   dst.create(src.cols, src.rows);
-  std::vector<uint16_t> h((size_t)src.cols * src.rows);
-  for (int y = 0; y < src.rows; y++) {
+  const int W = src.cols, H = src.rows;
+  std::vector<uint16_t> h((size_t)W * H);
+  for (int y = 0; y < H; y++) {
     const u8* s = src.row(y);
-    for (int x = 0; x < src.cols; x++) {
+    uint16_t* hr = &h[(size_t)y * W];
+    for (int x = 0; x < W; x++) {
       unsigned acc = 0;
-      for (int i = 0; i < 7; i++) acc += (unsigned)k[i] * s[reflect101(x + i - 3, src.cols)];
-      h[(size_t)y * src.cols + x] = (uint16_t)acc;
+      if (x >= 3 && x + 3 < W) {  // interior: no border arithmetic
+        const u8* p = s + x - 3;
+        acc = k[0] * p[0] + k[1] * p[1] + k[2] * p[2] + k[3] * p[3] + k[4] * p[4] + k[5] * p[5] + k[6] * p[6];
+      } else {
+        for (int i = 0; i < 7; i++) acc += (unsigned)k[i] * s[reflect101(x + i - 3, W)];
+      }
+      hr[x] = (uint16_t)acc;
     }
   }
-  for (int y = 0; y < src.rows; y++) {
+  for (int y = 0; y < H; y++) {
     u8* d = dst.row(y);
-    for (int x = 0; x < src.cols; x++) {
-      uint32_t acc = 0;
-      for (int j = 0; j < 7; j++) acc += (uint32_t)k[j] * h[(size_t)reflect101(y + j - 3, src.rows) * src.cols + x];
+    const uint16_t* r[7];
+    for (int j = 0; j < 7; j++) r[j] = &h[(size_t)reflect101(y + j - 3, H) * W];
+    for (int x = 0; x < W; x++) {
+      const uint32_t acc = (uint32_t)k[0] * r[0][x] + (uint32_t)k[1] * r[1][x] + (uint32_t)k[2] * r[2][x] + (uint32_t)k[3] * r[3][x] +
+                           (uint32_t)k[4] * r[4][x] + (uint32_t)k[5] * r[5][x] + (uint32_t)k[6] * r[6][x];
       d[x] = (u8)((acc + 32768u) >> 16);
     }
   }

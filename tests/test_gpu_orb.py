@@ -25,7 +25,8 @@ def _assert_same_result(n, kps, desc, n2, kps2, desc2):
 
 
 @pytest.mark.parametrize("rows,cols,nf,nl,frame", [(240, 320, 300, 5, 0), (480, 640, 500, 8, 1), (720, 1280, 2000, 8, 0),
-                                                   (360, 1000, 700, 6, 3), (600, 400, 1000, 7, 2)])
+                                                   (360, 1000, 700, 6, 3), (600, 400, 1000, 7, 2),
+                                                   (481, 643, 600, 6, 1), (250, 330, 200, 4, 4)])  # widths % 4 != 0: generic blur path
 def test_stage_and_end_to_end_parity(gpu, oracle, rows, cols, nf, nl, frame):
     img = synth.make_frame(frame, cols=cols, rows=rows)
     g, o = _pair(oracle, nf, nl)
