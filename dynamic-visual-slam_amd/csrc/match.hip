@@ -18,11 +18,12 @@ namespace dvs {
 
 typedef unsigned long long u64;
 
-__global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
+constexpr int kSplit = 8;  // train-set slices per workgroup (one wavefront each): finer waves balance the last scheduling round
+__global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
                                                const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
                                                int* __restrict__ outIdx, int* __restrict__ outDist) {
-  __shared__ int sd[4][64];
-  __shared__ int si[4][64];
+  __shared__ int sd[kSplit][64];
+  __shared__ int si[kSplit][64];
   const int pair = blockIdx.y;
   const int nq = nqArr ? nqArr[pair] : nqConst;
   const int nt = ntArr ? ntArr[pair] : ntConst;
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const 
   const int qi = q0 + lane;
   const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
   const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
-  const int chunk = (nt + 3) >> 2;
-  const int jb = w * chunk, je = min(nt, jb + chunk);
+  const int chunk = (nt + kSplit - 1) / kSplit;
+  const int jb = min(nt, w * chunk), je = min(nt, jb + chunk);
   const u64* tp = t + (size_t)pair * tStrideRows * 4;
   int best = INT_MAX, bi = -1;
   int j = jb;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void k_match(const u64* __restrict__ q, const 
   __syncthreads();
   if (w == 0 && qi < nq) {
 #pragma unroll
-    for (int k = 1; k < 4; k++) {
+    for (int k = 1; k < kSplit; k++) {
       const int d = sd[k][lane];
       if (d < best) { best = d; bi = si[k][lane]; }
     }
@@ -205,7 +206,7 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   if (npairs == 0) return DVS_OK;
   DVS_HIP(hipSetDevice(m->device));
   dim3 grid((q_stride_rows + 63) / 64, npairs);
-  hipLaunchKernelGGL(k_match, grid, dim3(256), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
+  hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
                      t_stride_rows, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
@@ -224,7 +225,7 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
   int* d_dist = d_idx + nq;
   DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
   if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-  hipLaunchKernelGGL(k_match, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
+  hipLaunchKernelGGL(k_match, dim3((nq + 63) / 64, 1), dim3(64 * kSplit), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   DVS_HIP(hipMemcpyAsync(train_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));

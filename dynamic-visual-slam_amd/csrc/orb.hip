@@ -346,31 +346,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
     const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
     if (aligned && D.gtab >= 0)
-      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
+      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
   }
   h->timer.end(st);
-  // blur only depends on the pyramid: fork it onto the auxiliary stream so it overlaps FAST + quad-tree
-  hipStream_t bst = st;
-  if (h->overlap) {
-    bst = h->aux_stream;
-    DVS_HIP(hipEventRecord(h->ev_pyr, st));
-    DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
-  }
-  h->timer.begin(DVS_STAGE_BLUR, bst);
-  // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
-  // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
-  bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
-  for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && G.lv[l].gtab >= 0;
-  if (stream_ok)
-    hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
-  else
-    hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
-  h->timer.end(bst);
-  if (bst != st) DVS_HIP(hipEventRecord(h->ev_blur, bst));
   // 2. FAST per cell
   h->timer.begin(DVS_STAGE_FAST, st);
   if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0) {
@@ -383,11 +365,32 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_fast_cell, dim3(G.totalCells, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
   }
   h->timer.end(st);
+  // blur only depends on the pyramid.  It is forked onto the auxiliary stream AFTER FAST so that the throughput-bound
+  // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
+  // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
+  hipStream_t bst = st;
+  if (h->overlap) {
+    bst = h->aux_stream;
+    DVS_HIP(hipEventRecord(h->ev_pyr, st));
+  }
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
   hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(256), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
+  // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
+  if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
+  h->timer.begin(DVS_STAGE_BLUR, bst);
+  // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
+  // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
+  bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
+  for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && G.lv[l].gtab >= 0;
+  if (stream_ok)
+    hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
+  else
+    hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
+  h->timer.end(bst);
+  if (bst != st) DVS_HIP(hipEventRecord(h->ev_blur, bst));
   if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
   // 5. orientation + descriptors + output records
   h->timer.begin(DVS_STAGE_DESCRIBE, st);

@@ -102,59 +102,71 @@ __global__ __launch_bounds__(256) void k_resize(const u8* __restrict__ src, uint
 // Same arithmetic, 4 output pixels per thread from TWO 12-byte source windows (dword loads) instead of 16 byte
 // gathers: the 4 left taps of a group lie within 8 bytes of the aligned `base` (scale <= 2), the right tap is the next
 // byte, and whenever the reference clamps the right tap (last column) its coefficient is 0.
+constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x kResizeRows independent 12-byte windows in flight
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
                                                  const int* __restrict__ beta) {
   const int gx = blockIdx.x * 64 + threadIdx.x;
   const int x4 = gx * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int y0 = (blockIdx.y * 4 + threadIdx.y) * kResizeRows;
   const int f = blockIdx.z;
-  if (x4 >= dw || y >= dh) return;
+  if (x4 >= dw || y0 >= dh) return;
   const ResizeGroup t = xt[gx];
-  const u8* s = src + (uint64_t)f * sfs;
-  u8* d = dst + (uint64_t)f * dfs + (uint64_t)y * dp;
-  const int sy = yofs[y];
-  const int b = beta[y];
-  const int b0 = (int)(short)(b & 0xffff), b1 = b >> 16;
-  const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
-  const u8* p0 = s + (uint64_t)r0 * sp + t.base;
-  const u8* p1 = s + (uint64_t)r1 * sp + t.base;
-  uint32_t w0[3], w1[3];
-  if (t.base + 12 <= sw) {
-    const uint2 a = *reinterpret_cast<const uint2*>(p0);
-    const uint2 c = *reinterpret_cast<const uint2*>(p1);
-    w0[0] = a.x; w0[1] = a.y; w0[2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
-    w1[0] = c.x; w1[1] = c.y; w1[2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
-  } else {  // row tail: bytewise, never past the last valid pixel
+  const u8* s = src + (uint64_t)f * sfs + t.base;
+  u8* d = dst + (uint64_t)f * dfs + x4;
+  const bool fastw = t.base + 12 <= sw;
+  uint32_t w0[kResizeRows][3], w1[kResizeRows][3];
+  int bb[kResizeRows];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      uint32_t u = 0, v = 0;
+  for (int r = 0; r < kResizeRows; r++) {
+    const int y = min(y0 + r, dh - 1);
+    const int sy = yofs[y];
+    bb[r] = beta[y];
+    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+    const u8* p0 = s + (uint64_t)r0 * sp;
+    const u8* p1 = s + (uint64_t)r1 * sp;
+    if (fastw) {
+      const uint2 a = *reinterpret_cast<const uint2*>(p0);
+      const uint2 c = *reinterpret_cast<const uint2*>(p1);
+      w0[r][0] = a.x; w0[r][1] = a.y; w0[r][2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
+      w1[r][0] = c.x; w1[r][1] = c.y; w1[r][2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
+    } else {  // row tail: bytewise, never past the last valid pixel
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int o = min(4 * k + i, sw - 1 - t.base);
-        u |= (uint32_t)p0[o] << (8 * i);
-        v |= (uint32_t)p1[o] << (8 * i);
+      for (int k = 0; k < 3; k++) {
+        uint32_t u = 0, v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int o = min(4 * k + i, sw - 1 - t.base);
+          u |= (uint32_t)p0[o] << (8 * i);
+          v |= (uint32_t)p1[o] << (8 * i);
+        }
+        w0[r][k] = u; w1[r][k] = v;
       }
-      w0[k] = u; w1[k] = v;
     }
   }
-  uint32_t out = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int o = (int)((t.offs >> (4 * i)) & 15u);
-    const bool hi = o >= 4;
-    const uint32_t sh8 = (uint32_t)(o & 3) * 8u;
-    const uint32_t pa = __builtin_amdgcn_alignbit(hi ? w0[2] : w0[1], hi ? w0[1] : w0[0], sh8);
-    const uint32_t pb = __builtin_amdgcn_alignbit(hi ? w1[2] : w1[1], hi ? w1[1] : w1[0], sh8);
-    const int a = t.alpha[i];
-    const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
-    const int h0 = (int)(pa & 0xff) * a0 + (int)((pa >> 8) & 0xff) * a1;
-    const int h1 = (int)(pb & 0xff) * a0 + (int)((pb >> 8) & 0xff) * a1;
-    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    out |= (uint32_t)(v & 0xff) << (8 * i);
+  for (int r = 0; r < kResizeRows; r++) {
+    if (y0 + r >= dh) break;
+    const int b0 = (int)(short)(bb[r] & 0xffff), b1 = bb[r] >> 16;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int o = (int)((t.offs >> (4 * i)) & 15u);
+      const bool hi = o >= 4;
+      const uint32_t sh8 = (uint32_t)(o & 3) * 8u;
+      const uint32_t pa = __builtin_amdgcn_alignbit(hi ? w0[r][2] : w0[r][1], hi ? w0[r][1] : w0[r][0], sh8);
+      const uint32_t pb = __builtin_amdgcn_alignbit(hi ? w1[r][2] : w1[r][1], hi ? w1[r][1] : w1[r][0], sh8);
+      const int a = t.alpha[i];
+      const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
+      const int h0 = (int)(pa & 0xff) * a0 + (int)((pa >> 8) & 0xff) * a1;
+      const int h1 = (int)(pb & 0xff) * a0 + (int)((pb >> 8) & 0xff) * a1;
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * i);
+    }
+    // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
+    *reinterpret_cast<uint32_t*>(d + (uint64_t)(y0 + r) * dp) = out;
   }
-  *reinterpret_cast<uint32_t*>(d + x4) = out;  // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
 }
 
 // =============================================================================================
@@ -408,18 +420,34 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     const uint32_t s14 = __builtin_amdgcn_alignbyte(Op2, Lp2, 2); // ring 14 (-2, 2)
     const uint32_t s6 = __builtin_amdgcn_alignbyte(Rm2, Om2, 2);  // ring 6  ( 2,-2)
     const uint32_t s10 = __builtin_amdgcn_alignbyte(Om2, Lm2, 2); // ring 10 (-2,-2)
-    bool pass[4];
+    // packed 16-bit evaluation, two pixels per instruction: with r_k the raw ring samples,
+    //   all four opposite pairs hold a darker sample   <=>  max_pairs(min(r_k, r_k+8)) < v - t
+    //   all four opposite pairs hold a brighter sample <=>  min_pairs(max(r_k, r_k+8)) > v + t
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    auto lo2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); };
+    auto hi2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); };
+    const s16x2 T2 = {(short)tmin, (short)tmin};
+    uint32_t sgn[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int col = wcol * 4 + j;
-      const int v = (int)((O0 >> (8 * j)) & 0xff);
-      const int d0 = (int)((Op3 >> (8 * j)) & 0xff) - v, d8 = (int)((Om3 >> (8 * j)) & 0xff) - v;
-      const int d4 = (int)((s4 >> (8 * j)) & 0xff) - v, d12 = (int)((s12 >> (8 * j)) & 0xff) - v;
-      const int d2 = (int)((s2 >> (8 * j)) & 0xff) - v, d10 = (int)((s10 >> (8 * j)) & 0xff) - v;
-      const int d6 = (int)((s6 >> (8 * j)) & 0xff) - v, d14 = (int)((s14 >> (8 * j)) & 0xff) - v;
-      const int mn = max(max(min(d0, d8), min(d4, d12)), max(min(d2, d10), min(d6, d14)));
-      const int mx = min(min(max(d0, d8), max(d4, d12)), min(max(d2, d10), max(d6, d14)));
-      pass[j] = valid && col >= cx0 && col < cx1 && (mn < -tmin || mx > tmin);
+    for (int hh = 0; hh < 2; hh++) {
+      auto un = [&](uint32_t w) -> s16x2 { return hh ? hi2(w) : lo2(w); };
+      const s16x2 v2 = un(O0);
+      const s16x2 r0 = un(Op3), r8 = un(Om3), r4 = un(s4), r12 = un(s12), r2 = un(s2), r10 = un(s10), r6 = un(s6), r14 = un(s14);
+      const s16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
+                                                 __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
+      const s16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
+                                                 __builtin_elementwise_min(__builtin_elementwise_max(r2, r10), __builtin_elementwise_max(r6, r14)));
+      const s16x2 e1 = (mn + T2) - v2;   // < 0  <=>  mn < v - t
+      const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
+      sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
+    }
+    bool pass[4];
+    {
+      const int col0 = wcol * 4;
+      pass[0] = valid && col0 >= cx0 && col0 < cx1 && (sgn[0] & 0x8000u);
+      pass[1] = valid && col0 + 1 >= cx0 && col0 + 1 < cx1 && (sgn[0] & 0x80000000u);
+      pass[2] = valid && col0 + 2 >= cx0 && col0 + 2 < cx1 && (sgn[1] & 0x8000u);
+      pass[3] = valid && col0 + 3 >= cx0 && col0 + 3 < cx1 && (sgn[1] & 0x80000000u);
     }
     const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
     int pos = nwork + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
