@@ -37,13 +37,13 @@ dvs_status check_device(int device);   // selects the device; DVS_ERR_NO_DEVICE 
 // stage timer: pairs of hipEvents recorded on the handle's stream, resolved lazily
 struct StageTimer {
   static const int kMaxPending = 4096;
-  struct Pending { hipEvent_t a, b; int stage; };
+  struct Pending { hipEvent_t a, b; int stage; bool count; };
   Pending pending[kMaxPending];
   int npending = 0;
   double ms[16] = {0};
   int64_t calls[16] = {0};
   bool on = false;
-  void begin(int stage, hipStream_t s);
+  void begin(int stage, hipStream_t s, bool count_call = true);
   void end(hipStream_t s);
   void resolve();
   void reset();

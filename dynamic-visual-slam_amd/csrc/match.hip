@@ -18,26 +18,36 @@ namespace dvs {
 
 typedef unsigned long long u64;
 
-constexpr int kSplit = 8;  // train-set slices per workgroup (one wavefront each): finer waves balance the last scheduling round
+constexpr int kSplit = 8;   // train-set slices per workgroup (one wavefront each): finer waves balance the last scheduling round
+constexpr int kQPL = 2;     // queries per lane: every scalar train row feeds two independent popcount chains
 __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
-                                               const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
-                                               int* __restrict__ outIdx, int* __restrict__ outDist) {
-  __shared__ int sd[kSplit][64];
-  __shared__ int si[kSplit][64];
+                                                       const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
+                                                       int* __restrict__ outIdx, int* __restrict__ outDist) {
+  __shared__ int sd[kSplit][64 * kQPL];
+  __shared__ int si[kSplit][64 * kQPL];
   const int pair = blockIdx.y;
   const int nq = nqArr ? nqArr[pair] : nqConst;
   const int nt = ntArr ? ntArr[pair] : ntConst;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * 64 * kQPL;
   if (q0 >= nq) return;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: train addresses become scalar
-  const int qi = q0 + lane;
-  const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
-  const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  u64 a[kQPL][4];
+#pragma unroll
+  for (int u = 0; u < kQPL; u++) {
+    const int qi = q0 + u * 64 + lane;
+    const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
+    a[u][0] = qp[0]; a[u][1] = qp[1]; a[u][2] = qp[2]; a[u][3] = qp[3];
+  }
   const int chunk = (nt + kSplit - 1) / kSplit;
   const int jb = min(nt, w * chunk), je = min(nt, jb + chunk);
   const u64* tp = t + (size_t)pair * tStrideRows * 4;
-  int best = INT_MAX, bi = -1;
+  int best[kQPL], bi[kQPL];
+#pragma unroll
+  for (int u = 0; u < kQPL; u++) { best[u] = INT_MAX; bi[u] = -1; }
+  auto dist = [&](int u, const u64* r) -> int {
+    return __popcll(a[u][0] ^ r[0]) + __popcll(a[u][1] ^ r[1]) + __popcll(a[u][2] ^ r[2]) + __popcll(a[u][3] ^ r[3]);
+  };
   int j = jb;
   if (j + 4 <= je) {  // software pipeline: the scalar loads of trip i+1 are issued before the popcounts of trip i
     u64 rr[16], nx[16];
@@ -52,30 +62,41 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
 #pragma unroll
       for (int k = 0; k < 16; k++) nx[k] = r[k];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int d = __popcll(a0 ^ rr[4 * k]) + __popcll(a1 ^ rr[4 * k + 1]) + __popcll(a2 ^ rr[4 * k + 2]) + __popcll(a3 ^ rr[4 * k + 3]);
-        if (d < best) { best = d; bi = j + k; }
-      }
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int u = 0; u < kQPL; u++) {
+          const int d = dist(u, &rr[4 * k]);
+          if (d < best[u]) { best[u] = d; bi[u] = j + k; }
+        }
 #pragma unroll
       for (int k = 0; k < 16; k++) rr[k] = nx[k];
     }
   }
   for (; j < je; j++) {
     const u64* r = tp + (size_t)j * 4;
-    const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
-    if (d < best) { best = d; bi = j; }
-  }
-  sd[w][lane] = best;
-  si[w][lane] = bi;
-  __syncthreads();
-  if (w == 0 && qi < nq) {
 #pragma unroll
-    for (int k = 1; k < kSplit; k++) {
-      const int d = sd[k][lane];
-      if (d < best) { best = d; bi = si[k][lane]; }
+    for (int u = 0; u < kQPL; u++) {
+      const int d = dist(u, r);
+      if (d < best[u]) { best[u] = d; bi[u] = j; }
     }
-    outIdx[(size_t)pair * qStrideRows + qi] = bi;
-    outDist[(size_t)pair * qStrideRows + qi] = best;
+  }
+#pragma unroll
+  for (int u = 0; u < kQPL; u++) { sd[w][u * 64 + lane] = best[u]; si[w][u * 64 + lane] = bi[u]; }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int u = 0; u < kQPL; u++) {
+      const int qi = q0 + u * 64 + lane;
+      if (qi >= nq) continue;
+      int bd = best[u], bidx = bi[u];
+#pragma unroll
+      for (int k = 1; k < kSplit; k++) {  // slices are ordered by train index: strict '<' keeps the lowest index on ties
+        const int d = sd[k][u * 64 + lane];
+        if (d < bd) { bd = d; bidx = si[k][u * 64 + lane]; }
+      }
+      outIdx[(size_t)pair * qStrideRows + qi] = bidx;
+      outDist[(size_t)pair * qStrideRows + qi] = bd;
+    }
   }
 }
 
@@ -205,7 +226,7 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   DVS_ARG(m && d_q && d_t && d_nq && d_nt && d_idx && d_dist && npairs >= 0 && q_stride_rows > 0 && t_stride_rows >= 0);
   if (npairs == 0) return DVS_OK;
   DVS_HIP(hipSetDevice(m->device));
-  dim3 grid((q_stride_rows + 63) / 64, npairs);
+  dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
   hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
                      t_stride_rows, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
@@ -225,7 +246,7 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
   int* d_dist = d_idx + nq;
   DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
   if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-  hipLaunchKernelGGL(k_match, dim3((nq + 63) / 64, 1), dim3(64 * kSplit), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
+  hipLaunchKernelGGL(k_match, dim3((nq + 64 * kQPL - 1) / (64 * kQPL), 1), dim3(64 * kSplit), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   DVS_HIP(hipMemcpyAsync(train_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));

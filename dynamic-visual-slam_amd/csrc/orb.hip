@@ -29,7 +29,7 @@ struct dvs_orb {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_l1 = nullptr, ev_lall = nullptr;
   bool overlap = true;
   int max_batch = 1;
   // ctor tables (ORBextractor.cpp:414-445)
@@ -335,8 +335,17 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   const Geom& G = h->geom;
   hipStream_t st = h->stream;
   src.pyr = h->d_pyr;
-  // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192)
-  h->timer.begin(DVS_STAGE_PYRAMID, st);
+  // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
+  //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
+  //    auxiliary stream while FAST starts on level 0, continues on level 1 once it exists, then takes the remaining levels.
+  const bool ov = h->overlap && G.nlevels >= 3;
+  hipStream_t pst = st;
+  if (ov) {
+    pst = h->aux_stream;
+    DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
+    DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
+  }
+  h->timer.begin(DVS_STAGE_PYRAMID, pst);
   for (int l = 1; l < G.nlevels; l++) {
     const LevelGeom& S = G.lv[l - 1];
     const LevelGeom& D = G.lv[l];
@@ -346,25 +355,49 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
     const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
     if (aligned && D.gtab >= 0)
-      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
+      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
+                         sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
     else
-      hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
+      hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+    if (ov && l == 1) DVS_HIP(hipEventRecord(h->ev_l1, pst));
   }
-  h->timer.end(st);
-  // 2. FAST per cell
-  h->timer.begin(DVS_STAGE_FAST, st);
-  if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0) {
-    const dim3 grid((G.totalCells + 3) / 4, nimg);
-    const size_t lds = 4 * (size_t)G.fastWaveLds;
-    if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
-    else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
-    else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
-  } else {
-    hipLaunchKernelGGL(k_fast_cell, dim3(G.totalCells, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount);
+  h->timer.end(pst);
+  if (ov) DVS_HIP(hipEventRecord(h->ev_lall, pst));
+  // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
+  {
+    const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
+    auto launch_fast = [&](int c0, int c1) {
+      if (c1 <= c0) return;
+      if (wavek) {
+        const dim3 grid((c1 - c0 + 3) / 4, nimg);
+        const size_t lds = 4 * (size_t)G.fastWaveLds;
+        if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+        else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+        else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+      } else {
+        hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0);
+      }
+    };
+    if (ov) {
+      h->timer.begin(DVS_STAGE_FAST, st);
+      launch_fast(0, G.lv[1].cellBase);
+      h->timer.end(st);
+      DVS_HIP(hipStreamWaitEvent(st, h->ev_l1, 0));
+      h->timer.begin(DVS_STAGE_FAST, st, false);
+      launch_fast(G.lv[1].cellBase, G.lv[2].cellBase);
+      h->timer.end(st);
+      DVS_HIP(hipStreamWaitEvent(st, h->ev_lall, 0));
+      h->timer.begin(DVS_STAGE_FAST, st, false);
+      launch_fast(G.lv[2].cellBase, G.totalCells);
+      h->timer.end(st);
+    } else {
+      h->timer.begin(DVS_STAGE_FAST, st);
+      launch_fast(0, G.totalCells);
+      h->timer.end(st);
+    }
   }
-  h->timer.end(st);
   // blur only depends on the pyramid.  It is forked onto the auxiliary stream AFTER FAST so that the throughput-bound
   // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
   // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
@@ -432,9 +465,14 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
   if (const char* e2 = getenv("DVS_NO_OVERLAP")) h->overlap = !(e2[0] == '1');  // diagnostics: serialise blur behind FAST
-  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+  int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_l1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_lall, hipEventDisableTiming) != hipSuccess) {
     dvs_orb_destroy(h);
     set_error("aux stream / event creation failed");
     return DVS_ERR_HIP;
@@ -453,6 +491,9 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
+  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_l1) (void)hipEventDestroy(h->ev_l1);
+  if (h->ev_lall) (void)hipEventDestroy(h->ev_lall);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

@@ -69,7 +69,7 @@ struct BlurTile { int16_t level, tx, ty, pad; };
 struct ResizeGroup { int32_t base; uint32_t offs; int32_t alpha[4]; };
 
 // streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
-constexpr int kBlurBand = 32;
+constexpr int kBlurBand = 64;
 struct BlurStrip { int16_t level, x0, w, y0; };
 
 // packed candidate / keypoint: x (12 bits) | y (12 bits) << 12 | score << 24, region-relative coordinates

@@ -204,7 +204,7 @@ __device__ __forceinline__ int fast_corner_score(const u8* c, int v) {
 }
 
 __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
-                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount) {
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0) {
   constexpr int P = kTilePitch;
   __shared__ __attribute__((aligned(16))) u8 tile[kMaxCellDim * P];
   __shared__ __attribute__((aligned(16))) u8 score[kMaxCellDim * P];
@@ -215,13 +215,14 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
 
   const int tid = threadIdx.x;
   const int f = blockIdx.y;
-  const Cell cell = cells[blockIdx.x];
+  const int ci = cell0 + blockIdx.x;
+  const Cell cell = cells[ci];
   const LevelGeom& L = g->lv[cell.level];
   int pitch;
   const u8* img = level_ptr(g, src, f, cell.level, pitch);
   const int cw = cell.cw, ch = cell.ch;
   const int iw = cw - 6, ih = ch - 6;
-  int* countOut = cellCount + (uint64_t)f * g->totalCells + blockIdx.x;
+  int* countOut = cellCount + (uint64_t)f * g->totalCells + ci;
   if (iw <= 0 || ih <= 0) {  // cv::FAST finds nothing in a sub-image narrower than 7
     if (tid == 0) *countOut = 0;
     return;
@@ -360,11 +361,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 template <int P>
 __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
-                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount) {
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int lane = lane_id();
-  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ci >= g->totalCells) return;
+  const int ci = cell0 + blockIdx.x * 4 + (threadIdx.x >> 6);  // cells [cell0, cell1) of the level-major cell table
+  if (ci >= cell1) return;
   const int f = blockIdx.y;
   unsigned char* base = fsm + (threadIdx.x >> 6) * g->fastWaveLds;
   const int tileBytes = g->fastRows * P;
@@ -994,8 +995,10 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
       const int k = k0 + kk;
       if (k < T) {
         const uint32_t own = cur[kk];
-        uint32_t left = __shfl_up(own, 1);
-        uint32_t right = __shfl_down(own, 1);
+        // neighbour words by DPP whole-wave shifts (wave_shr:1 / wave_shl:1: one VALU move each, no LDS crossbar trip;
+        // semantics checked on gfx950: lane i receives lane i-1 / i+1, the open end keeps `old` = 0)
+        uint32_t left = __builtin_amdgcn_update_dpp(0u, own, 0x138, 0xf, 0xf, false);
+        uint32_t right = __builtin_amdgcn_update_dpp(0u, own, 0x130, 0xf, 0xf, false);
         // px -3,-2,-1 = px 3,2,1 ; px W,W+1,W+2 = px W-2,W-3,W-4
         if (left_edge) left = ((own >> 24) << 8) | (((own >> 16) & 0xffu) << 16) | (((own >> 8) & 0xffu) << 24);
         if (right_edge) right = ((own >> 16) & 0xffu) | (((own >> 8) & 0xffu) << 8) | ((own & 0xffu) << 16);

@@ -26,7 +26,7 @@ dvs_status check_device(int device) {
   return DVS_OK;
 }
 
-void StageTimer::begin(int stage, hipStream_t s) {
+void StageTimer::begin(int stage, hipStream_t s, bool count_call) {
   if (!on) return;
   if (npending >= kMaxPending) resolve();
   Pending& p = pending[npending];
@@ -34,7 +34,7 @@ void StageTimer::begin(int stage, hipStream_t s) {
     hipEventCreate(&pool[npool++]);
     hipEventCreate(&pool[npool++]);
   }
-  p.a = pool[2 * npending]; p.b = pool[2 * npending + 1]; p.stage = stage;
+  p.a = pool[2 * npending]; p.b = pool[2 * npending + 1]; p.stage = stage; p.count = count_call;
   hipEventRecord(p.a, s);
   cur = npending++;
 }
@@ -47,7 +47,7 @@ void StageTimer::resolve() {
   for (int i = 0; i < npending; i++) {
     hipEventSynchronize(pending[i].b);
     float t = 0;
-    if (hipEventElapsedTime(&t, pending[i].a, pending[i].b) == hipSuccess) { ms[pending[i].stage] += t; calls[pending[i].stage]++; }
+    if (hipEventElapsedTime(&t, pending[i].a, pending[i].b) == hipSuccess) { ms[pending[i].stage] += t; if (pending[i].count) calls[pending[i].stage]++; }
   }
   npending = 0;
 }
