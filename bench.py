@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--pipelines", type=int, default=1, help="double-buffered batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,58 +115,81 @@ def main():
     for i in range(B):
         d_img[i].copy_(torch.from_numpy(host[i % uniq]))
 
-    orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
-    mat = dvslam_amd.BFMatcher(device=local)
-    cap = orb.capacity
-    tstream = torch.cuda.Stream(device=dev)          # every kernel, copy and collective of a step is ordered on this stream
-    torch.cuda.set_stream(tstream)
-    orb.set_stream(tstream.cuda_stream); mat.set_stream(tstream.cuda_stream)
-    # slot 0 = last frame of the previous (rank's or neighbour's) batch, slots 1..B = this step's frames
-    d_kps = torch.empty((B + 1, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    d_idx = torch.empty((B, cap), dtype=torch.int32, device=dev)
-    d_dist = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    # Two pipelines (extractor + matcher handle, HBM buffers, torch stream each) take alternate steps, so consecutive
+    # batches overlap on the GPU exactly like a double-buffered camera stream would; every step still processes one
+    # full batch of B frames through the whole path, and a step's first match job waits (stream event) for the
+    # descriptors of the previous step's last frame, which the other pipeline produced.
+    NP = max(1, args.pipelines)
+    pipes = []
+    for p in range(NP):
+        orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
+        mat = dvslam_amd.BFMatcher(device=local)
+        ts = torch.cuda.Stream(device=dev)
+        orb.set_stream(ts.cuda_stream); mat.set_stream(ts.cuda_stream)
+        cap = orb.capacity
+        with torch.cuda.stream(ts):
+            # slot 0 = last frame of the previous step (own rank's or the neighbour's), slots 1..B = this step's frames
+            bufs = dict(kps=torch.empty((B + 1, cap, 28), dtype=torch.uint8, device=dev),
+                        desc=torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev),
+                        n=torch.zeros(B + 1, dtype=torch.int32, device=dev),
+                        idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
+                        dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
+        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), **bufs))
+    cap = pipes[0]["orb"].capacity
+    torch.cuda.synchronize()
+    state = {"i": 0}
 
     def step():
-        orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
-                                 cap, d_n[1:].data_ptr())
-        mat.match_batch_device(d_desc[1].data_ptr(), d_n[1:].data_ptr(), cap, d_desc[0].data_ptr(), d_n[0:].data_ptr(), cap, B,
-                               d_idx.data_ptr(), d_dist.data_ptr())
-        # boundary exchange for the next step's first match job
-        bd, bn = dvdist.exchange_boundary(d_desc[B], d_n[B], cap)
-        d_desc[0].copy_(bd); d_n[0].copy_(bn)
+        i = state["i"]; state["i"] += 1
+        P = pipes[i % NP]; Q = pipes[(i - 1) % NP]
+        with torch.cuda.stream(P["stream"]):
+            P["orb"].extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][1].data_ptr(),
+                                          P["desc"][1].data_ptr(), cap, P["n"][1:].data_ptr())
+            if i > 0:
+                P["stream"].wait_event(Q["done"])          # previous step's last-frame descriptors
+                bd, bn = dvdist.exchange_boundary(Q["desc"][B], Q["n"][B], cap)
+                P["desc"][0].copy_(bd); P["n"][0].copy_(bn)
+            P["mat"].match_batch_device(P["desc"][1].data_ptr(), P["n"][1:].data_ptr(), cap, P["desc"][0].data_ptr(),
+                                        P["n"][0:].data_ptr(), cap, B, P["idx"].data_ptr(), P["dist"].data_ptr())
+            P["done"].record(P["stream"])
+
+    def sync_all():
+        for P in pipes:
+            P["stream"].synchronize()
 
     for _ in range(args.warmup):
         step()
+    sync_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
+    sync_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    # per-kernel durations: the same K steps again with hipEvents around every stage launch (the events themselves
-    # cost ~10 us of stream time per stage, so they are kept out of the whole-job timing above)
+    # per-kernel durations: K more steps on ONE pipeline with hipEvents around every stage launch (the events cost ~10 us
+    # of stream time per stage, so they stay out of the whole-job timing above)
+    orb = pipes[0]["orb"]
     orb.enable_stage_timing(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    P = pipes[0]
+    with torch.cuda.stream(P["stream"]):
+        for _ in range(args.steps):
+            orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][1].data_ptr(), P["desc"][1].data_ptr(),
+                                     cap, P["n"][1:].data_ptr())
+    sync_all()
     stage_ms, stage_calls = orb.stage_times()
     orb.enable_stage_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    d_n = pipes[0]["n"]; d_dist = pipes[0]["dist"]
 
     n_host = d_n.cpu().numpy()
     matched = int((d_dist[:, :].cpu().numpy()[0, :n_host[1]] < 50).sum())
@@ -182,13 +206,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame "
                                    "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[1]),
-                       "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather"},
+                       "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
             "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
             "stage_ms_per_step": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
-            "gpu_ms_per_step_rank0": round(gpu_ms / args.steps, 4),
+            "pipelines_per_gpu": NP,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]

@@ -29,7 +29,8 @@ struct dvs_orb {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_l1 = nullptr, ev_lall = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr;
+  hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete
   bool overlap = true;
   int max_batch = 1;
   // ctor tables (ORBextractor.cpp:414-445)
@@ -338,7 +339,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
   //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
   //    auxiliary stream while FAST starts on level 0, continues on level 1 once it exists, then takes the remaining levels.
-  const bool ov = h->overlap && G.nlevels >= 3;
+  const bool ov = h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
   if (ov) {
     pst = h->aux_stream;
@@ -361,10 +362,9 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
-    if (ov && l == 1) DVS_HIP(hipEventRecord(h->ev_l1, pst));
+    if (ov) DVS_HIP(hipEventRecord(h->ev_level[l], pst));
   }
   h->timer.end(pst);
-  if (ov) DVS_HIP(hipEventRecord(h->ev_lall, pst));
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
   {
     const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
@@ -380,18 +380,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
         hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0);
       }
     };
-    if (ov) {
-      h->timer.begin(DVS_STAGE_FAST, st);
-      launch_fast(0, G.lv[1].cellBase);
-      h->timer.end(st);
-      DVS_HIP(hipStreamWaitEvent(st, h->ev_l1, 0));
-      h->timer.begin(DVS_STAGE_FAST, st, false);
-      launch_fast(G.lv[1].cellBase, G.lv[2].cellBase);
-      h->timer.end(st);
-      DVS_HIP(hipStreamWaitEvent(st, h->ev_lall, 0));
-      h->timer.begin(DVS_STAGE_FAST, st, false);
-      launch_fast(G.lv[2].cellBase, G.totalCells);
-      h->timer.end(st);
+    if (ov) {  // one launch per level, each gated on its own level only
+      for (int l = 0; l < G.nlevels; l++) {
+        if (l > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[l], 0));
+        h->timer.begin(DVS_STAGE_FAST, st, l == 0);
+        launch_fast(G.lv[l].cellBase, G.lv[l].cellBase + G.lv[l].nCells);
+        h->timer.end(st);
+      }
     } else {
       h->timer.begin(DVS_STAGE_FAST, st);
       launch_fast(0, G.totalCells);
@@ -470,13 +465,17 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_l1, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_lall, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
     dvs_orb_destroy(h);
     set_error("aux stream / event creation failed");
     return DVS_ERR_HIP;
   }
+  for (int l = 1; l < params->nlevels; l++)
+    if (hipEventCreateWithFlags(&h->ev_level[l], hipEventDisableTiming) != hipSuccess) {
+      dvs_orb_destroy(h);
+      set_error("event creation failed");
+      return DVS_ERR_HIP;
+    }
   build_ctor_tables(h);
   *out = h;
   return DVS_OK;
@@ -492,8 +491,7 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-  if (h->ev_l1) (void)hipEventDestroy(h->ev_l1);
-  if (h->ev_lall) (void)hipEventDestroy(h->ev_lall);
+  for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
