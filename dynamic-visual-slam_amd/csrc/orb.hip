@@ -45,6 +45,7 @@ struct dvs_orb {
   BlurTile* d_tiles = nullptr;
   BlurStrip* d_strips = nullptr;
   ResizeGroup* d_rgroups = nullptr;
+  PyrTile* d_pyrtiles = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
   u8 *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -65,14 +66,14 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
-  void* ptrs[] = {h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
+  void* ptrs[] = {h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
                   h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
-  h->d_strips = nullptr; h->d_rgroups = nullptr;
+  h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
@@ -141,7 +142,8 @@ void build_axis_table(int ssize, int dsize, bool clamp_like_x, std::vector<int>&
 }
 
 dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<Cell>& cells, std::vector<BlurTile>& tiles,
-                          std::vector<BlurStrip>& strips, std::vector<ResizeGroup>& rgroups, std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
+                          std::vector<BlurStrip>& strips, std::vector<ResizeGroup>& rgroups, std::vector<PyrTile>& ptiles,
+                          std::vector<int>& xofs, std::vector<int>& alpha, std::vector<int>& yofs, std::vector<int>& beta) {
   memset(&G, 0, sizeof(G));
   const int nl = h->prm.nlevels;
   G.nlevels = nl; G.rows = rows; G.cols = cols;
@@ -258,6 +260,62 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
       if (!fits) L.gtab = -1;
     }
   }
+  // ---- pyramid cascade tiles (k_pyr_cascade) --------------------------------------------------------------------
+  if (nl >= 2) {
+    auto srcx = [&](int k, int x) { return xofs[G.lv[k].xtab + x]; };                                    // left tap (already clamped)
+    auto srcy = [&](int k, int y) { return std::min(std::max(yofs[G.lv[k].ytab + y], 0), G.lv[k - 1].h - 1); };  // top tap
+    int maxBytes = 0;
+    bool cascade_ok = true;
+    for (int ty = 0; ty < G.lv[1].h; ty += kPyrTileH)
+      for (int tx = 0; tx < G.lv[1].w; tx += kPyrTileW) {
+        PyrTile T{};
+        int oxa[DVS_MAX_LEVELS], oxb[DVS_MAX_LEVELS], oya[DVS_MAX_LEVELS], oyb[DVS_MAX_LEVELS];
+        oxa[1] = tx; oxb[1] = std::min(tx + kPyrTileW, G.lv[1].w);
+        oya[1] = ty; oyb[1] = std::min(ty + kPyrTileH, G.lv[1].h);
+        for (int k = 2; k < nl; k++) {  // owner of a pixel = owner of its top-left source tap
+          int a = 0, b;
+          while (a < G.lv[k].w && srcx(k, a) < oxa[k - 1]) a++;
+          b = a;
+          while (b < G.lv[k].w && srcx(k, b) < oxb[k - 1]) b++;
+          oxa[k] = a; oxb[k] = b;
+          a = 0;
+          while (a < G.lv[k].h && srcy(k, a) < oya[k - 1]) a++;
+          b = a;
+          while (b < G.lv[k].h && srcy(k, b) < oyb[k - 1]) b++;
+          oya[k] = a; oyb[k] = b;
+        }
+        int cxa = 0, cxb = 0, cya = 0, cyb = 0;  // compute region of the level below the current one (empty)
+        for (int k = nl - 1; k >= 1; k--) {
+          const bool own = oxb[k] > oxa[k] && oyb[k] > oya[k];
+          int xa = own ? oxa[k] : 0, xb = own ? oxb[k] : 0, ya = own ? oya[k] : 0, yb = own ? oyb[k] : 0;
+          if (cxb > cxa && cyb > cya) {  // what level k+1's region reads from level k
+            const int nxa = srcx(k + 1, cxa), nxb = std::min(srcx(k + 1, cxb - 1) + 1, G.lv[k].w - 1) + 1;
+            const int nya = srcy(k + 1, cya), nyb = std::min(srcy(k + 1, cyb - 1) + 1, G.lv[k].h - 1) + 1;
+            if (own) { xa = std::min(xa, nxa); xb = std::max(xb, nxb); ya = std::min(ya, nya); yb = std::max(yb, nyb); }
+            else { xa = nxa; xb = nxb; ya = nya; yb = nyb; }
+          }
+          xa &= ~3;  // dword-aligned groups in LDS and in HBM
+          PyrTileLevel& R = T.lv[k];
+          R.cx0 = (int16_t)xa; R.cx1 = (int16_t)xb; R.cy0 = (int16_t)ya; R.cy1 = (int16_t)yb;
+          R.ox0 = (int16_t)(own ? oxa[k] : 0); R.ox1 = (int16_t)(own ? oxb[k] : 0);
+          R.oy0 = (int16_t)(own ? oya[k] : 0); R.oy1 = (int16_t)(own ? oyb[k] : 0);
+          cxa = xa; cxb = xb; cya = ya; cyb = yb;
+          maxBytes = std::max(maxBytes, (((xb - xa) + 3) & ~3) * (yb - ya));
+        }
+        // level-0 source region of the level-1 compute region
+        T.sx0 = (int16_t)(srcx(1, cxa) & ~3);
+        T.sx1 = (int16_t)(std::min(srcx(1, cxb - 1) + 1, G.lv[0].w - 1) + 1);
+        T.sy0 = (int16_t)srcy(1, cya);
+        T.sy1 = (int16_t)(std::min(srcy(1, cyb - 1) + 1, G.lv[0].h - 1) + 1);
+        maxBytes = std::max(maxBytes, (((T.sx1 - T.sx0) + 3) & ~3) * (T.sy1 - T.sy0));
+        int tabx = 0, taby = 0;
+        for (int k = 1; k < nl; k++) { tabx += ((T.lv[k].cx1 - T.lv[k].cx0) + 3) & ~3; taby += T.lv[k].cy1 - T.lv[k].cy0; }
+        if (tabx > kPyrTabX || taby > kPyrTabY) cascade_ok = false;
+        ptiles.push_back(T);
+      }
+    G.pyrTiles = cascade_ok ? (int)ptiles.size() : 0;
+    G.pyrLds = (int)align_up(maxBytes, 16);
+  }
   G.frameBytes = off;
   G.candPerFrame = candOff; G.ptsPerFrame = ptsOff;
   G.totalCells = (int)cells.size();
@@ -288,8 +346,9 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   free_workspace(h);
   Geom G;
   std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
+  std::vector<PyrTile> ptiles;
   std::vector<int> xofs, alpha, yofs, beta;
-  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, strips, rgroups, xofs, alpha, yofs, beta));
+  DVS_TRY(build_geometry(h, rows, cols, G, cells, tiles, strips, rgroups, ptiles, xofs, alpha, yofs, beta));
   h->geom = G;
   const size_t B = (size_t)h->max_batch;
   DVS_HIP(hipMalloc((void**)&h->d_geom, sizeof(Geom)));
@@ -298,6 +357,8 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_TRY(upload(&h->d_tiles, tiles));
   DVS_TRY(upload(&h->d_strips, strips));
   DVS_TRY(upload(&h->d_rgroups, rgroups));
+  DVS_TRY(upload(&h->d_pyrtiles, ptiles));
+  if (G.pyrLds > 0) DVS_HIP(hipFuncSetAttribute((const void*)k_pyr_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G.pyrLds));
   DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
   DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
@@ -339,8 +400,21 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
   //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
   //    auxiliary stream while FAST starts on level 0, continues on level 1 once it exists, then takes the remaining levels.
-  const bool ov = h->overlap && G.nlevels >= 2;
+  const bool aligned0 = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
+  // k_pyr_cascade (all levels in one launch, LDS ping-pong) is bit-identical and reads level 0 only ~1.1x, but measured
+  // SLOWER than the per-level chain running beside FAST (0.29 vs 0.20 ms per 64 frames: the resize arithmetic is VALU-issue
+  // bound, so removing the launches and the re-reads buys nothing).  Kept selectable for HBM-traffic experiments.
+  const char* casc_env = getenv("DVS_CASCADE");
+  const bool cascade = casc_env && casc_env[0] == '1' && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
+  const bool ov = !cascade && h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
+  if (cascade) {
+    // all levels in ONE launch: each workgroup stages a level-0 region in LDS and walks down the levels (k_pyr_cascade)
+    h->timer.begin(DVS_STAGE_PYRAMID, st);
+    hipLaunchKernelGGL(k_pyr_cascade, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
+                       h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, G.pyrLds);
+    h->timer.end(st);
+  } else {
   if (ov) {
     pst = h->aux_stream;
     DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
@@ -365,6 +439,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     if (ov) DVS_HIP(hipEventRecord(h->ev_level[l], pst));
   }
   h->timer.end(pst);
+  }
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
   {
     const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
@@ -411,8 +486,8 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   h->timer.begin(DVS_STAGE_BLUR, bst);
   // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
   // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
-  bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
-  for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && G.lv[l].gtab >= 0;
+  bool stream_ok = aligned0 && G.lv[0].w % 4 == 0;
+  for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && (cascade || G.lv[l].gtab >= 0);
   if (stream_ok)
     hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
   else
@@ -675,8 +750,9 @@ dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t
   h.prm = *params;
   build_ctor_tables(&h);
   Geom G;
-  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rg; std::vector<int> xo, al, yo, be;
-  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, strips, rg, xo, al, yo, be));
+  std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rg; std::vector<PyrTile> pt;
+  std::vector<int> xo, al, yo, be;
+  DVS_TRY(build_geometry(&h, rows, cols, G, cells, tiles, strips, rg, pt, xo, al, yo, be));
   for (int l = 0; l < G.nlevels; l++) {
     if (level_w) level_w[l] = G.lv[l].w;
     if (level_h) level_h[l] = G.lv[l].h;

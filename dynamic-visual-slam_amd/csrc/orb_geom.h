@@ -40,6 +40,8 @@ struct Geom {
   int32_t outCap;       // nfeatures + 3 * nlevels
   int32_t blurTiles;    // tiles of the (generic) blur launch over all levels
   int32_t blurStrips;   // wave work items of the streaming blur
+  int32_t pyrTiles;     // workgroups of the pyramid cascade
+  int32_t pyrLds;       // bytes of ONE of its two LDS buffers
   int32_t fastP;        // LDS tile pitch of the wave-per-cell FAST kernel (48 / 64 / 80)
   int32_t fastRows;     // max cell height (rows of the LDS tile)
   int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
@@ -71,6 +73,13 @@ struct ResizeGroup { int32_t base; uint32_t offs; int32_t alpha[4]; };
 // streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
 constexpr int kBlurBand = 64;
 struct BlurStrip { int16_t level, x0, w, y0; };
+
+// pyramid cascade: one workgroup builds its share of EVERY level from one staged level-0 region (LDS ping-pong).
+// Ownership: level-1 tiles partition level 1; a pixel of level k >= 2 belongs to the tile that owns its top-left source tap,
+// so each level is partitioned too.  c* = region that must be computed (owned + what deeper levels read), o* = owned part.
+struct PyrTileLevel { int16_t cx0, cx1, cy0, cy1, ox0, ox1, oy0, oy1; };
+struct PyrTile { int16_t sx0, sx1, sy0, sy1; PyrTileLevel lv[DVS_MAX_LEVELS]; };
+constexpr int kPyrTileW = 128, kPyrTileH = 64;
 
 // packed candidate / keypoint: x (12 bits) | y (12 bits) << 12 | score << 24, region-relative coordinates
 __host__ __device__ inline uint32_t pack_pt(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }

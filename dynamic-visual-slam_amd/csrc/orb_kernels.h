@@ -169,6 +169,133 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pyramid cascade: ALL levels in one launch.  The 7 dependent per-level launches are short and latency-bound (each
+// waits on table -> source -> store round trips, ~15 us even for the 72 k-pixel last level); here a workgroup stages
+// one level-0 region in LDS and walks down the levels with LDS as source, writing only the pixels it owns.  Same
+// integer arithmetic as k_resize (OpenCV's Q11 INTER_LINEAR), level 0 is read ~1.1x, every level is written once.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPyrTabX = 1024, kPyrTabY = 640;  // LDS table entries over all levels of one tile (checked on the host)
+__global__ __launch_bounds__(256) void k_pyr_cascade(const Geom* __restrict__ g, const PyrTile* __restrict__ tiles, ImgSrc src,
+                                                     const int* __restrict__ xofs, const int* __restrict__ alpha,
+                                                     const int* __restrict__ yofs, const int* __restrict__ beta, int bufBytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  // coefficient tables of every level's region, made tile-relative once (one global-latency phase for the whole cascade)
+  __shared__ uint2 tx[kPyrTabX];  // .x = left tap | right tap << 16 (columns relative to the source region), .y = a0 | a1 << 16
+  __shared__ uint2 ty[kPyrTabY];  // .x = top row | bottom row << 16 (relative),                              .y = b0 | b1 << 16
+  const PyrTile& T = tiles[blockIdx.x];
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int nl = g->nlevels;
+  u8* buf[2] = {psm, psm + bufBytes};
+  // stage the level-0 region (sx0 is a multiple of 4; rows are dword aligned — checked on the host)
+  const int sw = T.sx1 - T.sx0, shh = T.sy1 - T.sy0;
+  int sP = (sw + 3) & ~3;
+  {
+    const u8* img = src.img0 + (uint64_t)f * src.fstride0 + (uint64_t)T.sy0 * src.step0 + T.sx0;
+    const int wpr = sP >> 2;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(buf[0]);
+    const int n = wpr * shh;
+    const float inv = 1.0f / (float)wpr;
+    const int W0 = g->lv[0].w;
+    for (int i = tid; i < n; i += 256) {
+      const int r = (int)(((float)i + 0.5f) * inv);
+      const int c = i - r * wpr;
+      const u8* p = img + (uint64_t)r * src.step0 + 4 * c;
+      uint32_t v;
+      if (T.sx0 + 4 * c + 3 < W0) v = *reinterpret_cast<const uint32_t*>(p);
+      else {  // last word of a row whose width is not a multiple of 4: never read past the image
+        v = 0;
+        for (int b = 0; b < 4; b++) if (T.sx0 + 4 * c + b < W0) v |= (uint32_t)p[b] << (8 * b);
+      }
+      d32[i] = v;
+    }
+    // tables
+    int xo = 0, yo = 0, ox = T.sx0, oy = T.sy0;
+    for (int k = 1; k < nl; k++) {
+      const PyrTileLevel R = T.lv[k];
+      const int cw = R.cx1 - R.cx0, chh = R.cy1 - R.cy0;
+      if (cw <= 0 || chh <= 0) break;
+      const LevelGeom& L = g->lv[k];
+      const int SW = g->lv[k - 1].w, SH = g->lv[k - 1].h;
+      const int cwp = (cw + 3) & ~3;
+      for (int i = tid; i < cwp; i += 256) {
+        const int x = min(R.cx0 + i, L.w - 1);
+        const int o = xofs[L.xtab + x];
+        tx[xo + i] = make_uint2((uint32_t)(o - ox) | ((uint32_t)(min(o + 1, SW - 1) - ox) << 16), (uint32_t)alpha[L.xtab + x]);
+      }
+      for (int i = tid; i < chh; i += 256) {
+        const int sy = yofs[L.ytab + R.cy0 + i];
+        ty[yo + i] = make_uint2((uint32_t)(min(max(sy, 0), SH - 1) - oy) | ((uint32_t)(min(max(sy + 1, 0), SH - 1) - oy) << 16),
+                                (uint32_t)beta[L.ytab + R.cy0 + i]);
+      }
+      xo += cwp; yo += chh; ox = R.cx0; oy = R.cy0;
+    }
+  }
+  __syncthreads();
+  int cur = 0, xo = 0, yo = 0;
+  for (int k = 1; k < nl; k++) {
+    const PyrTileLevel R = T.lv[k];
+    const int cw = R.cx1 - R.cx0, chh = R.cy1 - R.cy0;
+    if (cw <= 0 || chh <= 0) break;  // deeper levels own nothing either
+    const LevelGeom& L = g->lv[k];
+    const int dP = (cw + 3) & ~3;
+    const u8* sb = buf[cur];
+    u8* db = buf[cur ^ 1];
+    const int ng = dP >> 2;
+    const int rpp = 256 / ng;  // rows per pass
+    const int gx = tid % ng, ry = tid / ng;
+    u8* gdst = src.pyr + (uint64_t)f * g->frameBytes + L.off;
+    if (ry < rpp) {
+      int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint2 e = tx[xo + 4 * gx + i];
+        sx[i] = (int)(e.x & 0xffff); sx1[i] = (int)(e.x >> 16);
+        a0[i] = (int)(short)(e.y & 0xffff); a1[i] = (int)e.y >> 16;
+      }
+      const int x0 = R.cx0 + 4 * gx;
+      const bool full = x0 >= R.ox0 && x0 + 3 < R.ox1;
+      const bool mirror = x0 + 3 >= L.w - 9;
+      for (int y = R.cy0 + ry; y < R.cy1; y += rpp) {
+        const uint2 e = ty[yo + y - R.cy0];
+        const int b0 = (int)(short)(e.y & 0xffff), b1 = (int)e.y >> 16;
+        const u8* p0 = sb + (int)(e.x & 0xffff) * sP;
+        const u8* p1 = sb + (int)(e.x >> 16) * sP;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int h0 = p0[sx[i]] * a0[i] + p0[sx1[i]] * a1[i];
+          const int h1 = p1[sx[i]] * a0[i] + p1[sx1[i]] * a1[i];
+          const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          out |= (uint32_t)(v & 0xff) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(db + (y - R.cy0) * dP + 4 * gx) = out;
+        if (y >= R.oy0 && y < R.oy1) {
+          u8* grow = gdst + (uint64_t)y * L.pitch;
+          if (full) {
+            *reinterpret_cast<uint32_t*>(grow + x0) = out;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (x0 + i >= R.ox0 && x0 + i < R.ox1) grow[x0 + i] = (u8)(out >> (8 * i));
+          }
+          // BORDER_REFLECT_101 continuation right of the image (read by the streaming blur): column 2W-2-c mirrors c
+          if (mirror) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int c = x0 + i;
+              if (c >= R.ox0 && c < R.ox1 && c >= L.w - 9 && c <= L.w - 2) grow[2 * L.w - 2 - c] = (u8)(out >> (8 * i));
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    sP = dP; xo += dP; yo += chh;
+  }
+}
+
 // =============================================================================================
 // FAST-9/16 per reference cell.  One 256-thread workgroup = one cell of one frame:
 //   1. stage the (cw x ch) sub-image into LDS

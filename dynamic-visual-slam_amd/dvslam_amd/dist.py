@@ -3,6 +3,7 @@ ranks (rank r owns frames [r*B, (r+1)*B) of every global batch), extraction need
 and the ONE exchange step is the boundary descriptor block: the match job (t, t-1) with t = r*B needs
 the descriptors of frame r*B - 1, which the previous rank produced.  One all_gather of the fixed-size
 block {n, descriptors[cap x 32]} per step (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+import os
 import torch
 import torch.distributed as dist
 
@@ -28,7 +29,7 @@ def exchange_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, cap: int, g
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = pack_boundary(desc_last, n_last)
-    if world == 1:
+    if world == 1 and not (dist.is_initialized() and os.environ.get("DVS_FORCE_COLLECTIVE") == "1"):
         return unpack_boundary(mine, cap)
     out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
     dist.all_gather_into_tensor(out, mine, group=group)
