@@ -53,19 +53,43 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0):
             "sample": f"{done} frames 1280x720 extract(2000kp)+match vs previous frame, oracle/ C++ -O2, 1 thread"}
 
 
-def ba_bench(dvslam_amd, synth, device, iters=200):
+def _replicate_ba(P, W):
+    """W independent copies of one window as ONE block-diagonal problem: a batch of windows per launch pair"""
+    Q = dict(P)
+    K, L = P["K"], P["L"]
+    Q["K"], Q["L"] = K * W, L * W
+    for k in ("q", "t", "X", "uv"):
+        Q[k] = np.tile(P[k], (W, 1))
+    Q["cam_idx"] = np.concatenate([P["cam_idx"] + w * K for w in range(W)]).astype(np.int32)
+    Q["lm_idx"] = np.concatenate([P["lm_idx"] + w * L for w in range(W)]).astype(np.int32)
+    Q["pose_fixed"] = np.tile(P["pose_fixed"], W); Q["lm_fixed"] = np.tile(P["lm_fixed"], W)
+    return Q
+
+
+def ba_bench(dvslam_amd, synth, device, iters=200, W=64):
     """second half of BASELINE.json's metric: BA residual-evaluations/s on the 10 KF x 2000 LM window (config 3).
     One evaluation = all 20 000 residual blocks with local Jacobians, Huber corrector, cost and the H_pp / H_ll / g
-    reductions (k_ba_eval + k_ba_reduce), parameters and outputs resident in HBM."""
+    reductions (k_ba_eval + k_ba_reduce), parameters and outputs resident in HBM.  A single window is launch/latency
+    bound (~4 MB, ~6 MFLOP), so the throughput figure batches W independent windows per launch pair (SURVEY.md §8e:
+    "independent windows shard trivially"); the single-window latency is reported beside it."""
     import oracle_bindings as ob
     P = synth.make_ba_problem(K=10, L=2000, seed=42)
+    R = len(P["cam_idx"])
     g = dvslam_amd.BAProblem(P, device=device)
     g.evaluate_device(20); g.synchronize()
-    t0 = time.perf_counter(); g.evaluate_device(iters); g.synchronize(); dt = time.perf_counter() - t0
-    R = len(P["cam_idx"])
-    out = {"metric": "BA residual-eval/sec 10KF x 2000LM", "evals_per_s": round(iters / dt, 1), "residual_blocks_per_s": round(iters * R / dt, 1),
-           "us_per_eval": round(1e6 * dt / iters, 2), "residual_blocks": R, "dtype": "f64",
-           "algorithmic_bytes_per_eval": 528_560 + R * 160, "achieved_GBps": round((528_560 + R * 160) * iters / dt / 1e9, 2)}
+    t0 = time.perf_counter(); g.evaluate_device(iters); g.synchronize(); dt1 = (time.perf_counter() - t0) / iters
+    c1 = g.evaluate()[0]
+    gb = dvslam_amd.BAProblem(_replicate_ba(P, W), device=device)
+    cW = gb.evaluate()[0]
+    assert abs(cW - W * c1) <= 1e-9 * abs(W * c1), "batched evaluation must equal W x the single-window cost"
+    gb.evaluate_device(10); gb.synchronize()
+    t0 = time.perf_counter(); gb.evaluate_device(iters // 2); gb.synchronize(); dtW = (time.perf_counter() - t0) / (iters // 2)
+    bytes_eval = 528_560 + R * 160
+    out = {"metric": "BA residual-eval/sec 10KF x 2000LM", "evals_per_s": round(W / dtW, 1), "windows_per_launch": W,
+           "residual_blocks_per_s": round(W * R / dtW, 1), "us_per_eval_batched": round(1e6 * dtW / W, 3),
+           "single_window_evals_per_s": round(1 / dt1, 1), "single_window_us_per_eval": round(1e6 * dt1, 2), "residual_blocks": R,
+           "dtype": "f64", "algorithmic_bytes_per_eval": bytes_eval, "achieved_GBps": round(bytes_eval * W / dtW / 1e9, 2),
+           "roofline_frac_hbm": round(bytes_eval * W / dtW / HBM_PEAK, 5)}
     s = g.solve(20)
     out["lm_solve"] = {"iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "initial_cost": s.initial_cost, "final_cost": s.final_cost}
     o = ob.OracleBA(P)

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
                                                    const int* __restrict__ lmObs, const double* __restrict__ res,
                                                    const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
                                                    int withLm, double* __restrict__ Hpp, double* __restrict__ Hll,
-                                                   double* __restrict__ g, double* __restrict__ cost) {
+                                                   double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
+                                                   int* __restrict__ ticketCounter) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < lmBlocks) {
     if (!withLm) return;
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
     g[6 * K + 3 * l] = gl[0]; g[6 * K + 3 * l + 1] = gl[1]; g[6 * K + 3 * l + 2] = gl[2];
     return;
   }
-  // camera fold: thread (c, k) sums the camera's chunk partials in chunk order
-  for (int idx = tid; idx < K * 28; idx += 256) {
-    const int c = idx / 28, k = idx - c * 28;
-    if (k == 27) continue;
+  // camera fold: 8 cameras per workgroup, thread (c, k) sums the camera's chunk partials in chunk order (k = 27: cost)
+  const int cb = (int)blockIdx.x - lmBlocks;
+  const int c = cb * 8 + (tid >> 5), k = tid & 31;
+  if (c < K && k < 28) {
     double sacc = 0;
     for (int ch = camChunkStart[c]; ch < camChunkStart[c + 1]; ch++) sacc += partial[(size_t)ch * 28 + k];
     if (k < 21) {
@@ -221,14 +222,41 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
       const int bcol = a + rem;
       Hpp[36 * (size_t)c + 6 * a + bcol] = sacc;
       Hpp[36 * (size_t)c + 6 * bcol + a] = sacc;
-    } else {
+    } else if (k < 27) {
       g[6 * c + (k - 21)] = sacc;
+    } else {
+      costCam[c] = sacc;
     }
   }
+  // total cost = sum over cameras in index order, done by whichever camera workgroup arrives last (agent-scope
+  // release -> ticket -> acquire, cdna_hip_programming.md Guideline 16); the ticket counter is reset for the next launch
+  __shared__ int s_last;
+  __shared__ double s_red[256];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nCamBlocks = (int)gridDim.x - lmBlocks;
+    const int ticket = __hip_atomic_fetch_add(ticketCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == nCamBlocks - 1 ? 1 : 0;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (s_last) {
     double sacc = 0;
-    for (int ch = 0; ch < nChunks; ch++) sacc += partial[(size_t)ch * 28 + 27];
-    *cost = sacc;
+    const int per = (K + 255) / 256;
+    for (int i = tid * per; i < min(K, (tid + 1) * per); i++) sacc += __hip_atomic_load(&costCam[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_red[tid] = sacc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {  // fixed-shape tree: deterministic
+      if (tid < o) s_red[tid] += s_red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) { *cost = s_red[0]; __hip_atomic_store(ticketCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 
@@ -251,7 +279,8 @@ struct dvs_ba {
   unsigned char *d_pf = nullptr, *d_lf = nullptr;
   BaChunk* d_chunks = nullptr;
   double *d_res = nullptr, *d_Jp = nullptr, *d_Jl = nullptr, *d_W = nullptr, *d_partial = nullptr;
-  double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr;
+  double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr, *d_costCam = nullptr;
+  int* d_ticket = nullptr;
   double *d_raw = nullptr;  // R*(2+8+6+6)
 };
 
@@ -259,11 +288,11 @@ namespace {
 
 void ba_free(dvs_ba* h) {
   void* ptrs[] = {h->d_q, h->d_t, h->d_X, h->d_uv, h->d_cam, h->d_lm, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_pf,
-                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw};
+                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw, h->d_costCam, h->d_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
   h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
-  h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr;
+  h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr; h->d_ticket = nullptr;
 }
 
 template <class T>
@@ -289,9 +318,9 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
   hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
                      h->d_partial, raw, raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr,
                      raw ? raw + 16 * (size_t)h->R : nullptr);
-  hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + 1), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
+  hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + (h->K + 7) / 8), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
                      h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_res, h->d_Jl, h->d_partial, h->lmBlocks, withLm ? 1 : 0,
-                     h->d_Hpp, h->d_Hll, h->d_g, h->d_cost);
+                     h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_costCam, h->d_ticket);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
@@ -447,6 +476,8 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
   DVS_HIP(hipMalloc((void**)&h->d_g, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMalloc((void**)&h->d_cost, 8));
   DVS_HIP(hipMemset(h->d_Hpp, 0, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMemset(h->d_Hll, 0, (size_t)std::max(L, 1) * 9 * 8));
   DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
+  DVS_HIP(hipMalloc((void**)&h->d_costCam, (size_t)std::max(K, 1) * 8)); DVS_HIP(hipMemset(h->d_costCam, 0, (size_t)std::max(K, 1) * 8));
+  DVS_HIP(hipMalloc((void**)&h->d_ticket, 4)); DVS_HIP(hipMemset(h->d_ticket, 0, 4));
   return DVS_OK;
 }
 
