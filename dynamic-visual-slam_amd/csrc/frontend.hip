@@ -1,0 +1,376 @@
+// frontend.hip — the glue either side of the hot path, so keypoints and descriptors can stay
+// resident in HBM between extraction, matching and the backend's association:
+//   dvs_bgr_to_gray*        cv::cvtColor(BGR2GRAY), 8-bit fixed point            frontend.cpp:1084
+//   dvs_filter_depth*       filterDepth / isValidDepth (order-preserving compaction) frontend.cpp:457-527
+//   dvs_filter_matches      distance < 50 filter                                 frontend.cpp:618-623, 1126-1132
+//   dvs_backproject         publishKeyframe's depth back-projection               frontend.cpp:732-776
+//   dvs_associate           associateObservation + reprojectPoint on a database snapshot  backend.cpp:1064-1173
+// All of it is byte/integer or explicitly rounded float/double work: gathers and stream compactions, HBM/latency bound.
+// The context is a dvs_matcher handle (stream + grow-only scratch), declared in match.hip.
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "common.h"
+
+namespace dvs {
+
+typedef unsigned long long u64;
+
+// scratch + stream access to the matcher handle (match.hip)
+dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out);
+hipStream_t matcher_stream(dvs_matcher* m);
+int matcher_device(dvs_matcher* m);
+// match.hip: candidate pairs (Hamming < max_dist) as (q, t, dist) triplets + per-query offsets, left on the device
+dvs_status matcher_thresh_device(dvs_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int max_dist, const long long** d_offs,
+                                 const int** d_pairs, long long* total);
+
+__device__ __forceinline__ int blk_excl_scan(int v, int* wsum, int& total) {  // 256 threads
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const int s = wsum[i]; if (i < w) base += s; }
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
+// 4 pixels per thread; coefficients of OpenCV's RGB2Gray<uchar> (variant 0: 15-bit, 4.x; variant 1: 14-bit, older releases)
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, uint64_t step, uint64_t fstride, int rows, int cols,
+                                                  uint8_t* __restrict__ gray, uint64_t gstep, uint64_t gfstride, int cb, int cg, int cr,
+                                                  int shift) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+  if (x4 >= cols || y >= rows) return;
+  const uint8_t* s = bgr + (uint64_t)f * fstride + (uint64_t)y * step + 3 * (uint64_t)x4;
+  uint8_t* d = gray + (uint64_t)f * gfstride + (uint64_t)y * gstep + x4;
+  const int rnd = 1 << (shift - 1);
+  const int n = min(4, cols - x4);
+  uint8_t px[12];
+  if (n == 4 && (((uintptr_t)s) & 3) == 0) {
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s);
+    const uint32_t a = s32[0], b = s32[1], c = s32[2];
+    memcpy(px, &a, 4); memcpy(px + 4, &b, 4); memcpy(px + 8, &c, 4);
+  } else {
+    for (int i = 0; i < 3 * n; i++) px[i] = s[i];
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < n) out |= (uint32_t)((px[3 * i] * cb + px[3 * i + 1] * cg + px[3 * i + 2] * cr + rnd) >> shift) << (8 * i);
+  if (n == 4 && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t*>(d) = out;
+  else for (int i = 0; i < n; i++) d[i] = (uint8_t)(out >> (8 * i));
+}
+
+// std::round(float): half away from zero
+__device__ __forceinline__ int round_half_away(float v) { return (int)roundf(v); }
+
+// one workgroup per frame: order-preserving compaction of keypoints / descriptors with a valid depth
+__global__ __launch_bounds__(256) void k_filter_depth(const dvs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                      const int* __restrict__ nArr, int nConst, int strideRows,
+                                                      const uint16_t* __restrict__ depth, uint64_t dstep, uint64_t dfstride, int rows,
+                                                      int cols, float dmin, float dmax, dvs_keypoint* __restrict__ okps,
+                                                      uint8_t* __restrict__ odesc, int* __restrict__ oindex, int* __restrict__ nOut) {
+  __shared__ int wsum[5];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = nArr ? nArr[f] : nConst;
+  const dvs_keypoint* kp = kps + (size_t)f * strideRows;
+  const uint8_t* dp = (const uint8_t*)depth + (uint64_t)f * dfstride;
+  int carry = 0;
+  for (int b = 0; b < n; b += 256) {
+    const int i = b + tid;
+    bool keep = false;
+    dvs_keypoint k;
+    if (i < n) {
+      k = kp[i];
+      const int x = round_half_away(k.x), y = round_half_away(k.y);
+      if (x >= 0 && y >= 0 && x < cols && y < rows) {
+        const float d = __fmul_rn((float)*(const uint16_t*)(dp + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+        keep = !(d < dmin || d > dmax);
+      }
+    }
+    int tot;
+    const int pos = carry + blk_excl_scan(keep ? 1 : 0, wsum, tot);
+    if (keep) {
+      okps[(size_t)f * strideRows + pos] = k;
+      if (oindex) oindex[(size_t)f * strideRows + pos] = i;
+      if (desc) {
+        const uint4* sd = reinterpret_cast<const uint4*>(desc + ((size_t)f * strideRows + i) * 32);
+        uint4* dd = reinterpret_cast<uint4*>(odesc + ((size_t)f * strideRows + pos) * 32);
+        dd[0] = sd[0]; dd[1] = sd[1];
+      }
+    }
+    carry += tot;
+  }
+  if (tid == 0) nOut[f] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_filter_matches(const int* __restrict__ idx, const int* __restrict__ dist, const int* __restrict__ nArr,
+                                                        int nConst, int strideRows, float maxd, int* __restrict__ out, int* __restrict__ nOut) {
+  __shared__ int wsum[5];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = nArr ? nArr[f] : nConst;
+  int carry = 0;
+  for (int b = 0; b < n; b += 256) {
+    const int i = b + tid;
+    const bool keep = i < n && (float)dist[(size_t)f * strideRows + i] < maxd;
+    int tot;
+    const int pos = carry + blk_excl_scan(keep ? 1 : 0, wsum, tot);
+    if (keep) {
+      int* o = out + 3 * ((size_t)f * strideRows + pos);
+      o[0] = i; o[1] = idx[(size_t)f * strideRows + i]; o[2] = dist[(size_t)f * strideRows + i];
+    }
+    carry += tot;
+  }
+  if (tid == 0) nOut[f] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_backproject(const dvs_keypoint* __restrict__ kps, int n, const uint16_t* __restrict__ depth,
+                                                     uint64_t dstep, float fx, float fy, float cx, float cy, const double* __restrict__ Rt,
+                                                     double* __restrict__ world, int* __restrict__ oindex, int* __restrict__ nOut) {
+  __shared__ int wsum[5];
+  const int tid = threadIdx.x;
+  int carry = 0;
+  for (int b = 0; b < n; b += 256) {
+    const int i = b + tid;
+    bool keep = false;
+    float X = 0, Y = 0, Z = 0;
+    if (i < n) {
+      const float px = kps[i].x, py = kps[i].y;
+      const int x = round_half_away(px), y = round_half_away(py);
+      Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+      X = __fdiv_rn(__fmul_rn(__fsub_rn(px, cx), Z), fx);
+      Y = __fdiv_rn(__fmul_rn(__fsub_rn(py, cy), Z), fy);
+      keep = (double)Z > 0.3 && (double)Z < 3.0;
+    }
+    int tot;
+    const int pos = carry + blk_excl_scan(keep ? 1 : 0, wsum, tot);
+    if (keep) {
+      const double v0 = X, v1 = Y, v2 = Z;
+#pragma unroll
+      for (int r = 0; r < 3; r++) world[3 * (size_t)pos + r] = (Rt[3 * r] * v0 + Rt[3 * r + 1] * v1 + Rt[3 * r + 2] * v2) + Rt[9 + r];
+      oindex[pos] = i;
+    }
+    carry += tot;
+  }
+  if (tid == 0) *nOut = carry;
+}
+
+// reprojectPoint (backend.cpp:1153-1173) + cv::norm for every candidate pair; Rt = R (9, row-major) followed by t (3)
+__global__ __launch_bounds__(256) void k_reproject_errors(const int* __restrict__ pairs3, long long npairs, const float* __restrict__ obs_px,
+                                                          const float* __restrict__ lm_xyz, const double* __restrict__ Rt, double fx,
+                                                          double fy, double cx, double cy, double* __restrict__ err) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npairs) return;
+  const float* o = obs_px + 2 * (size_t)pairs3[3 * p];
+  const float* l = lm_xyz + 3 * (size_t)pairs3[3 * p + 1];
+  const double d0 = (double)l[0] - Rt[9], d1 = (double)l[1] - Rt[10], d2 = (double)l[2] - Rt[11];
+  const double c0 = Rt[0] * d0 + Rt[3] * d1 + Rt[6] * d2;
+  const double c1 = Rt[1] * d0 + Rt[4] * d1 + Rt[7] * d2;
+  const double c2 = Rt[2] * d0 + Rt[5] * d1 + Rt[8] * d2;
+  float u = -1.f, v = -1.f;
+  if (!(c2 <= 0)) { u = (float)(fx * c0 / c2 + cx); v = (float)(fy * c1 / c2 + cy); }
+  const float dx = __fsub_rn(o[0], u), dy = __fsub_rn(o[1], v);
+  err[p] = sqrt((double)dx * dx + (double)dy * dy);
+}
+
+// per observation: first candidate (landmark order) with the smallest error below the gate
+__global__ __launch_bounds__(256) void k_assoc_argmin(const long long* __restrict__ offs, int nobs, const int* __restrict__ pairs3,
+                                                      const double* __restrict__ err, double max_reproj, int* __restrict__ best) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nobs) return;
+  int bl = -1;
+  double be = DBL_MAX;
+  for (long long p = offs[i]; p < offs[i + 1]; p++) {
+    const double e = err[p];
+    if (e < max_reproj && e < be) { bl = pairs3[3 * p + 1]; be = e; }
+  }
+  best[i] = bl;
+}
+
+}  // namespace dvs
+
+using namespace dvs;
+
+extern "C" {
+
+dvs_status dvs_bgr_to_gray_device(dvs_matcher* ctx, const uint8_t* d_bgr, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                  size_t frame_stride, uint8_t* d_gray, size_t gray_step, size_t gray_frame_stride, int32_t variant) {
+  DVS_ARG(ctx && d_bgr && d_gray && nimg >= 0 && rows > 0 && cols > 0 && step >= (size_t)cols * 3 && gray_step >= (size_t)cols);
+  DVS_ARG(variant == 0 || variant == 1);
+  if (nimg == 0) return DVS_OK;
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  const int cb = variant == 0 ? 3735 : 1868, cg = variant == 0 ? 19235 : 9617, cr = variant == 0 ? 9798 : 4899, shift = variant == 0 ? 15 : 14;
+  hipLaunchKernelGGL(k_bgr2gray, dim3((cols + 255) / 256, (rows + 3) / 4, nimg), dim3(64, 4), 0, matcher_stream(ctx), d_bgr, (uint64_t)step,
+                     (uint64_t)frame_stride, rows, cols, d_gray, (uint64_t)gray_step, (uint64_t)gray_frame_stride, cb, cg, cr, shift);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_bgr_to_gray(dvs_matcher* ctx, const uint8_t* bgr, int32_t rows, int32_t cols, size_t step, uint8_t* gray, size_t gray_step,
+                           int32_t variant) {
+  DVS_ARG(ctx && bgr && gray && rows > 0 && cols > 0);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  void *d_in, *d_out;
+  DVS_TRY(matcher_scratch(ctx, 0, (size_t)rows * cols * 3, &d_in));
+  DVS_TRY(matcher_scratch(ctx, 1, (size_t)rows * cols, &d_out));
+  hipStream_t st = matcher_stream(ctx);
+  DVS_HIP(hipMemcpy2DAsync(d_in, (size_t)cols * 3, bgr, step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, st));
+  DVS_TRY(dvs_bgr_to_gray_device(ctx, (const uint8_t*)d_in, 1, rows, cols, (size_t)cols * 3, 0, (uint8_t*)d_out, cols, 0, variant));
+  DVS_HIP(hipMemcpy2DAsync(gray, gray_step, d_out, cols, cols, rows, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  return DVS_OK;
+}
+
+dvs_status dvs_filter_depth_batch_device(dvs_matcher* ctx, const dvs_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                         int32_t stride_rows, int32_t nframes, const uint16_t* d_depth, int32_t rows, int32_t cols,
+                                         size_t step_bytes, size_t frame_stride_bytes, float min_depth, float max_depth,
+                                         dvs_keypoint* d_out_kps, uint8_t* d_out_desc, int32_t* d_out_index, int32_t* d_n_out) {
+  DVS_ARG(ctx && d_kps && d_n && d_depth && d_out_kps && d_n_out && nframes >= 0 && stride_rows > 0 && rows > 0 && cols > 0);
+  DVS_ARG(!d_desc || d_out_desc);
+  if (nframes == 0) return DVS_OK;
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipLaunchKernelGGL(k_filter_depth, dim3(nframes), dim3(256), 0, matcher_stream(ctx), d_kps, d_desc, d_n, 0, stride_rows, d_depth,
+                     (uint64_t)step_bytes, (uint64_t)frame_stride_bytes, rows, cols, min_depth, max_depth, d_out_kps, d_out_desc, d_out_index, d_n_out);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_filter_depth(dvs_matcher* ctx, const dvs_keypoint* kps, const uint8_t* desc, int32_t n, const uint16_t* depth, int32_t rows,
+                            int32_t cols, size_t step_bytes, float min_depth, float max_depth, dvs_keypoint* out_kps, uint8_t* out_desc,
+                            int32_t* out_index, int32_t* n_out) {
+  DVS_ARG(ctx && n_out && n >= 0 && rows > 0 && cols > 0 && depth);
+  *n_out = 0;
+  if (n == 0) return DVS_OK;
+  DVS_ARG(kps && out_kps && (!desc || out_desc));
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const size_t kb = (size_t)n * sizeof(dvs_keypoint), db = (size_t)n * 32;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, 2 * kb + 2 * db + (size_t)n * 4 + 16 + (size_t)rows * cols * 2, (void**)&base));
+  dvs_keypoint* d_k = (dvs_keypoint*)base; dvs_keypoint* d_ok = (dvs_keypoint*)(base + kb);
+  uint8_t* d_d = base + 2 * kb; uint8_t* d_od = d_d + db;
+  int* d_oi = (int*)(d_od + db); int* d_no = d_oi + n;
+  uint16_t* d_dep = (uint16_t*)(((uintptr_t)(d_no + 2) + 15) & ~(uintptr_t)15);
+  DVS_HIP(hipMemcpyAsync(d_k, kps, kb, hipMemcpyHostToDevice, st));
+  if (desc) DVS_HIP(hipMemcpyAsync(d_d, desc, db, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpy2DAsync(d_dep, (size_t)cols * 2, depth, step_bytes, (size_t)cols * 2, rows, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_filter_depth, dim3(1), dim3(256), 0, st, d_k, desc ? d_d : nullptr, (const int*)nullptr, n, n, d_dep, (uint64_t)cols * 2,
+                     (uint64_t)0, rows, cols, min_depth, max_depth, d_ok, d_od, d_oi, d_no);
+  DVS_HIP(hipGetLastError());
+  int m = 0;
+  DVS_HIP(hipMemcpyAsync(&m, d_no, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  if (m) {
+    DVS_HIP(hipMemcpy(out_kps, d_ok, (size_t)m * sizeof(dvs_keypoint), hipMemcpyDeviceToHost));
+    if (desc) DVS_HIP(hipMemcpy(out_desc, d_od, (size_t)m * 32, hipMemcpyDeviceToHost));
+    if (out_index) DVS_HIP(hipMemcpy(out_index, d_oi, (size_t)m * 4, hipMemcpyDeviceToHost));
+  }
+  *n_out = m;
+  return DVS_OK;
+}
+
+dvs_status dvs_filter_matches(dvs_matcher* ctx, const int32_t* train_idx, const int32_t* dist, int32_t n, float max_distance,
+                              int32_t* out_triplets, int32_t* n_out) {
+  DVS_ARG(ctx && n_out && n >= 0);
+  *n_out = 0;
+  if (n == 0) return DVS_OK;
+  DVS_ARG(train_idx && dist && out_triplets);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  int* base;
+  DVS_TRY(matcher_scratch(ctx, 0, (size_t)n * 4 * 5 + 16, (void**)&base));
+  int *d_i = base, *d_d = base + n, *d_o = base + 2 * n, *d_n = base + 5 * n;
+  DVS_HIP(hipMemcpyAsync(d_i, train_idx, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_d, dist, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_filter_matches, dim3(1), dim3(256), 0, st, d_i, d_d, (const int*)nullptr, n, n, max_distance, d_o, d_n);
+  DVS_HIP(hipGetLastError());
+  int m = 0;
+  DVS_HIP(hipMemcpyAsync(&m, d_n, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  if (m) DVS_HIP(hipMemcpy(out_triplets, d_o, (size_t)m * 12, hipMemcpyDeviceToHost));
+  *n_out = m;
+  return DVS_OK;
+}
+
+dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n, const uint16_t* depth, int32_t rows, int32_t cols,
+                           size_t step_bytes, float fx, float fy, float cx, float cy, const double* R, const double* t, double* world_xyz,
+                           int32_t* out_index, int32_t* n_out) {
+  DVS_ARG(ctx && n_out && n >= 0 && rows > 0 && cols > 0 && depth && R && t);
+  *n_out = 0;
+  if (n == 0) return DVS_OK;
+  DVS_ARG(kps && world_xyz && out_index);
+  for (int i = 0; i < n; i++) {  // the reference indexes the depth image unchecked (frontend.cpp:737): refuse instead of faulting
+    const long x = lroundf(kps[i].x), y = lroundf(kps[i].y);
+    if (x < 0 || y < 0 || x >= cols || y >= rows) { set_error("keypoint %d (%g, %g) outside the %dx%d depth image", i, kps[i].x, kps[i].y, cols, rows); return DVS_ERR_ARG; }
+  }
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const size_t kb = ((size_t)n * sizeof(dvs_keypoint) + 15) & ~(size_t)15;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, kb + 96 + (size_t)n * 24 + (size_t)n * 4 + 16 + (size_t)rows * cols * 2 + 32, (void**)&base));
+  dvs_keypoint* d_k = (dvs_keypoint*)base;
+  double* d_Rt = (double*)(base + kb);
+  double* d_w = d_Rt + 12;
+  int* d_oi = (int*)(d_w + 3 * (size_t)n); int* d_no = d_oi + n;
+  uint16_t* d_dep = (uint16_t*)(((uintptr_t)(d_no + 2) + 15) & ~(uintptr_t)15);
+  double Rt[12];
+  memcpy(Rt, R, 72); memcpy(Rt + 9, t, 24);
+  DVS_HIP(hipMemcpyAsync(d_k, kps, (size_t)n * sizeof(dvs_keypoint), hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_Rt, Rt, 96, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpy2DAsync(d_dep, (size_t)cols * 2, depth, step_bytes, (size_t)cols * 2, rows, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_backproject, dim3(1), dim3(256), 0, st, d_k, n, d_dep, (uint64_t)cols * 2, fx, fy, cx, cy, d_Rt, d_w, d_oi, d_no);
+  DVS_HIP(hipGetLastError());
+  int m = 0;
+  DVS_HIP(hipMemcpyAsync(&m, d_no, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  if (m) {
+    DVS_HIP(hipMemcpy(world_xyz, d_w, (size_t)m * 24, hipMemcpyDeviceToHost));
+    DVS_HIP(hipMemcpy(out_index, d_oi, (size_t)m * 4, hipMemcpyDeviceToHost));
+  }
+  *n_out = m;
+  return DVS_OK;
+}
+
+dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                         const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
+                         double max_descriptor_distance, double max_reprojection_distance, int32_t* best) {
+  DVS_ARG(ctx && nobs >= 0 && nlm >= 0);
+  if (nobs == 0) return DVS_OK;
+  DVS_ARG(obs_desc && obs_px && best && R && t);
+  for (int i = 0; i < nobs; i++) best[i] = -1;
+  if (nlm == 0) return DVS_OK;
+  DVS_ARG(lm_desc && lm_xyz);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  // (float)d < max_desc with integer d  <=>  d < ceil(max_desc)
+  const int thr = (int)std::min<double>(ceil(max_descriptor_distance), 257.0);
+  const long long* d_offs; const int* d_pairs; long long total = 0;
+  DVS_TRY(matcher_thresh_device(ctx, obs_desc, nobs, lm_desc, nlm, thr, &d_offs, &d_pairs, &total));
+  if (total == 0) return DVS_OK;
+  uint8_t* base;
+  const size_t pb = ((size_t)nobs * 8 + 15) & ~(size_t)15, lb = ((size_t)nlm * 12 + 15) & ~(size_t)15;
+  DVS_TRY(matcher_scratch(ctx, 2, pb + lb + 96 + (size_t)total * 8 + (size_t)nobs * 4 + 64, (void**)&base));
+  float* d_px = (float*)base; float* d_lm = (float*)(base + pb);
+  double* d_Rt = (double*)(base + pb + lb); double* d_err = d_Rt + 12;
+  int* d_best = (int*)(d_err + total);
+  double Rt[12];
+  memcpy(Rt, R, 72); memcpy(Rt + 9, t, 24);
+  DVS_HIP(hipMemcpyAsync(d_px, obs_px, (size_t)nobs * 8, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_lm, lm_xyz, (size_t)nlm * 12, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_Rt, Rt, 96, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_reproject_errors, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_pairs, total, d_px, d_lm, d_Rt, fx, fy, cx, cy, d_err);
+  hipLaunchKernelGGL(k_assoc_argmin, dim3((nobs + 255) / 256), dim3(256), 0, st, d_offs, nobs, d_pairs, d_err, max_reprojection_distance, d_best);
+  DVS_HIP(hipGetLastError());
+  DVS_HIP(hipMemcpyAsync(best, d_best, (size_t)nobs * 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  return DVS_OK;
+}
+
+}  // extern "C"

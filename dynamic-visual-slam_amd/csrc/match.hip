@@ -162,6 +162,8 @@ struct dvs_matcher {
   // grow-only staging for the host entry points
   void *d_q = nullptr, *d_t = nullptr, *d_idx = nullptr, *d_dist = nullptr, *d_counts = nullptr, *d_offs = nullptr, *d_pairs = nullptr;
   size_t cq = 0, ct = 0, cidx = 0, ccounts = 0, cpairs = 0;
+  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only buffers of the glue entry points (frontend.hip)
+  size_t cscratch[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -174,6 +176,46 @@ dvs_status grow(void** p, size_t* cap, size_t need) {
   return DVS_OK;
 }
 }  // namespace
+
+namespace dvs {
+dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out) {
+  DVS_TRY(grow(&m->scratch[slot], &m->cscratch[slot], bytes));
+  *out = m->scratch[slot];
+  return DVS_OK;
+}
+hipStream_t matcher_stream(dvs_matcher* m) { return m->stream; }
+int matcher_device(dvs_matcher* m) { return m->device; }
+
+// every (query, train) pair with distance < max_dist as (q, t, dist) triplets in (q, t) order, LEFT ON THE DEVICE:
+// offsets[nq + 1] (exclusive, 64-bit) and the triplet array.  Host inputs are staged; synchronises once for the total.
+dvs_status matcher_thresh_device(dvs_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int max_dist, const long long** d_offs,
+                                 const int** d_pairs, long long* total) {
+  DVS_HIP(hipSetDevice(m->device));
+  DVS_TRY(grow(&m->d_q, &m->cq, (size_t)nq * 32));
+  DVS_TRY(grow(&m->d_t, &m->ct, (size_t)nt * 32));
+  DVS_TRY(grow(&m->d_counts, &m->ccounts, (size_t)nq * 4));
+  if (m->d_offs) { DVS_HIP(hipFree(m->d_offs)); m->d_offs = nullptr; }
+  DVS_HIP(hipMalloc(&m->d_offs, ((size_t)nq + 1) * 8));
+  DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+  DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+  const dim3 grid((nq + 255) / 256);
+  hipLaunchKernelGGL(k_thresh_count, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist, (int*)m->d_counts);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, m->stream, (const int*)m->d_counts, nq, (long long*)m->d_offs);
+  DVS_HIP(hipGetLastError());
+  long long tot = 0;
+  DVS_HIP(hipMemcpyAsync(&tot, (long long*)m->d_offs + nq, 8, hipMemcpyDeviceToHost, m->stream));
+  DVS_HIP(hipStreamSynchronize(m->stream));
+  DVS_TRY(grow(&m->d_pairs, &m->cpairs, (size_t)std::max<long long>(tot, 1) * 12));
+  if (tot) {
+    hipLaunchKernelGGL(k_thresh_write, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist,
+                       (const long long*)m->d_offs, (int*)m->d_pairs, tot);
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipStreamSynchronize(m->stream));
+  }
+  *d_offs = (const long long*)m->d_offs; *d_pairs = (const int*)m->d_pairs; *total = tot;
+  return DVS_OK;
+}
+}  // namespace dvs
 
 extern "C" {
 
@@ -195,7 +237,7 @@ void dvs_matcher_destroy(dvs_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs};
+  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
@@ -261,26 +303,10 @@ dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq
   *n_pairs = 0;
   if (nq == 0 || nt == 0) return DVS_OK;
   DVS_ARG(q && t && (pairs || cap == 0));
-  DVS_HIP(hipSetDevice(m->device));
-  DVS_TRY(grow(&m->d_q, &m->cq, (size_t)nq * 32));
-  DVS_TRY(grow(&m->d_t, &m->ct, (size_t)nt * 32));
-  DVS_TRY(grow(&m->d_counts, &m->ccounts, (size_t)nq * 4));
-  if (m->d_offs) { DVS_HIP(hipFree(m->d_offs)); m->d_offs = nullptr; }
-  DVS_HIP(hipMalloc(&m->d_offs, ((size_t)nq + 1) * 8));
-  DVS_TRY(grow(&m->d_pairs, &m->cpairs, (size_t)std::max(cap, 1) * 12));
-  DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-  DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-  const dim3 grid((nq + 255) / 256);
-  hipLaunchKernelGGL(k_thresh_count, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist, (int*)m->d_counts);
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, m->stream, (const int*)m->d_counts, nq, (long long*)m->d_offs);
-  hipLaunchKernelGGL(k_thresh_write, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist,
-                     (const long long*)m->d_offs, (int*)m->d_pairs, (long long)cap);
-  DVS_HIP(hipGetLastError());
-  long long total = 0;
-  DVS_HIP(hipMemcpyAsync(&total, (long long*)m->d_offs + nq, 8, hipMemcpyDeviceToHost, m->stream));
-  DVS_HIP(hipStreamSynchronize(m->stream));
+  const long long* d_offs; const int* d_pairs; long long total = 0;
+  DVS_TRY(matcher_thresh_device(m, q, nq, t, nt, max_dist, &d_offs, &d_pairs, &total));
   const long long nw = std::min<long long>(total, cap);
-  if (nw) DVS_HIP(hipMemcpy(pairs, m->d_pairs, (size_t)nw * 12, hipMemcpyDeviceToHost));
+  if (nw) DVS_HIP(hipMemcpy(pairs, d_pairs, (size_t)nw * 12, hipMemcpyDeviceToHost));
   *n_pairs = (int32_t)std::min<long long>(total, INT_MAX);
   return DVS_OK;
 }

@@ -9,3 +9,4 @@ from ._lib import lib, DvsError, KP_DTYPE, device_count, build_library  # noqa: 
 from .orb import ORBextractor  # noqa: F401
 from .matcher import BFMatcher  # noqa: F401
 from .ba import BAProblem, SlidingWindowBA  # noqa: F401
+from .glue import FrontendGlue  # noqa: F401

@@ -139,6 +139,42 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
 dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,
                                     int32_t max_dist, int32_t* pairs, int32_t cap, int32_t* n_pairs);
 
+/* ======================= glue either side of the path =============== */
+/* A dvs_matcher handle is the context (stream + scratch).  Host pointers unless the name says _device. */
+
+/* cv::cvtColor(bgr, gray, COLOR_BGR2GRAY) on 8UC3 (frontend.cpp:1084).  variant 0 = OpenCV 4.x 15-bit coefficients
+ * (B*3735 + G*19235 + R*9798 + 16384) >> 15, variant 1 = the 14-bit ones of older releases. */
+dvs_status dvs_bgr_to_gray(dvs_matcher* ctx, const uint8_t* bgr, int32_t rows, int32_t cols, size_t step, uint8_t* gray, size_t gray_step,
+                           int32_t variant);
+dvs_status dvs_bgr_to_gray_device(dvs_matcher* ctx, const uint8_t* d_bgr, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                  size_t frame_stride, uint8_t* d_gray, size_t gray_step, size_t gray_frame_stride, int32_t variant);
+/* filterDepth / isValidDepth (frontend.cpp:457-527): keep keypoints (and descriptor rows) whose pixel (std::round of pt) has
+ * depth_u16 * 0.001f in [min_depth, max_depth]; order preserved; out_index = original indices (may be NULL). */
+dvs_status dvs_filter_depth(dvs_matcher* ctx, const dvs_keypoint* kps, const uint8_t* desc, int32_t n, const uint16_t* depth, int32_t rows,
+                            int32_t cols, size_t step_bytes, float min_depth, float max_depth, dvs_keypoint* out_kps, uint8_t* out_desc,
+                            int32_t* out_index, int32_t* n_out);
+/* nframes frames resident in HBM: frame f uses rows [0, d_n[f]) of the [nframes][stride_rows] blocks dvs_orb_extract_batch_device
+ * wrote and the depth image at d_depth + f * frame_stride_bytes.  Asynchronous. */
+dvs_status dvs_filter_depth_batch_device(dvs_matcher* ctx, const dvs_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                         int32_t stride_rows, int32_t nframes, const uint16_t* d_depth, int32_t rows, int32_t cols,
+                                         size_t step_bytes, size_t frame_stride_bytes, float min_depth, float max_depth,
+                                         dvs_keypoint* d_out_kps, uint8_t* d_out_desc, int32_t* d_out_index, int32_t* d_n_out);
+/* frontend.cpp:1126-1132: matches with (float)distance < max_distance as (queryIdx, trainIdx, distance) int32 triplets */
+dvs_status dvs_filter_matches(dvs_matcher* ctx, const int32_t* train_idx, const int32_t* dist, int32_t n, float max_distance,
+                              int32_t* out_triplets, int32_t* n_out);
+/* publishKeyframe (frontend.cpp:732-776): float back-projection with the depth image, keep 0.3 < Z < 3.0, world = R * p + t
+ * (R row-major 3x3, double).  world_xyz[3 * n_out], out_index = keypoint indices (= the message's landmark_id). */
+dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n, const uint16_t* depth, int32_t rows, int32_t cols,
+                           size_t step_bytes, float fx, float fy, float cx, float cy, const double* R, const double* t, double* world_xyz,
+                           int32_t* out_index, int32_t* n_out);
+/* associateObservation + reprojectPoint (backend.cpp:1064-1173) for all observations of one category against a snapshot of
+ * that category's landmarks (arrays in the database's iteration order): best[i] = index of the candidate with Hamming
+ * distance < max_descriptor_distance and the smallest reprojection error < max_reprojection_distance (first on ties), or -1.
+ * obs_px: nobs x (u, v) float; lm_xyz: nlm x 3 float (cv::Point3f); R, t: keyframe pose as extractPoseFromTransform gives it. */
+dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                         const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
+                         double max_descriptor_distance, double max_reprojection_distance, int32_t* best);
+
 /* ======================================= B3: bundle adjustment ================================= */
 
 typedef struct dvs_ba dvs_ba;

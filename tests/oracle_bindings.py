@@ -198,3 +198,54 @@ class OracleBA:
         q = np.zeros((self.K, 4)); t = np.zeros((self.K, 3)); X = np.zeros((self.Ln, 3))
         self.L.orc_ba_get_parameters(self.h, _p(q), _p(t), _p(X))
         return q, t, X
+
+
+# ------------------------------------------------ frontend / backend glue oracle (N1, N2) -------------------------------
+def _glue_lib():
+    L = lib()
+    vp, i32, sz, f32, dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
+    L.orc_bgr_to_gray.argtypes = [vp, i32, i32, sz, vp, sz, i32]
+    L.orc_filter_depth.restype = i32; L.orc_filter_depth.argtypes = [vp, vp, i32, vp, i32, i32, sz, f32, f32, vp, vp, vp]
+    L.orc_filter_matches.restype = i32; L.orc_filter_matches.argtypes = [vp, vp, i32, f32, vp]
+    L.orc_backproject.restype = i32; L.orc_backproject.argtypes = [vp, i32, vp, sz, f32, f32, f32, f32, vp, vp, vp, vp]
+    L.orc_associate.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl, vp]
+    return L
+
+
+def bgr_to_gray(bgr, variant=0):
+    bgr = np.ascontiguousarray(bgr); rows, cols, _ = bgr.shape
+    g = np.zeros((rows, cols), np.uint8)
+    _glue_lib().orc_bgr_to_gray(_p(bgr), rows, cols, cols * 3, _p(g), cols, variant)
+    return g
+
+
+def filter_depth(kps, desc, depth, dmin=0.3, dmax=3.0):
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+    n = len(kps); ok = np.zeros(n, KP_DTYPE); od = np.zeros((n, 32), np.uint8); oi = np.zeros(n, np.int32)
+    m = _glue_lib().orc_filter_depth(_p(kps), _p(desc), n, _p(depth), depth.shape[0], depth.shape[1], depth.shape[1] * 2, dmin, dmax, _p(ok), _p(od), _p(oi))
+    return ok[:m], od[:m], oi[:m]
+
+
+def filter_matches(idx, dist, maxd=50.0):
+    idx = np.ascontiguousarray(idx, np.int32); dist = np.ascontiguousarray(dist, np.int32)
+    out = np.zeros((len(idx), 3), np.int32)
+    m = _glue_lib().orc_filter_matches(_p(idx), _p(dist), len(idx), maxd, _p(out))
+    return out[:m]
+
+
+def backproject(kps, depth, fx, fy, cx, cy, R, t):
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16)
+    R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64)
+    n = len(kps); w = np.zeros((n, 3)); oi = np.zeros(n, np.int32)
+    m = _glue_lib().orc_backproject(_p(kps), n, _p(depth), depth.shape[1] * 2, fx, fy, cx, cy, _p(R), _p(t), _p(w), _p(oi))
+    return w[:m], oi[:m]
+
+
+def associate(obs_desc, obs_px, lm_desc, lm_xyz, R, t, fx, fy, cx, cy, max_desc=50.0, max_reproj=5.0):
+    obs_desc = np.ascontiguousarray(obs_desc, np.uint8); obs_px = np.ascontiguousarray(obs_px, np.float32)
+    lm_desc = np.ascontiguousarray(lm_desc, np.uint8); lm_xyz = np.ascontiguousarray(lm_xyz, np.float32)
+    R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64)
+    best = np.zeros(len(obs_desc), np.int32)
+    _glue_lib().orc_associate(_p(obs_desc), _p(obs_px), len(obs_desc), _p(lm_desc), _p(lm_xyz), len(lm_desc), _p(R), _p(t), fx, fy, cx, cy,
+                              max_desc, max_reproj, _p(best))
+    return best

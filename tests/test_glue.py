@@ -1,0 +1,88 @@
+"""N1 / N2 rows: BGR->gray, depth filter, distance filter, back-projection, backend association.
+CPU: known-answers of the oracle restatements; GPU: HIP entry points vs the oracle — bit-exact (integer / index work,
+doubles produced by identically ordered operations)."""
+import numpy as np
+import pytest
+from dvslam_amd import synth
+
+
+def _scene(seed=0, n=700):
+    rng = np.random.default_rng(seed)
+    from oracle_bindings import KP_DTYPE
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(0, 639.49, n).astype(np.float32); kps["y"] = rng.uniform(0, 479.49, n).astype(np.float32)
+    kps["x"][:5] = [10.5, 11.5, 100.49999, 0.0, 639.4]          # .5 cases: std::round goes away from zero
+    kps["response"] = rng.integers(7, 200, n); kps["octave"] = rng.integers(0, 8, n); kps["class_id"] = -1
+    desc = synth.make_descriptors(n, seed + 1)
+    depth = rng.integers(0, 4000, (480, 640)).astype(np.uint16)
+    depth[::7, ::5] = 0; depth[3, 3] = 300; depth[4, 4] = 3000; depth[5, 5] = 299; depth[6, 6] = 3001
+    return kps, desc, depth
+
+
+def test_oracle_known_answers(oracle):
+    bgr = np.zeros((2, 3, 3), np.uint8)
+    bgr[0, 0] = [255, 255, 255]; bgr[0, 1] = [255, 0, 0]; bgr[0, 2] = [0, 255, 0]; bgr[1, 0] = [0, 0, 255]; bgr[1, 1] = [10, 20, 30]
+    g = oracle.bgr_to_gray(bgr, 0)
+    assert g[0, 0] == 255 and g[0, 1] == 29 and g[0, 2] == 150 and g[1, 0] == 76          # 0.114 / 0.587 / 0.299 weights
+    assert g[1, 1] == (10 * 3735 + 20 * 19235 + 30 * 9798 + 16384) >> 15
+    assert oracle.bgr_to_gray(bgr, 1)[1, 1] == (10 * 1868 + 20 * 9617 + 30 * 4899 + 8192) >> 14
+    kps, desc, depth = _scene()
+    ok, od, oi = oracle.filter_depth(kps, desc, depth)
+    x = np.floor(np.abs(kps["x"]) + 0.5).astype(int); y = np.floor(np.abs(kps["y"]) + 0.5).astype(int)
+    inside = (x < 640) & (y < 480)
+    d = depth[np.minimum(y, 479), np.minimum(x, 639)].astype(np.float32) * np.float32(0.001)
+    keep = inside & ~((d < np.float32(0.3)) | (d > np.float32(3.0)))
+    assert (oi == np.nonzero(keep)[0]).all() and (od == desc[keep]).all() and ok.tobytes() == kps[keep].tobytes()
+    idx = np.arange(6, dtype=np.int32)[::-1].copy(); dist = np.array([49, 50, 0, 256, 51, 12], np.int32)
+    assert oracle.filter_matches(idx, dist).tolist() == [[0, 5, 49], [2, 3, 0], [5, 0, 12]]
+
+
+@pytest.mark.gpu
+def test_glue_parity(gpu, oracle):
+    from dvslam_amd import FrontendGlue
+    g = FrontendGlue()
+    bgr, depth16 = synth.make_rgbd(0, cols=642, rows=481)
+    rng = np.random.default_rng(3)
+    bgr = np.ascontiguousarray(rng.integers(0, 256, bgr.shape, dtype=np.uint8))            # arbitrary colours, odd width
+    for variant in (0, 1):
+        assert (g.bgr_to_gray(bgr, variant) == oracle.bgr_to_gray(bgr, variant)).all()
+    big = np.zeros((100, 50 * 3 + 7), np.uint8); view = big[:, 2:2 + 150].reshape(100, 50, 3)  # unaligned rows
+    view[:] = rng.integers(0, 256, (100, 50, 3))
+    assert (g.bgr_to_gray(view) == oracle.bgr_to_gray(np.ascontiguousarray(view))).all()
+    kps, desc, depth = _scene(5, 2011)
+    a = g.filter_depth(kps, desc, depth); b = oracle.filter_depth(kps, desc, depth)
+    assert a[0].tobytes() == b[0].tobytes() and (a[1] == b[1]).all() and (a[2] == b[2]).all() and 0 < len(b[2]) < len(kps)
+    e = g.filter_depth(kps[:0], desc[:0], depth)
+    assert len(e[0]) == 0
+    idx = rng.integers(0, 2000, 2024).astype(np.int32); dist = rng.integers(0, 120, 2024).astype(np.int32)
+    assert (g.filter_matches(idx, dist) == oracle.filter_matches(idx, dist)).all()
+    R = np.array([[0.9975, -0.0499, 0.05], [0.0524, 0.9974, -0.0498], [-0.0474, 0.0523, 0.9975]]); t = np.array([0.1, -0.2, 0.05])
+    w1, i1 = g.backproject(kps, depth, 615.5, 616.25, 320.1, 241.3, R, t); w2, i2 = oracle.backproject(kps, depth, 615.5, 616.25, 320.1, 241.3, R, t)
+    assert (i1 == i2).all() and w1.tobytes() == w2.tobytes() and len(i2) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nobs,nlm,seed", [(1, 1, 0), (300, 1500, 1), (1200, 4000, 2), (64, 0, 3)])
+def test_association_parity(gpu, oracle, nobs, nlm, seed):
+    """backend.cpp:1064-1120 on a database snapshot: Hamming gate 50, reprojection gate 5 px, first-in-order ties"""
+    from dvslam_amd import FrontendGlue
+    rng = np.random.default_rng(seed)
+    lm_desc = synth.make_descriptors(max(nlm, 1), 50 + seed)[:nlm]
+    lm_xyz = np.stack([rng.uniform(-2, 2, nlm), rng.uniform(-1.5, 1.5, nlm), rng.uniform(2, 6, nlm)], axis=1).astype(np.float32)
+    obs_desc = synth.make_descriptors(nobs, 60 + seed)
+    R = np.eye(3); t = np.array([0.05, 0.02, -0.1]); fx = fy = 600.0; cx, cy = 320.0, 240.0
+    obs_px = rng.uniform(0, 640, (nobs, 2)).astype(np.float32)
+    for i in range(min(nobs, nlm)):            # make most observations true re-observations with small descriptor / pixel noise
+        j = int(rng.integers(0, nlm))
+        d = lm_desc[j].copy(); flips = rng.integers(0, 256, int(rng.integers(0, 60)))
+        for f in flips: d[f // 8] ^= 1 << (f % 8)
+        obs_desc[i] = d
+        pc = R.T @ (lm_xyz[j].astype(np.float64) - t)
+        obs_px[i] = [fx * pc[0] / pc[2] + cx + rng.normal(0, 2.5), fy * pc[1] / pc[2] + cy + rng.normal(0, 2.5)]
+    if nlm > 10 and nobs > 3:                  # exact duplicates in the database: the first one in order must win
+        lm_desc[7] = lm_desc[3]; lm_xyz[7] = lm_xyz[3]
+    got = FrontendGlue().associate(obs_desc, obs_px, lm_desc, lm_xyz, R, t, fx, fy, cx, cy)
+    ref = oracle.associate(obs_desc, obs_px, lm_desc, lm_xyz, R, t, fx, fy, cx, cy) if nlm else np.full(nobs, -1, np.int32)
+    assert (got == ref).all()
+    if nlm > 100:
+        assert (ref >= 0).sum() > 0.2 * min(nobs, nlm) and (ref < 0).sum() > 0
