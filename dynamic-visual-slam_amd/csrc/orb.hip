@@ -455,11 +455,16 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
         hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0);
       }
     };
-    if (ov) {  // one launch per level, each gated on its own level only
+    if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
+      int tail = G.nlevels;  // first level of the merged tail: levels whose cells are < 1/16 of all cells each
+      while (tail > 2 && G.lv[tail - 1].nCells * 16 < G.totalCells) tail--;
       for (int l = 0; l < G.nlevels; l++) {
-        if (l > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[l], 0));
+        const bool merged = l >= tail;
+        if (merged && l > tail) continue;
+        const int lastl = merged ? G.nlevels - 1 : l;
+        if (lastl > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[lastl], 0));
         h->timer.begin(DVS_STAGE_FAST, st, l == 0);
-        launch_fast(G.lv[l].cellBase, G.lv[l].cellBase + G.lv[l].nCells);
+        launch_fast(G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
         h->timer.end(st);
       }
     } else {
