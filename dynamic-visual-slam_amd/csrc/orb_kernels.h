@@ -1187,91 +1187,126 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+// Two keypoints per wavefront, addressed by their fixed (level, index) slot in the per-level keypoint block, so the first
+// memory round trip fetches the level counts, both packed keypoints and the weight tables together; the orientation
+// loads of both keypoints are then in flight at once, and so are their 16 descriptor gathers.  (With one keypoint per wave
+// and the level looked up from the counts first, the kernel was a chain of 4-5 dependent round trips: 26 % VALU busy.)
+constexpr int kDescKP = 2;
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
                                                   const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
                                                   int* __restrict__ nOut, int capacity) {
+  typedef uint32_t __attribute__((aligned(1))) u32u;
   const int f = blockIdx.y;
-  const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
-  int level = -1, off = 0, total = 0;
-  for (int l = 0; l < nl; l++) {
-    const int c = cnt[l];
-    if (level < 0 && gi < total + c) { level = l; off = total; }
-    total += c;
+  const int slot0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kDescKP;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int total = 0;
+    for (int l = 0; l < nl; l++) total += cnt[l];
+    nOut[f] = min(total, capacity);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) nOut[f] = min(total, capacity);
-  if (level < 0 || gi >= capacity) return;
-  const LevelGeom& L = g->lv[level];
-  const uint32_t pk = lvlKp[(uint64_t)f * g->kpBlock + L.kpOff + (gi - off)];
-  const int x = pt_x(pk) + kMinBorder, y = pt_y(pk) + kMinBorder;  // level pixel coordinates (:886-887)
-  int pitch;
-  const u8* img = level_ptr(g, src, f, level, pitch);
-
-  // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch (umax).  Lane = 2*row + half owns 16 bytes of
-  // one patch row (4 unaligned dword loads); membership and the u weights are per-lane byte tables (Geom::icw), so the
-  // sums are 8 v_dot4_u32_u8:  sum u*I = sum (u+15)*I - 15 * sum I.  Exact integer arithmetic, order independent.
-  int m10 = 0, m01 = 0;
-  {
-    typedef uint32_t __attribute__((aligned(1))) u32u;
-    const int row = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
-    const int v = row - kHalfPatch;
-    const u8* p = img + (int64_t)(y + v) * pitch + x + (half ? 1 : -kHalfPatch);
-    const uint32_t d0 = *reinterpret_cast<const u32u*>(p), d1 = *reinterpret_cast<const u32u*>(p + 4),
-                   d2 = *reinterpret_cast<const u32u*>(p + 8), d3 = *reinterpret_cast<const u32u*>(p + 12);
-    const uint32_t* wt = g->icw[lane];
-    uint32_t su = __builtin_amdgcn_udot4(d0, wt[0], 0u, false);
-    su = __builtin_amdgcn_udot4(d1, wt[1], su, false);
-    su = __builtin_amdgcn_udot4(d2, wt[2], su, false);
-    su = __builtin_amdgcn_udot4(d3, wt[3], su, false);
-    uint32_t sm = __builtin_amdgcn_udot4(d0, wt[4], 0u, false);
-    sm = __builtin_amdgcn_udot4(d1, wt[5], sm, false);
-    sm = __builtin_amdgcn_udot4(d2, wt[6], sm, false);
-    sm = __builtin_amdgcn_udot4(d3, wt[7], sm, false);
-    m10 = (int)su - kHalfPatch * (int)sm;
-    m01 = v * (int)sm;
+  if (slot0 >= g->kpBlock) return;
+  // slot -> (level, index in level, output position); all wave-uniform
+  int level[kDescKP], gi[kDescKP];
+  bool valid[kDescKP];
+  uint32_t pk[kDescKP];
+#pragma unroll
+  for (int u = 0; u < kDescKP; u++) {
+    const int slot = slot0 + u;
+    int lv = 0, pre = 0, acc = 0;
+    for (int l = 0; l < nl; l++) {
+      if (slot >= g->lv[l].kpOff) { lv = l; pre = acc; }
+      acc += cnt[l];
+    }
+    const int idx = slot - g->lv[lv].kpOff;
+    level[u] = lv;
+    gi[u] = pre + idx;
+    valid[u] = slot < g->kpBlock && idx < cnt[lv] && gi[u] < capacity;
+    pk[u] = lvlKp[(uint64_t)f * g->kpBlock + min(slot, g->kpBlock - 1)];
+  }
+  if (!valid[0] && !valid[1]) return;
+  const uint32_t* wt = g->icw[lane];
+  const uint32_t w8[8] = {wt[0], wt[1], wt[2], wt[3], wt[4], wt[5], wt[6], wt[7]};
+  const int row = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
+  const int v = row - kHalfPatch;
+  int x[kDescKP], y[kDescKP], pitch[kDescKP];
+  uint32_t d[kDescKP][4];
+#pragma unroll
+  for (int u = 0; u < kDescKP; u++) {
+    x[u] = pt_x(pk[u]) + kMinBorder; y[u] = pt_y(pk[u]) + kMinBorder;  // level pixel coordinates (:886-887)
+    if (!valid[u]) { x[u] = kEdge; y[u] = kEdge; }                       // harmless in-bounds dummy
+    const u8* img = level_ptr(g, src, f, level[u], pitch[u]);
+    // IC_Angle (ORBextractor.cpp:76-103): lane = 2*row + half owns 16 bytes of one patch row
+    const u8* p = img + (int64_t)(y[u] + v) * pitch[u] + x[u] + (half ? 1 : -kHalfPatch);
+    d[u][0] = *reinterpret_cast<const u32u*>(p); d[u][1] = *reinterpret_cast<const u32u*>(p + 4);
+    d[u][2] = *reinterpret_cast<const u32u*>(p + 8); d[u][3] = *reinterpret_cast<const u32u*>(p + 12);
+  }
+  float angle[kDescKP];
+#pragma unroll
+  for (int u = 0; u < kDescKP; u++) {
+    // membership and the u weights are per-lane byte tables (Geom::icw): sum u*I = sum (u+15)*I - 15 * sum I, exact integers
+    uint32_t su = __builtin_amdgcn_udot4(d[u][0], w8[0], 0u, false);
+    su = __builtin_amdgcn_udot4(d[u][1], w8[1], su, false);
+    su = __builtin_amdgcn_udot4(d[u][2], w8[2], su, false);
+    su = __builtin_amdgcn_udot4(d[u][3], w8[3], su, false);
+    uint32_t sm = __builtin_amdgcn_udot4(d[u][0], w8[4], 0u, false);
+    sm = __builtin_amdgcn_udot4(d[u][1], w8[5], sm, false);
+    sm = __builtin_amdgcn_udot4(d[u][2], w8[6], sm, false);
+    sm = __builtin_amdgcn_udot4(d[u][3], w8[7], sm, false);
+    int m10 = (int)su - kHalfPatch * (int)sm;
+    int m01 = v * (int)sm;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    angle[u] = fast_atan2_deg((float)m01, (float)m10);
   }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-
   // steered BRIEF on the blurred level (:107-146)
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float arad = __fmul_rn(angle, factorPI);
-  const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
-  const u8* bc = blur + (uint64_t)f * g->frameBytes + L.off + (uint64_t)y * L.pitch + x;
-  const int bp = L.pitch;
-  unsigned long long words[4];
+  int t0[kDescKP][4], t1[kDescKP][4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int p = 64 * r + lane;
-    const int pat = reinterpret_cast<const int*>(c_pattern)[p];
-    const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bc[(int64_t)r0 * bp + c0];
-    const int t1 = bc[(int64_t)r1 * bp + c1];
-    words[r] = __ballot(t0 < t1);
+  for (int u = 0; u < kDescKP; u++) {
+    const LevelGeom& L = g->lv[level[u]];
+    const float arad = __fmul_rn(angle[u], factorPI);
+    const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
+    const u8* bc = blur + (uint64_t)f * g->frameBytes + L.off + (uint64_t)y[u] * L.pitch + x[u];
+    const int bp = L.pitch;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int p = 64 * r + lane;
+      const int pat = reinterpret_cast<const int*>(c_pattern)[p];
+      const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
+      const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+      t0[u][r] = bc[(int64_t)r0 * bp + c0];
+      t1[u][r] = bc[(int64_t)r1 * bp + c1];
+    }
   }
-  if (lane < 4) {
-    unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-    reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi) * 32)[lane] = w;
-  }
-  if (lane == 0) {
-    dvs_keypoint kp;
-    kp.x = (float)x; kp.y = (float)y;
-    if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
-    kp.size = L.kpSize;
-    kp.angle = angle;
-    kp.response = (float)pt_s(pk);
-    kp.octave = level;
-    kp.class_id = -1;
-    outKp[(uint64_t)f * capacity + gi] = kp;
+#pragma unroll
+  for (int u = 0; u < kDescKP; u++) {
+    unsigned long long words[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) words[r] = __ballot(t0[u][r] < t1[u][r]);
+    if (!valid[u]) continue;
+    const LevelGeom& L = g->lv[level[u]];
+    if (lane < 4) {
+      const unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+      reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi[u]) * 32)[lane] = w;
+    }
+    if (lane == 0) {
+      dvs_keypoint kp;
+      kp.x = (float)x[u]; kp.y = (float)y[u];
+      if (level[u] != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
+      kp.size = L.kpSize;
+      kp.angle = angle[u];
+      kp.response = (float)pt_s(pk[u]);
+      kp.octave = level[u];
+      kp.class_id = -1;
+      outKp[(uint64_t)f * capacity + gi[u]] = kp;
+    }
   }
 }
 
