@@ -201,6 +201,7 @@ def main():
     # per-kernel durations: K more steps on ONE pipeline with hipEvents around every stage launch (the events cost ~10 us
     # of stream time per stage, so they stay out of the whole-job timing above)
     orb = pipes[0]["orb"]
+    orb.set_overlap(False)          # each kernel alone on the stream: clean per-kernel durations for the roofline
     orb.enable_stage_timing(True)
     P = pipes[0]
     with torch.cuda.stream(P["stream"]):
@@ -210,6 +211,7 @@ def main():
     sync_all()
     stage_ms, stage_calls = orb.stage_times()
     orb.enable_stage_timing(False)
+    orb.set_overlap(True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,6 +225,12 @@ def main():
         total_frames = world * B * args.steps
         fps = total_frames / elapsed
         dom = max(stage_ms, key=lambda k: stage_ms[k])
+        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = int(tj["bytes_per_launch"][dom] * B / tj["batch"])
+        except Exception:
+            pass
         dom_ms = stage_ms[dom] / max(stage_calls[dom], 1)
         achieved = STAGE_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
@@ -233,10 +241,10 @@ def main():
                                    "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[1]),
                        "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
             "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
-            "stage_ms_per_step": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
+            "stage_ms_per_launch_isolated": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
             "pipelines_per_gpu": NP,
         }
         if world == 1 and not args.no_cpu_baseline:

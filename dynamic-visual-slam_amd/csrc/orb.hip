@@ -583,6 +583,13 @@ dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
   h->stream = (hipStream_t)s;  // NULL is a real stream: HIP's legacy default stream
   return DVS_OK;
 }
+dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
+  DVS_ARG(h);
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  h->overlap = on != 0;
+  return DVS_OK;
+}
 dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
   DVS_ARG(h);
   DVS_HIP(hipStreamSynchronize(h->stream));

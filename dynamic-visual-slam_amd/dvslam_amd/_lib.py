@@ -61,6 +61,7 @@ def lib():
     L.dvs_orb_set_stream.argtypes = [vp, vp]
     L.dvs_orb_get_stream.argtypes = [vp]; L.dvs_orb_get_stream.restype = vp
     L.dvs_orb_use_own_stream.argtypes = [vp]
+    L.dvs_orb_set_overlap.argtypes = [vp, i32]
     L.dvs_matcher_use_own_stream.argtypes = [vp]
     L.dvs_orb_synchronize.argtypes = [vp]
     L.dvs_orb_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -111,6 +111,9 @@ class ORBextractor:
     def set_stream(self, stream_ptr):
         check(self._L.dvs_orb_set_stream(self._h, stream_ptr))
 
+    def set_overlap(self, on):
+        check(self._L.dvs_orb_set_overlap(self._h, int(on)))
+
     # -- parity introspection (mvImagePyramid is public in the reference, ORBextractor.hpp:84) --
     def level(self, l, blurred=False, frame=0):
         rows, cols = self._shape

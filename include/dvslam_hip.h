@@ -84,6 +84,9 @@ int32_t dvs_orb_max_keypoints(const dvs_orb* h);
  * stream; NULL selects HIP's legacy default stream.  dvs_orb_use_own_stream() switches back. */
 dvs_status dvs_orb_set_stream(dvs_orb* h, void* hip_stream);
 dvs_status dvs_orb_use_own_stream(dvs_orb* h);
+/* 1 (default): independent stages overlap on an internal auxiliary stream (pyramid chain beside FAST, blur beside the quad-tree);
+ * 0: every kernel runs alone on the handle's stream — what the per-kernel roofline durations are measured with */
+dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on);
 void* dvs_orb_get_stream(dvs_orb* h);
 dvs_status dvs_orb_synchronize(dvs_orb* h);
 
