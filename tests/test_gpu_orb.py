@@ -142,3 +142,26 @@ def test_full_size_properties(gpu):
     # keypoints are distinct pixels per level
     key = np.stack([kps["octave"], kps["x"].view(np.int32), kps["y"].view(np.int32)], axis=1)
     assert len(np.unique(key, axis=0)) == n
+
+
+def test_resolution_changes_and_large_batch(gpu, oracle):
+    """one handle, changing resolutions (workspace rebuild) and a 20-frame batch through max_batch = 16"""
+    from dvslam_amd import ORBextractor
+    g = ORBextractor(400, 1.2, 6, 20, 7, max_batch=16)
+    o = oracle.OracleORB(400, 1.2, 6, 20, 7)
+    for (rows, cols) in [(480, 640), (240, 320), (480, 640), (300, 404)]:
+        img = synth.make_frame(1, cols=cols, rows=rows)
+        _assert_same_result(*g(img), *o.extract(img))
+    frames = [synth.make_frame(t, cols=640, rows=480) for t in range(20)]
+    nout, kps, desc = g.extract_batch(frames)
+    for i, fr in enumerate(frames):
+        n2, k2, d2 = o.extract(fr)
+        _assert_same_result(int(nout[i]), kps[i, :nout[i]], desc[i, :nout[i]], n2, k2, d2)
+
+
+def test_overlap_on_off_identical(gpu):
+    from dvslam_amd import ORBextractor
+    img = synth.make_frame(3)
+    a = ORBextractor(2000, 1.2, 8, 20, 7); b = ORBextractor(2000, 1.2, 8, 20, 7)
+    b.set_overlap(False)
+    _assert_same_result(*a(img), *b(img))
