@@ -165,3 +165,10 @@ def test_overlap_on_off_identical(gpu):
     a = ORBextractor(2000, 1.2, 8, 20, 7); b = ORBextractor(2000, 1.2, 8, 20, 7)
     b.set_overlap(False)
     _assert_same_result(*a(img), *b(img))
+
+
+def test_full_hd_3000_features(gpu, oracle):
+    """larger than the BASELINE configs: 1920x1080, 3000 features (more cells, bigger quad-tree quota)"""
+    img = synth.make_frame(2, cols=1920, rows=1080)
+    g, o = _pair(oracle, 3000, 8)
+    _assert_same_result(*g(img), *o.extract(img))

@@ -123,3 +123,37 @@ def test_golden_fixture_oracle(oracle):
     assert n == int(gold["n"])
     assert kps.tobytes() == gold["kps"].tobytes()
     assert (desc == gold["desc"]).all()
+
+
+def test_fast_against_independent_numpy_definition(oracle):
+    """Second, independent restatement of FAST-9/16 straight from its definition (Rosten & Drummond; score = largest
+    threshold for which the pixel still has a 9-arc, as cv::FAST's cornerScore returns), incl. 3x3 NMS with a zero border:
+    guards the oracle's transcription of OpenCV's early-exit loops."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (40, 47), dtype=np.uint8)
+    img[10:25, 12:30] = 200; img[18:35, 5:20] = 30           # some real corners besides the noise
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    H, W = img.shape
+    I = img.astype(np.int32)
+    for t in (20, 7, 60):
+        score = np.zeros((H, W), np.int32)
+        for y in range(3, H - 3):
+            for x in range(3, W - 3):
+                d = np.array([I[y, x] - I[y + dy, x + dx] for dx, dy in ring])
+                best = -1
+                for s in range(16):
+                    arc = d[[(s + i) % 16 for i in range(9)]]
+                    best = max(best, arc.min(), (-arc).min())       # darker arc: all d > thr ; brighter: all -d > thr
+                if best > t:                                         # corner at t  <=>  some arc strictly beyond t
+                    score[y, x] = best - 1
+        exp = []
+        for y in range(3, H - 3):
+            for x in range(3, W - 3):
+                s = score[y, x]
+                if s > 0:                                            # a corner at t (score >= t > 0)
+                    nb = score[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+                    if s > nb.max():                                 # strict 3x3 maximum, non-corners count as 0
+                        exp.append((x, y, s))
+        out = np.zeros((4096, 3), np.int32)
+        n = oracle.lib().orc_fast(oracle._p(img), W, H, W, t, oracle._p(out), 4096)
+        assert [tuple(r) for r in out[:n].tolist()] == exp, t
