@@ -42,11 +42,21 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   const int chunk = (nt + kSplit - 1) / kSplit;
   const int jb = min(nt, w * chunk), je = min(nt, jb + chunk);
   const u64* tp = t + (size_t)pair * tStrideRows * 4;
-  int best[kQPL], bi[kQPL];
+  // running best as ONE word: distance << 23 | train index (nt < 2^23, checked on the host) -> a single v_min_u32 per pair
+  // keeps the smallest distance and, on ties, the lowest index; the eight popcounts chain through v_bcnt's accumulator.
+  unsigned bestp[kQPL];
 #pragma unroll
-  for (int u = 0; u < kQPL; u++) { best[u] = INT_MAX; bi[u] = -1; }
-  auto dist = [&](int u, const u64* r) -> int {
-    return __popcll(a[u][0] ^ r[0]) + __popcll(a[u][1] ^ r[1]) + __popcll(a[u][2] ^ r[2]) + __popcll(a[u][3] ^ r[3]);
+  for (int u = 0; u < kQPL; u++) bestp[u] = 0xFFFFFFFFu;
+  auto dist = [&](int u, const u64* r) -> unsigned {
+    unsigned d = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 x = a[u][k] ^ r[k];
+      // v_bcnt_u32_b32 d, x, d : popcount with accumulate (hipcc otherwise emits separate v_add3 trees)
+      asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"((unsigned)x));
+      asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"((unsigned)(x >> 32)));
+    }
+    return d;
   };
   int j = jb;
   if (j + 4 <= je) {  // software pipeline: the scalar loads of trip i+1 are issued before the popcounts of trip i
@@ -64,10 +74,7 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
 #pragma unroll
       for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int u = 0; u < kQPL; u++) {
-          const int d = dist(u, &rr[4 * k]);
-          if (d < best[u]) { best[u] = d; bi[u] = j + k; }
-        }
+        for (int u = 0; u < kQPL; u++) bestp[u] = min(bestp[u], (dist(u, &rr[4 * k]) << 23) | (unsigned)(j + k));
 #pragma unroll
       for (int k = 0; k < 16; k++) rr[k] = nx[k];
     }
@@ -75,10 +82,13 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   for (; j < je; j++) {
     const u64* r = tp + (size_t)j * 4;
 #pragma unroll
-    for (int u = 0; u < kQPL; u++) {
-      const int d = dist(u, r);
-      if (d < best[u]) { best[u] = d; bi[u] = j; }
-    }
+    for (int u = 0; u < kQPL; u++) bestp[u] = min(bestp[u], (dist(u, r) << 23) | (unsigned)j);
+  }
+  int best[kQPL], bi[kQPL];
+#pragma unroll
+  for (int u = 0; u < kQPL; u++) {
+    best[u] = bestp[u] == 0xFFFFFFFFu ? INT_MAX : (int)(bestp[u] >> 23);
+    bi[u] = bestp[u] == 0xFFFFFFFFu ? -1 : (int)(bestp[u] & 0x7FFFFFu);
   }
 #pragma unroll
   for (int u = 0; u < kQPL; u++) { sd[w][u * 64 + lane] = best[u]; si[w][u * 64 + lane] = bi[u]; }
@@ -266,6 +276,7 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
                                           const uint8_t* d_t, const int32_t* d_nt, int32_t t_stride_rows, int32_t npairs,
                                           int32_t* d_idx, int32_t* d_dist) {
   DVS_ARG(m && d_q && d_t && d_nq && d_nt && d_idx && d_dist && npairs >= 0 && q_stride_rows > 0 && t_stride_rows >= 0);
+  DVS_ARG(t_stride_rows < (1 << 23));  // k_match packs the train index into 23 bits
   if (npairs == 0) return DVS_OK;
   DVS_HIP(hipSetDevice(m->device));
   dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
@@ -280,6 +291,7 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
   DVS_ARG(m && nq >= 0 && nt >= 0);
   if (nq == 0) return DVS_OK;  // empty query -> empty result
   DVS_ARG(q && train_idx && dist && (t || nt == 0));
+  DVS_ARG(nt < (1 << 23));  // k_match packs the train index into 23 bits
   DVS_HIP(hipSetDevice(m->device));
   DVS_TRY(grow(&m->d_q, &m->cq, (size_t)nq * 32));
   DVS_TRY(grow(&m->d_t, &m->ct, (size_t)std::max(nt, 1) * 32));
