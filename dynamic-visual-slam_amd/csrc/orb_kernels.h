@@ -34,6 +34,19 @@ __device__ __forceinline__ const u8* level_ptr(const Geom* g, const ImgSrc& s, i
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// 24-bit multiplies, forced: hipcc lowers __umul24/__mul24 with a scalar or loop-invariant operand to v_mul_lo_u32 (+ v_add3),
+// and the full 32-bit multiplier runs at a quarter of the 24-bit rate on gfx950.  Operands here are always < 2^24.
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mul_i24(int a, int b) {
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -161,7 +174,8 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
       const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
       const int h0 = (int)(pa & 0xff) * a0 + (int)((pa >> 8) & 0xff) * a1;
       const int h1 = (int)(pb & 0xff) * a0 + (int)((pb >> 8) & 0xff) * a1;
-      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      // |b| <= 2048, h >> 4 <= 32 640: 24-bit multiplier
+      const int v = (((mul_i24(b0, h0 >> 4)) >> 16) + ((mul_i24(b1, h1 >> 4)) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xff) << (8 * i);
     }
     // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
@@ -461,24 +475,37 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
 // ---------------------------------------------------------------------------------------------
 template <int P>
 __device__ __forceinline__ int fast_corner_score_p(const u8* c, int v) {
+  // cornerScore<16> on the RAW ring samples r_k (no per-sample subtraction): with d_k = v - r_k,
+  //   max over 9-arcs of min(d)  = v - min over arcs of max(r)   and   max over arcs of min(-d) = max over arcs of min(r) - v,
+  // so score = max(v - min_k hi9_k, max_k lo9_k - v) - 1 where hi9 / lo9 are the 9-window max / min (3 + 3 + 3 by v_max3 / v_min3).
   const int o[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,  -P + 3,  -2 * P + 2,  -3 * P + 1,
                      -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3,   2 * P - 2,   3 * P - 1};
-  int d[16];
+  int r[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - (int)c[o[k]];
+  for (int k = 0; k < 16; k++) r[k] = (int)c[o[k]];
   int lo3[16], hi3[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    lo3[k] = min(min(r[k], r[(k + 1) & 15]), r[(k + 2) & 15]);
+    hi3[k] = max(max(r[k], r[(k + 1) & 15]), r[(k + 2) & 15]);
   }
-  int A = -1000, B = 1000;
+  int lo9[16], hi9[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    A = max(A, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));
-    B = min(B, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));
+    lo9[k] = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+    hi9[k] = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
   }
-  return max(A, -B) - 1;
+  // 16 -> 1 by 3-operand trees
+  int mn[6], mx[6];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    mn[k] = min(min(hi9[3 * k], hi9[3 * k + 1]), hi9[3 * k + 2]);
+    mx[k] = max(max(lo9[3 * k], lo9[3 * k + 1]), lo9[3 * k + 2]);
+  }
+  mn[5] = hi9[15]; mx[5] = lo9[15];
+  const int minHi = min(min(min(mn[0], mn[1]), mn[2]), min(min(mn[3], mn[4]), mn[5]));
+  const int maxLo = max(max(max(mx[0], mx[1]), mx[2]), max(max(mx[3], mx[4]), mx[5]));
+  return max(v - minHi, maxLo - v) - 1;
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -578,7 +605,10 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       pass[3] = valid && col0 + 3 >= cx0 && col0 + 3 < cx1 && (sgn[1] & 0x80000000u);
     }
     const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
-    int pos = nwork + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+    auto below = [](unsigned long long b) -> int {  // set bits of b in lanes below this one: v_mbcnt_lo + v_mbcnt_hi
+      return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    };
+    int pos = nwork + below(b0) + below(b1) + below(b2) + below(b3);
     const int cbase = y * P + wcol * 4;
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1144,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
           for (int j = 0; j < 4; j++) {
             uint32_t acc = 32768u;
 #pragma unroll
-            for (int i = 0; i < 7; i++) acc = __umul24(ring[(kk + 1 + i) % 7][j], kv[i]) + acc;  // row k-6+i, weight i
+            for (int i = 0; i < 7; i++) acc = mad_u24(ring[(kk + 1 + i) % 7][j], kv[i], acc);  // row k-6+i, weight i
             o |= ((acc >> 16) & 0xffu) << (8 * j);
           }
           u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
