@@ -249,10 +249,11 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
           mn = std::min(mn, xofs[L.xtab + x]);
         }
         rg.base = mn & ~3;
+        rg.shift = (uint32_t)(mn & 3) * 8;
         for (int i = 0; i < 4; i++) {
-          const int o = xofs[L.xtab + cols4[i]] - rg.base;
-          if (o < 0 || o > 7) fits = false;  // both taps must lie inside the 12-byte window handled by k_resize4
-          rg.offs |= (uint32_t)(o & 15) << (4 * i);
+          const int o = xofs[L.xtab + cols4[i]] - mn;  // both taps (o, o + 1) must lie inside the 8-byte window
+          if (o < 0 || o > 6) fits = false;
+          rg.sel[i] = (uint32_t)o | (0x0cu << 8) | ((uint32_t)(o + 1) << 16) | (0x0cu << 24);
           rg.alpha[i] = alpha[L.xtab + cols4[i]];
         }
         rgroups.push_back(rg);

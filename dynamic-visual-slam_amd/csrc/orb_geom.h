@@ -66,9 +66,10 @@ struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
 
 struct BlurTile { int16_t level, tx, ty, pad; };
 
-// resize: one entry per group of 4 output columns — aligned source byte `base`, 4-bit offsets of the four left taps
-// relative to base (each <= 7, right tap = +1), and the Q11 coefficient pairs (a0 | a1 << 16)
-struct ResizeGroup { int32_t base; uint32_t offs; int32_t alpha[4]; };
+// resize: one entry per group of 4 output columns — dword-aligned source byte `base`, bit shift that moves the group's first
+// tap to byte 0 of an 8-byte window, one v_perm selector per column that places (left tap, right tap) into the two 16-bit
+// halves, and the Q11 coefficient pairs (a0 | a1 << 16) for v_dot2_u32_u16
+struct ResizeGroup { int32_t base; uint32_t shift; uint32_t sel[4]; int32_t alpha[4]; };
 
 // streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
 constexpr int kBlurBand = 64;

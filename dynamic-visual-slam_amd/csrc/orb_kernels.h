@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void k_resize(const u8* __restrict__ src, uint
 }
 
 // Same arithmetic, 4 output pixels per thread from TWO 12-byte source windows (dword loads) instead of 16 byte
-// gathers: the 4 left taps of a group lie within 8 bytes of the aligned `base` (scale <= 2), the right tap is the next
-// byte, and whenever the reference clamps the right tap (last column) its coefficient is 0.
+// gathers: v_alignbit moves the group's first tap to byte 0 of an 8-byte window (all 8 taps of the group lie inside it for
+// scale factors < 1.5), then per pixel ONE v_perm picks (left, right) into 16-bit halves and ONE v_dot2_u32_u16 applies the
+// Q11 pair.  Whenever the reference clamps the right tap (last column) its coefficient is 0, so its byte is irrelevant.
 constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x kResizeRows independent 12-byte windows in flight
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
@@ -158,22 +159,21 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
       }
     }
   }
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int r = 0; r < kResizeRows; r++) {
     if (y0 + r >= dh) break;
     const int b0 = (int)(short)(bb[r] & 0xffff), b1 = bb[r] >> 16;
+    // 8-byte window starting at the group's first tap
+    const uint32_t lo0 = __builtin_amdgcn_alignbit(w0[r][1], w0[r][0], t.shift), hi0 = __builtin_amdgcn_alignbit(w0[r][2], w0[r][1], t.shift);
+    const uint32_t lo1 = __builtin_amdgcn_alignbit(w1[r][1], w1[r][0], t.shift), hi1 = __builtin_amdgcn_alignbit(w1[r][2], w1[r][1], t.shift);
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int o = (int)((t.offs >> (4 * i)) & 15u);
-      const bool hi = o >= 4;
-      const uint32_t sh8 = (uint32_t)(o & 3) * 8u;
-      const uint32_t pa = __builtin_amdgcn_alignbit(hi ? w0[r][2] : w0[r][1], hi ? w0[r][1] : w0[r][0], sh8);
-      const uint32_t pb = __builtin_amdgcn_alignbit(hi ? w1[r][2] : w1[r][1], hi ? w1[r][1] : w1[r][0], sh8);
-      const int a = t.alpha[i];
-      const int a0 = (int)(short)(a & 0xffff), a1 = a >> 16;
-      const int h0 = (int)(pa & 0xff) * a0 + (int)((pa >> 8) & 0xff) * a1;
-      const int h1 = (int)(pb & 0xff) * a0 + (int)((pb >> 8) & 0xff) * a1;
+      // (left tap, right tap) as two u16 halves, then a0 * left + a1 * right in one v_dot2_u32_u16
+      const us2 al = __builtin_bit_cast(us2, t.alpha[i]);
+      const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), al, 0u, false);
+      const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), al, 0u, false);
       // |b| <= 2048, h >> 4 <= 32 640: 24-bit multiplier
       const int v = (((mul_i24(b0, h0 >> 4)) >> 16) + ((mul_i24(b1, h1 >> 4)) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xff) << (8 * i);
