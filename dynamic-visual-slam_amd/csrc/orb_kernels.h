@@ -1133,7 +1133,10 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
     sy = sy >= H ? 2 * H - 2 - sy : sy;
     return *reinterpret_cast<const uint32_t*>(img + (uint64_t)sy * pitch + xl);
   };
-  uint32_t ring[7][4];
+  typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+  const us2v k01 = {(unsigned short)kv[0], (unsigned short)kv[1]}, k23 = {(unsigned short)kv[2], (unsigned short)kv[3]},
+             k45 = {(unsigned short)kv[4], (unsigned short)kv[5]};
+  uint32_t ring[7][4], hprev[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int a = 0; a < 7; a++)
 #pragma unroll
@@ -1164,17 +1167,23 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
                        a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
         const uint32_t b0 = __builtin_amdgcn_alignbyte(right, own, 1), b1 = __builtin_amdgcn_alignbyte(right, own, 2),
                        b2 = __builtin_amdgcn_alignbyte(right, own, 3), b3 = right;
-        ring[kk][0] = __builtin_amdgcn_udot4(b0, w1, __builtin_amdgcn_udot4(a0, w0, 0u, false), false);
-        ring[kk][1] = __builtin_amdgcn_udot4(b1, w1, __builtin_amdgcn_udot4(a1, w0, 0u, false), false);
-        ring[kk][2] = __builtin_amdgcn_udot4(b2, w1, __builtin_amdgcn_udot4(a2, w0, 0u, false), false);
-        ring[kk][3] = __builtin_amdgcn_udot4(b3, w1, __builtin_amdgcn_udot4(a3, w0, 0u, false), false);
+        uint32_t hc[4];
+        hc[0] = __builtin_amdgcn_udot4(b0, w1, __builtin_amdgcn_udot4(a0, w0, 0u, false), false);
+        hc[1] = __builtin_amdgcn_udot4(b1, w1, __builtin_amdgcn_udot4(a1, w0, 0u, false), false);
+        hc[2] = __builtin_amdgcn_udot4(b2, w1, __builtin_amdgcn_udot4(a2, w0, 0u, false), false);
+        hc[3] = __builtin_amdgcn_udot4(b3, w1, __builtin_amdgcn_udot4(a3, w0, 0u, false), false);
+        // ring slot kk holds the PAIR (row k-1, row k) of horizontal sums as two u16 halves: the 7-tap column filter is then
+        // three v_dot2_u32_u16 on the pairs formed at rows k-5, k-3, k-1 plus one multiply-add for row k
+#pragma unroll
+        for (int j = 0; j < 4; j++) { ring[kk][j] = hprev[j] | (hc[j] << 16); hprev[j] = hc[j]; }
         if (k >= 6 && outl) {
           uint32_t o = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            uint32_t acc = 32768u;
-#pragma unroll
-            for (int i = 0; i < 7; i++) acc = mad_u24(ring[(kk + 1 + i) % 7][j], kv[i], acc);  // row k-6+i, weight i
+            uint32_t acc = mad_u24(hc[j], kv[6], 32768u);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 2) % 7][j]), k01, acc, false);  // rows k-6, k-5
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 4) % 7][j]), k23, acc, false);  // rows k-4, k-3
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 6) % 7][j]), k45, acc, false);  // rows k-2, k-1
             o |= ((acc >> 16) & 0xffu) << (8 * j);
           }
           u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
