@@ -1226,126 +1226,119 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// Two keypoints per wavefront, addressed by their fixed (level, index) slot in the per-level keypoint block, so the first
-// memory round trip fetches the level counts, both packed keypoints and the weight tables together; the orientation
-// loads of both keypoints are then in flight at once, and so are their 16 descriptor gathers.  (With one keypoint per wave
-// and the level looked up from the counts first, the kernel was a chain of 4-5 dependent round trips: 26 % VALU busy.)
-constexpr int kDescKP = 2;
+// One wavefront per keypoint slot (fixed (level, index) slots of the per-level keypoint block).  The 512 BRIEF samples are
+// NOT gathered from HBM/L2: a fully divergent byte gather costs the CU's texture-address unit one cache line per lane, and 8
+// of them per keypoint is what bound the first version.  Instead the 37 x 37 blurred window (every sample lies within +-18 px
+// of the keypoint) is staged into LDS with two coalesced 16-byte-per-lane loads (3 lanes per row), and the samples are LDS
+// byte reads.  The orientation patch is one unaligned 16-byte load per lane (lane = 2*row + half).
+constexpr int kDescKP = 1;
+constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinPitch = 48;
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
                                                   const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
                                                   int* __restrict__ nOut, int capacity) {
-  typedef uint32_t __attribute__((aligned(1))) u32u;
+  typedef uint4 __attribute__((aligned(1))) uint4u;
+  __shared__ __attribute__((aligned(16))) u8 win[4][kWinRows * kWinPitch];
   const int f = blockIdx.y;
   const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
-  const int slot0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kDescKP;
+  const int slot = blockIdx.x * 4 + wv;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int total = 0;
     for (int l = 0; l < nl; l++) total += cnt[l];
     nOut[f] = min(total, capacity);
   }
-  if (slot0 >= g->kpBlock) return;
-  // slot -> (level, index in level, output position); all wave-uniform
-  int level[kDescKP], gi[kDescKP];
-  bool valid[kDescKP];
-  uint32_t pk[kDescKP];
-#pragma unroll
-  for (int u = 0; u < kDescKP; u++) {
-    const int slot = slot0 + u;
-    int lv = 0, pre = 0, acc = 0;
-    for (int l = 0; l < nl; l++) {
-      if (slot >= g->lv[l].kpOff) { lv = l; pre = acc; }
-      acc += cnt[l];
-    }
-    const int idx = slot - g->lv[lv].kpOff;
-    level[u] = lv;
-    gi[u] = pre + idx;
-    valid[u] = slot < g->kpBlock && idx < cnt[lv] && gi[u] < capacity;
-    pk[u] = lvlKp[(uint64_t)f * g->kpBlock + min(slot, g->kpBlock - 1)];
+  if (slot >= g->kpBlock) return;
+  // slot -> (level, index in level, output position); wave-uniform, independent of the keypoint load below
+  int level = 0, pre = 0, acc = 0;
+  for (int l = 0; l < nl; l++) {
+    if (slot >= g->lv[l].kpOff) { level = l; pre = acc; }
+    acc += cnt[l];
   }
-  if (!valid[0] && !valid[1]) return;
+  const LevelGeom& L = g->lv[level];
+  const int idx = slot - L.kpOff;
+  const int gi = pre + idx;
+  const uint32_t pk = lvlKp[(uint64_t)f * g->kpBlock + slot];
+  if (idx >= cnt[level] || gi >= capacity) return;
+  const int x = pt_x(pk) + kMinBorder, y = pt_y(pk) + kMinBorder;  // level pixel coordinates (:886-887)
+  int pitch;
+  const u8* img = level_ptr(g, src, f, level, pitch);
+  // requests: orientation patch (unblurred level) and the blurred window, all issued before anything is consumed
+  const int prow = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
+  const int v = prow - kHalfPatch;
+  const uint4 d = *reinterpret_cast<const uint4u*>(img + (int64_t)(y + v) * pitch + x + (half ? 1 : -kHalfPatch));
+  const u8* bbase = blur + (uint64_t)f * g->frameBytes + L.off;
+  const int bp = L.pitch;
+  const int xa = (x - kWinR) & ~3;          // dword-aligned window origin; 48 bytes per row cover x-18 .. x+18
+  const int wx = x - xa;                     // column of the keypoint inside the window
+  uint4 wq[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int e = h * 64 + lane;             // 111 = 37 rows x 3 sixteen-byte pieces
+    const int r = e / 3, c = e - 3 * r;
+    wq[h] = e < kWinRows * 3 ? *reinterpret_cast<const uint4*>(bbase + (int64_t)(y - kWinR + r) * bp + xa + 16 * c) : make_uint4(0, 0, 0, 0);
+  }
   const uint32_t* wt = g->icw[lane];
-  const uint32_t w8[8] = {wt[0], wt[1], wt[2], wt[3], wt[4], wt[5], wt[6], wt[7]};
-  const int row = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
-  const int v = row - kHalfPatch;
-  int x[kDescKP], y[kDescKP], pitch[kDescKP];
-  uint32_t d[kDescKP][4];
+  // IC_Angle (ORBextractor.cpp:76-103): membership and the u weights are per-lane byte tables (Geom::icw):
+  // sum u*I = sum (u+15)*I - 15 * sum I, exact integers
+  uint32_t su = __builtin_amdgcn_udot4(d.x, wt[0], 0u, false);
+  su = __builtin_amdgcn_udot4(d.y, wt[1], su, false);
+  su = __builtin_amdgcn_udot4(d.z, wt[2], su, false);
+  su = __builtin_amdgcn_udot4(d.w, wt[3], su, false);
+  uint32_t sm = __builtin_amdgcn_udot4(d.x, wt[4], 0u, false);
+  sm = __builtin_amdgcn_udot4(d.y, wt[5], sm, false);
+  sm = __builtin_amdgcn_udot4(d.z, wt[6], sm, false);
+  sm = __builtin_amdgcn_udot4(d.w, wt[7], sm, false);
+  int m10 = (int)su - kHalfPatch * (int)sm;
+  int m01 = v * (int)sm;
 #pragma unroll
-  for (int u = 0; u < kDescKP; u++) {
-    x[u] = pt_x(pk[u]) + kMinBorder; y[u] = pt_y(pk[u]) + kMinBorder;  // level pixel coordinates (:886-887)
-    if (!valid[u]) { x[u] = kEdge; y[u] = kEdge; }                       // harmless in-bounds dummy
-    const u8* img = level_ptr(g, src, f, level[u], pitch[u]);
-    // IC_Angle (ORBextractor.cpp:76-103): lane = 2*row + half owns 16 bytes of one patch row
-    const u8* p = img + (int64_t)(y[u] + v) * pitch[u] + x[u] + (half ? 1 : -kHalfPatch);
-    d[u][0] = *reinterpret_cast<const u32u*>(p); d[u][1] = *reinterpret_cast<const u32u*>(p + 4);
-    d[u][2] = *reinterpret_cast<const u32u*>(p + 8); d[u][3] = *reinterpret_cast<const u32u*>(p + 12);
+  for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // window -> LDS
+  u8* wl = win[wv];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int e = h * 64 + lane;
+    const int r = e / 3, c = e - 3 * r;
+    if (e < kWinRows * 3) *reinterpret_cast<uint4*>(wl + r * kWinPitch + 16 * c) = wq[h];
   }
-  float angle[kDescKP];
-#pragma unroll
-  for (int u = 0; u < kDescKP; u++) {
-    // membership and the u weights are per-lane byte tables (Geom::icw): sum u*I = sum (u+15)*I - 15 * sum I, exact integers
-    uint32_t su = __builtin_amdgcn_udot4(d[u][0], w8[0], 0u, false);
-    su = __builtin_amdgcn_udot4(d[u][1], w8[1], su, false);
-    su = __builtin_amdgcn_udot4(d[u][2], w8[2], su, false);
-    su = __builtin_amdgcn_udot4(d[u][3], w8[3], su, false);
-    uint32_t sm = __builtin_amdgcn_udot4(d[u][0], w8[4], 0u, false);
-    sm = __builtin_amdgcn_udot4(d[u][1], w8[5], sm, false);
-    sm = __builtin_amdgcn_udot4(d[u][2], w8[6], sm, false);
-    sm = __builtin_amdgcn_udot4(d[u][3], w8[7], sm, false);
-    int m10 = (int)su - kHalfPatch * (int)sm;
-    int m01 = v * (int)sm;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    angle[u] = fast_atan2_deg((float)m01, (float)m10);
-  }
+  wave_lds_fence();
   // steered BRIEF on the blurred level (:107-146)
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  int t0[kDescKP][4], t1[kDescKP][4];
+  const float arad = __fmul_rn(angle, factorPI);
+  const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
+  const u8* bc = wl + kWinR * kWinPitch + wx;
+  unsigned long long words[4];
 #pragma unroll
-  for (int u = 0; u < kDescKP; u++) {
-    const LevelGeom& L = g->lv[level[u]];
-    const float arad = __fmul_rn(angle[u], factorPI);
-    const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
-    const u8* bc = blur + (uint64_t)f * g->frameBytes + L.off + (uint64_t)y[u] * L.pitch + x[u];
-    const int bp = L.pitch;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int p = 64 * r + lane;
-      const int pat = reinterpret_cast<const int*>(c_pattern)[p];
-      const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
-      const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
-      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      t0[u][r] = bc[(int64_t)r0 * bp + c0];
-      t1[u][r] = bc[(int64_t)r1 * bp + c1];
-    }
+  for (int r = 0; r < 4; r++) {
+    const int p = 64 * r + lane;
+    const int pat = reinterpret_cast<const int*>(c_pattern)[p];
+    const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+    const int t0 = bc[r0 * kWinPitch + c0];
+    const int t1 = bc[r1 * kWinPitch + c1];
+    words[r] = __ballot(t0 < t1);
   }
-#pragma unroll
-  for (int u = 0; u < kDescKP; u++) {
-    unsigned long long words[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) words[r] = __ballot(t0[u][r] < t1[u][r]);
-    if (!valid[u]) continue;
-    const LevelGeom& L = g->lv[level[u]];
-    if (lane < 4) {
-      const unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-      reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi[u]) * 32)[lane] = w;
-    }
-    if (lane == 0) {
-      dvs_keypoint kp;
-      kp.x = (float)x[u]; kp.y = (float)y[u];
-      if (level[u] != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
-      kp.size = L.kpSize;
-      kp.angle = angle[u];
-      kp.response = (float)pt_s(pk[u]);
-      kp.octave = level[u];
-      kp.class_id = -1;
-      outKp[(uint64_t)f * capacity + gi[u]] = kp;
-    }
+  if (lane < 4) {
+    const unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+    reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi) * 32)[lane] = w;
+  }
+  if (lane == 0) {
+    dvs_keypoint kp;
+    kp.x = (float)x; kp.y = (float)y;
+    if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
+    kp.size = L.kpSize;
+    kp.angle = angle;
+    kp.response = (float)pt_s(pk);
+    kp.octave = level;
+    kp.class_id = -1;
+    outKp[(uint64_t)f * capacity + gi] = kp;
   }
 }
 
