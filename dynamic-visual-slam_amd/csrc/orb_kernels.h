@@ -34,6 +34,16 @@ __device__ __forceinline__ const u8* level_ptr(const Geom* g, const ImgSrc& s, i
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// XCD-aware work-item id (speed only): workgroups are dealt round-robin over the 8 XCDs, each with a private 4 MiB L2.  Remap
+// the linear workgroup id so that every XCD works through ONE contiguous range of work items — for the (x = piece, y = frame)
+// grids here that is a contiguous run of frames, so the lines neighbouring pieces share are fetched into one L2 once instead of
+// into eight.  Bijective for any workgroup count.
+__device__ __forceinline__ int xcd_contiguous_id() {
+  const int nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // 24-bit multiplies, forced: hipcc lowers __umul24/__mul24 with a scalar or loop-invariant operand to v_mul_lo_u32 (+ v_add3),
 // and the full 32-bit multiplier runs at a quarter of the 24-bit rate on gfx950.  Operands here are always < 2^24.
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
@@ -1226,32 +1236,40 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// One wavefront per keypoint slot (fixed (level, index) slots of the per-level keypoint block).  The 512 BRIEF samples are
-// NOT gathered from HBM/L2: a fully divergent byte gather costs the CU's texture-address unit one cache line per lane, and 8
-// of them per keypoint is what bound the first version.  Instead the 37 x 37 blurred window (every sample lies within +-18 px
-// of the keypoint) is staged into LDS with two coalesced 16-byte-per-lane loads (3 lanes per row), and the samples are LDS
-// byte reads.  The orientation patch is one unaligned 16-byte load per lane (lane = 2*row + half).
-constexpr int kDescKP = 1;
+// Eight keypoint slots per wavefront (fixed (level, index) slots of the per-level keypoint block).
+//  * slot -> (level, index, output position), the keypoint word and its addresses are resolved by lanes 0..7 in one pass and
+//    broadcast with v_readlane;
+//  * orientation: one unaligned 16-byte load per lane and keypoint (lane = 2*row + half of the 31 x 31 patch), all eight in
+//    flight together; the 16 moment sums are reduced with a transposing butterfly (17 shuffles instead of 96) that leaves
+//    keypoint k's totals in lanes 4k..4k+3, where fastAtan2 and the (double precision, glibc-exact) sin/cos run ONCE for all
+//    eight keypoints;
+//  * BRIEF: the 512 samples are NOT gathered from HBM/L2 — a fully divergent byte gather costs the CU's texture-address unit one
+//    cache line per lane.  The 37 x 37 blurred window (every sample lies within +-18 px) is staged into LDS with two coalesced
+//    16-byte-per-lane loads (3 lanes per row, next keypoint's loads issued behind the current keypoint's sampling), and the
+//    samples are LDS byte reads.  The pattern is unpacked to floats once per wave.
+constexpr int kDescKP = 8;
 constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinPitch = 48;
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
                                                   const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
                                                   int* __restrict__ nOut, int capacity) {
   typedef uint4 __attribute__((aligned(1))) uint4u;
-  __shared__ __attribute__((aligned(16))) u8 win[4][kWinRows * kWinPitch];
-  const int f = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) u8 win[4][2][kWinRows * kWinPitch];
+  const int wg = xcd_contiguous_id();
+  const int f = wg / (int)gridDim.x, bx = wg - f * (int)gridDim.x;
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
-  const int slot = blockIdx.x * 4 + wv;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  const int slot0 = (bx * 4 + wv) * kDescKP;
+  if (bx == 0 && threadIdx.x == 0) {
     int total = 0;
     for (int l = 0; l < nl; l++) total += cnt[l];
     nOut[f] = min(total, capacity);
   }
-  if (slot >= g->kpBlock) return;
-  // slot -> (level, index in level, output position); wave-uniform, independent of the keypoint load below
+  if (slot0 >= g->kpBlock) return;
+  // ---- slot resolve (lane & 7 = keypoint of the wave; lanes >= 8 repeat lanes 0..7)
+  const int slot = min(slot0 + (lane & 7), g->kpBlock - 1);
   int level = 0, pre = 0, acc = 0;
   for (int l = 0; l < nl; l++) {
     if (slot >= g->lv[l].kpOff) { level = l; pre = acc; }
@@ -1260,76 +1278,129 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const LevelGeom& L = g->lv[level];
   const int idx = slot - L.kpOff;
   const int gi = pre + idx;
-  const uint32_t pk = lvlKp[(uint64_t)f * g->kpBlock + slot];
-  if (idx >= cnt[level] || gi >= capacity) return;
-  const int x = pt_x(pk) + kMinBorder, y = pt_y(pk) + kMinBorder;  // level pixel coordinates (:886-887)
-  int pitch;
-  const u8* img = level_ptr(g, src, f, level, pitch);
-  // requests: orientation patch (unblurred level) and the blurred window, all issued before anything is consumed
+  const bool valid = slot0 + (lane & 7) < g->kpBlock && idx < cnt[level] && gi < capacity;
+  if ((__ballot(valid) & 0xffull) == 0) return;
+  const uint32_t pk = valid ? lvlKp[(uint64_t)f * g->kpBlock + slot] : 0u;
+  // an empty slot reads the patch of (level 0, first legal position): in bounds, result discarded
+  const int lvl = valid ? level : 0;
+  const int x = pt_x(pk) + kMinBorder + (valid ? 0 : 3), y = pt_y(pk) + kMinBorder + (valid ? 0 : 3);  // level pixels (:886-887)
+  const uint64_t pyrOff = (uint64_t)f * g->frameBytes + g->lv[lvl].off;
+  const u8* imgL = lvl == 0 ? src.img0 + (uint64_t)f * src.fstride0 : src.pyr + pyrOff;
+  const int pitchL = lvl == 0 ? (int)src.step0 : g->lv[lvl].pitch;
+  const u8* blurL = blur + pyrOff;
+  const int bpL = g->lv[lvl].pitch;
+#define DVS_RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+#define DVS_RLP(p, i) reinterpret_cast<const u8*>(((uint64_t)(uint32_t)DVS_RL((uint32_t)((uint64_t)(p) >> 32), i) << 32) | (uint32_t)DVS_RL((uint32_t)(uint64_t)(p), i))
+  // ---- orientation patches, all eight requested before any is consumed
   const int prow = min(lane >> 1, 2 * kHalfPatch), half = lane & 1;
   const int v = prow - kHalfPatch;
-  const uint4 d = *reinterpret_cast<const uint4u*>(img + (int64_t)(y + v) * pitch + x + (half ? 1 : -kHalfPatch));
-  const u8* bbase = blur + (uint64_t)f * g->frameBytes + L.off;
-  const int bp = L.pitch;
-  const int xa = (x - kWinR) & ~3;          // dword-aligned window origin; 48 bytes per row cover x-18 .. x+18
-  const int wx = x - xa;                     // column of the keypoint inside the window
-  uint4 wq[2];
+  const int pcol = half ? 1 : -kHalfPatch;
+  uint4 d[kDescKP];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int e = h * 64 + lane;             // 111 = 37 rows x 3 sixteen-byte pieces
-    const int r = e / 3, c = e - 3 * r;
-    wq[h] = e < kWinRows * 3 ? *reinterpret_cast<const uint4*>(bbase + (int64_t)(y - kWinR + r) * bp + xa + 16 * c) : make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < kDescKP; i++) {
+    const u8* ib = DVS_RLP(imgL, i);
+    const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
+    d[i] = *reinterpret_cast<const uint4u*>(ib + (int64_t)(yi + v) * pi + xi + pcol);
   }
-  const uint32_t* wt = g->icw[lane];
-  // IC_Angle (ORBextractor.cpp:76-103): membership and the u weights are per-lane byte tables (Geom::icw):
-  // sum u*I = sum (u+15)*I - 15 * sum I, exact integers
-  uint32_t su = __builtin_amdgcn_udot4(d.x, wt[0], 0u, false);
-  su = __builtin_amdgcn_udot4(d.y, wt[1], su, false);
-  su = __builtin_amdgcn_udot4(d.z, wt[2], su, false);
-  su = __builtin_amdgcn_udot4(d.w, wt[3], su, false);
-  uint32_t sm = __builtin_amdgcn_udot4(d.x, wt[4], 0u, false);
-  sm = __builtin_amdgcn_udot4(d.y, wt[5], sm, false);
-  sm = __builtin_amdgcn_udot4(d.z, wt[6], sm, false);
-  sm = __builtin_amdgcn_udot4(d.w, wt[7], sm, false);
-  int m10 = (int)su - kHalfPatch * (int)sm;
-  int m01 = v * (int)sm;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // window -> LDS
-  u8* wl = win[wv];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int e = h * 64 + lane;
-    const int r = e / 3, c = e - 3 * r;
-    if (e < kWinRows * 3) *reinterpret_cast<uint4*>(wl + r * kWinPitch + 16 * c) = wq[h];
-  }
-  wave_lds_fence();
-  // steered BRIEF on the blurred level (:107-146)
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float arad = __fmul_rn(angle, factorPI);
-  const float a = gsc::cosf_(arad), b = gsc::sinf_(arad);
-  const u8* bc = wl + kWinR * kWinPitch + wx;
-  unsigned long long words[4];
+  // blurred window of keypoint 0
+  const int e0 = lane, e1 = 64 + lane;  // 111 = 37 rows x 3 sixteen-byte pieces
+  const int wr0 = e0 / 3, wc0 = e0 - 3 * wr0, wr1 = min(e1 / 3, kWinRows - 1), wc1 = e1 - 3 * (e1 / 3);
+  const bool w1ok = e1 < kWinRows * 3;
+  uint4 wq0, wq1;
+  int wx;
+  auto request_window = [&](int i) {
+    const u8* bb = DVS_RLP(blurL, i);
+    const int bp = DVS_RL(bpL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
+    const int xa = (xi - kWinR) & ~3;  // dword-aligned window origin; 48 bytes per row cover x-18 .. x+18
+    wx = xi - xa;
+    const u8* o = bb + (int64_t)(yi - kWinR) * bp + xa;
+    wq0 = *reinterpret_cast<const uint4*>(o + wr0 * bp + 16 * wc0);
+    wq1 = *reinterpret_cast<const uint4*>(o + wr1 * bp + 16 * wc1);
+  };
+  // pattern -> floats, once per wave
+  float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int p = 64 * r + lane;
-    const int pat = reinterpret_cast<const int*>(c_pattern)[p];
-    const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)((pat >> 24) & 0xff);
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bc[r0 * kWinPitch + c0];
-    const int t1 = bc[r1 * kWinPitch + c1];
-    words[r] = __ballot(t0 < t1);
+    const int pat = reinterpret_cast<const int*>(c_pattern)[64 * r + lane];
+    px0[r] = (float)(int8_t)(pat & 0xff); py0[r] = (float)(int8_t)((pat >> 8) & 0xff);
+    px1[r] = (float)(int8_t)((pat >> 16) & 0xff); py1[r] = (float)(int8_t)((pat >> 24) & 0xff);
   }
-  if (lane < 4) {
-    const unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-    reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gi) * 32)[lane] = w;
+  // ---- IC_Angle (ORBextractor.cpp:76-103): membership and the u weights are per-lane byte tables (Geom::icw):
+  // sum u*I = sum (u+15)*I - 15 * sum I, exact integers
+  const uint32_t* wt = g->icw[lane];
+  const uint32_t w0 = wt[0], w1 = wt[1], w2 = wt[2], w3 = wt[3], w4 = wt[4], w5 = wt[5], w6 = wt[6], w7 = wt[7];
+  int q[2 * kDescKP];  // [i] = m10 of keypoint i, [8 + i] = m01
+#pragma unroll
+  for (int i = 0; i < kDescKP; i++) {
+    uint32_t su = __builtin_amdgcn_udot4(d[i].x, w0, 0u, false);
+    su = __builtin_amdgcn_udot4(d[i].y, w1, su, false);
+    su = __builtin_amdgcn_udot4(d[i].z, w2, su, false);
+    su = __builtin_amdgcn_udot4(d[i].w, w3, su, false);
+    uint32_t sm = __builtin_amdgcn_udot4(d[i].x, w4, 0u, false);
+    sm = __builtin_amdgcn_udot4(d[i].y, w5, sm, false);
+    sm = __builtin_amdgcn_udot4(d[i].z, w6, sm, false);
+    sm = __builtin_amdgcn_udot4(d[i].w, w7, sm, false);
+    q[i] = (int)su - kHalfPatch * (int)sm;
+    q[kDescKP + i] = v * (int)sm;
   }
-  if (lane == 0) {
+  request_window(0);
+  // transposing butterfly: after the step with lane bit B, a lane keeps the half of the quantities selected by its bit B
+#pragma unroll
+  for (int n = kDescKP, o = 32; n >= 1; n >>= 1, o >>= 1) {
+    const bool hi = (lane & o) != 0;
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+      const int keep = hi ? q[n + j] : q[j];
+      const int send = hi ? q[j] : q[n + j];
+      q[j] = keep + __shfl_xor(send, o);
+    }
+  }
+  int tot = q[0];
+  tot += __shfl_xor(tot, 2);
+  tot += __shfl_xor(tot, 1);
+  // lane bits 5 | 4 3 2 = (m01 ? : m10) | keypoint index bits 2 1 0  (bit 4 chose between i and i+4, bit 3 i and i+2, bit 2 i and i+1)
+  const int other = __shfl_xor(tot, 32);
+  const int m10 = lane < 32 ? tot : other, m01 = lane < 32 ? other : tot;
+  const float angleK = fast_atan2_deg((float)m01, (float)m10);  // keypoint (lane >> 2) & 7
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float arad = __fmul_rn(angleK, factorPI);
+  const float cosK = gsc::cosf_(arad), sinK = gsc::sinf_(arad);
+  // ---- steered BRIEF on the blurred level (:107-146), one keypoint after the other
+  const unsigned vmask = (unsigned)(__ballot(valid) & 0xffull);
+  const int giL = gi;
+#pragma unroll
+  for (int i = 0; i < kDescKP; i++) {
+    u8* wl = win[wv][i & 1];
+    *reinterpret_cast<uint4*>(wl + wr0 * kWinPitch + 16 * wc0) = wq0;
+    if (w1ok) *reinterpret_cast<uint4*>(wl + wr1 * kWinPitch + 16 * wc1) = wq1;
+    const int wxi = wx;
+    wave_lds_fence();
+    if (i + 1 < kDescKP) request_window(i + 1);
+    const float a = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, cosK), 4 * i));
+    const float b = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, sinK), 4 * i));
+    const u8* bc = wl + kWinR * kWinPitch + wxi;
+    unsigned long long words[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
+      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
+      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
+      const int t0 = bc[r0 * kWinPitch + c0];
+      const int t1 = bc[r1 * kWinPitch + c1];
+      words[r] = __ballot(t0 < t1);
+    }
+    if ((vmask >> i) & 1u) {
+      const int gii = DVS_RL(giL, i);
+      if (lane < 4) {
+        const unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gii) * 32)[lane] = w;
+      }
+    }
+  }
+  // ---- keypoints: lane i < 8 writes keypoint i; its angle lives in lane 4 * i
+  const float angle = __shfl(angleK, 4 * (lane & 7));
+  if (lane < kDescKP && valid) {
     dvs_keypoint kp;
     kp.x = (float)x; kp.y = (float)y;
     if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }  // pt *= scale (:1148-1150)
@@ -1340,6 +1411,8 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     kp.class_id = -1;
     outKp[(uint64_t)f * capacity + gi] = kp;
   }
+#undef DVS_RL
+#undef DVS_RLP
 }
 
 }  // namespace dvs
