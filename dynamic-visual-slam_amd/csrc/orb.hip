@@ -503,7 +503,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
   // 5. orientation + descriptors + output records
   h->timer.begin(DVS_STAGE_DESCRIBE, st);
-  hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp,
+  hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), (getenv("DVS_DESC_PAD") ? atoi(getenv("DVS_DESC_PAD")) : 0), st, h->d_geom, src, h->d_blur, h->d_lvlkp,
                      h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
   h->timer.end(st);
   DVS_HIP(hipGetLastError());

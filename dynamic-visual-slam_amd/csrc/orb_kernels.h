@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   if (slot0 >= g->kpBlock) return;
   // ---- slot resolve (lane & 7 = keypoint of the wave; lanes >= 8 repeat lanes 0..7)
   const int slot = min(slot0 + (lane & 7), g->kpBlock - 1);
+  const uint32_t pkRaw = lvlKp[(uint64_t)f * g->kpBlock + slot];  // requested before the counts it is validated against
   int level = 0, pre = 0, acc = 0;
   for (int l = 0; l < nl; l++) {
     if (slot >= g->lv[l].kpOff) { level = l; pre = acc; }
@@ -1280,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int gi = pre + idx;
   const bool valid = slot0 + (lane & 7) < g->kpBlock && idx < cnt[level] && gi < capacity;
   if ((__ballot(valid) & 0xffull) == 0) return;
-  const uint32_t pk = valid ? lvlKp[(uint64_t)f * g->kpBlock + slot] : 0u;
+  const uint32_t pk = valid ? pkRaw : 0u;
   // an empty slot reads the patch of (level 0, first legal position): in bounds, result discarded
   const int lvl = valid ? level : 0;
   const int x = pt_x(pk) + kMinBorder + (valid ? 0 : 3), y = pt_y(pk) + kMinBorder + (valid ? 0 : 3);  // level pixels (:886-887)
@@ -1306,17 +1307,20 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int e0 = lane, e1 = 64 + lane;  // 111 = 37 rows x 3 sixteen-byte pieces
   const int wr0 = e0 / 3, wc0 = e0 - 3 * wr0, wr1 = min(e1 / 3, kWinRows - 1), wc1 = e1 - 3 * (e1 / 3);
   const bool w1ok = e1 < kWinRows * 3;
-  uint4 wq0, wq1;
-  int wx;
-  auto request_window = [&](int i) {
-    const u8* bb = DVS_RLP(blurL, i);
-    const int bp = DVS_RL(bpL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
-    const int xa = (xi - kWinR) & ~3;  // dword-aligned window origin; 48 bytes per row cover x-18 .. x+18
-    wx = xi - xa;
-    const u8* o = bb + (int64_t)(yi - kWinR) * bp + xa;
-    wq0 = *reinterpret_cast<const uint4*>(o + wr0 * bp + 16 * wc0);
-    wq1 = *reinterpret_cast<const uint4*>(o + wr1 * bp + 16 * wc1);
-  };
+  static_assert(kDescKP == 8, "the window registers below are named per keypoint");
+  uint4 wq0_0, wq0_1, wq0_2, wq0_3, wq0_4, wq0_5, wq0_6, wq0_7, wq1_0, wq1_1, wq1_2, wq1_3, wq1_4, wq1_5, wq1_6, wq1_7;
+#define DVS_REQUEST_WINDOW(i)                                                                                  \
+  {                                                                                                            \
+    const u8* bb = DVS_RLP(blurL, i);                                                                          \
+    const int bp = DVS_RL(bpL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);                                       \
+    const int xa = (xi - kWinR) & ~3; /* dword-aligned window origin; 48 bytes per row cover x-18 .. x+18 */  \
+    const u8* o = bb + (int64_t)(yi - kWinR) * bp + xa;                                                        \
+    wq0_##i = *reinterpret_cast<const uint4*>(o + wr0 * bp + 16 * wc0);                                        \
+    wq1_##i = *reinterpret_cast<const uint4*>(o + wr1 * bp + 16 * wc1);                                        \
+  }
+  // a wave's life is one latency chain (slot -> patches / windows -> samples), so every window is requested up front: the
+  // first half behind the patches, the second half into the registers the patches free
+  DVS_REQUEST_WINDOW(0) DVS_REQUEST_WINDOW(1) DVS_REQUEST_WINDOW(2) DVS_REQUEST_WINDOW(3)
   // pattern -> floats, once per wave
   float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
@@ -1343,18 +1347,19 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     q[i] = (int)su - kHalfPatch * (int)sm;
     q[kDescKP + i] = v * (int)sm;
   }
-  request_window(0);
+  DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7)
   // transposing butterfly: after the step with lane bit B, a lane keeps the half of the quantities selected by its bit B
-#pragma unroll
-  for (int n = kDescKP, o = 32; n >= 1; n >>= 1, o >>= 1) {
-    const bool hi = (lane & o) != 0;
-#pragma unroll
-    for (int j = 0; j < n; j++) {
-      const int keep = hi ? q[n + j] : q[j];
-      const int send = hi ? q[j] : q[n + j];
-      q[j] = keep + __shfl_xor(send, o);
-    }
+#define DVS_BFLY(n, o)                                        \
+  {                                                           \
+    const bool hi = (lane & (o)) != 0;                        \
+    _Pragma("unroll") for (int j = 0; j < (n); j++) {         \
+      const int keep = hi ? q[(n) + j] : q[j];                \
+      const int send = hi ? q[j] : q[(n) + j];                \
+      q[j] = keep + __shfl_xor(send, (o));                    \
+    }                                                         \
   }
+  DVS_BFLY(8, 32) DVS_BFLY(4, 16) DVS_BFLY(2, 8) DVS_BFLY(1, 4)
+#undef DVS_BFLY
   int tot = q[0];
   tot += __shfl_xor(tot, 2);
   tot += __shfl_xor(tot, 1);
@@ -1368,14 +1373,13 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   // ---- steered BRIEF on the blurred level (:107-146), one keypoint after the other
   const unsigned vmask = (unsigned)(__ballot(valid) & 0xffull);
   const int giL = gi;
-#pragma unroll
-  for (int i = 0; i < kDescKP; i++) {
+  auto brief = [&](const int i, const uint4& wa, const uint4& wb) __attribute__((always_inline)) {
     u8* wl = win[wv][i & 1];
-    *reinterpret_cast<uint4*>(wl + wr0 * kWinPitch + 16 * wc0) = wq0;
-    if (w1ok) *reinterpret_cast<uint4*>(wl + wr1 * kWinPitch + 16 * wc1) = wq1;
-    const int wxi = wx;
+    *reinterpret_cast<uint4*>(wl + wr0 * kWinPitch + 16 * wc0) = wa;
+    if (w1ok) *reinterpret_cast<uint4*>(wl + wr1 * kWinPitch + 16 * wc1) = wb;
+    const int xi = DVS_RL(x, i);
+    const int wxi = xi - ((xi - kWinR) & ~3);
     wave_lds_fence();
-    if (i + 1 < kDescKP) request_window(i + 1);
     const float a = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, cosK), 4 * i));
     const float b = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, sinK), 4 * i));
     const u8* bc = wl + kWinR * kWinPitch + wxi;
@@ -1397,7 +1401,9 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
         reinterpret_cast<unsigned long long*>(outDesc + ((uint64_t)f * capacity + gii) * 32)[lane] = w;
       }
     }
-  }
+  };
+  brief(0, wq0_0, wq1_0); brief(1, wq0_1, wq1_1); brief(2, wq0_2, wq1_2); brief(3, wq0_3, wq1_3);
+  brief(4, wq0_4, wq1_4); brief(5, wq0_5, wq1_5); brief(6, wq0_6, wq1_6); brief(7, wq0_7, wq1_7);
   // ---- keypoints: lane i < 8 writes keypoint i; its angle lives in lane 4 * i
   const float angle = __shfl(angleK, 4 * (lane & 7));
   if (lane < kDescKP && valid) {
@@ -1411,6 +1417,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     kp.class_id = -1;
     outKp[(uint64_t)f * capacity + gi] = kp;
   }
+#undef DVS_REQUEST_WINDOW
 #undef DVS_RL
 #undef DVS_RLP
 }
