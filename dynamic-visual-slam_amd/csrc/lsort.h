@@ -154,4 +154,69 @@ LSORT_HD void sort(T* first, long n, C comp) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same std::sort, restated so that it parallelises (the GPU quad-tree runs this form, one wavefront per range):
+//
+//  * __unguarded_partition: with GE = positions of [first, last) holding an element that stops the left scan (!(x < pivot))
+//    in ascending order, and LE = positions that stop the right scan (!(pivot < x)) in descending order, the k-th swap of the
+//    Hoare loop exchanges GE[k] and LE[k] as long as GE[k] < LE[k] (both scans only ever cross untouched elements: swapped ones
+//    lie outside the open interval between the previous pair).  With K swaps done, the left scan stops at GE[K] or, if that lies
+//    beyond it, at LE[K-1] — which now holds a GE element; the returned cut is the smaller of the two.
+//  * __final_insertion_sort: after the introsort loop every range of <= 16 elements holds nothing smaller than its left
+//    neighbour range's elements, so the insertion sort never carries an element across a range boundary: it is a stable sort
+//    of every leaf range by itself (position = first + #smaller + #equal-before).
+//  * ranges are disjoint, so the order in which they are partitioned is irrelevant.
+// sort_ranked is the sequential statement of that form, used by the host tests (against the real std::sort) and mirrored
+// lane-for-lane by qt_sort_block in orb_kernels.h.  Lp / Rp: scratch of n ints each.
+template <class T, class C>
+LSORT_HD long ranked_partition(T* a, long f, long l, C comp, int* Lp, int* Rp) {
+  move_median_to_first(a + f, a + f + 1, a + f + (l - f) / 2, a + l - 1, comp);
+  const T pivot = a[f];
+  long nge = 0, nle = 0;
+  for (long i = f + 1; i < l; i++) {
+    if (!comp(a[i], pivot)) Lp[f + nge++] = (int)i;
+    if (!comp(pivot, a[i])) Rp[f + nle++] = (int)i;  // ascending; k-th from the right = Rp[f + nle - 1 - k]
+  }
+  const long mm = nge < nle ? nge : nle;
+  long K = 0;
+  while (K < mm && Lp[f + K] < Rp[f + nle - 1 - K]) K++;
+  for (long k = 0; k < K; k++) swp(a + Lp[f + k], a + Rp[f + nle - 1 - k]);
+  const long big = 0x7fffffff;
+  const long lK = K < nge ? Lp[f + K] : big;
+  const long rprev = K > 0 ? Rp[f + nle - K] : big;
+  return lK < rprev ? lK : rprev;
+}
+
+template <class T, class C>
+LSORT_HD void ranked_leaf(T* a, long f, long l, C comp) {  // stable placement of a[f, l), l - f <= 16
+  T tmp[16];
+  int pos[16];
+  for (long i = f; i < l; i++) {
+    int r = 0;
+    for (long j = f; j < l; j++) r += (comp(a[j], a[i]) || (!comp(a[i], a[j]) && j < i)) ? 1 : 0;
+    tmp[i - f] = a[i]; pos[i - f] = r;
+  }
+  for (long i = f; i < l; i++) a[f + pos[i - f]] = tmp[i - f];
+}
+
+template <class T, class C>
+LSORT_HD void sort_ranked(T* a, long n, C comp, int* Lp, int* Rp) {
+  if (n <= 1) return;
+  int lg = 0;
+  for (long m = n; m > 1; m >>= 1) lg++;
+  struct Frame { long f, l; int d; };
+  Frame stack[128];
+  int sp = 0;
+  stack[sp++] = Frame{0, n, lg * 2};
+  while (sp > 0) {
+    const Frame fr = stack[--sp];
+    if (fr.l - fr.f <= 16) { ranked_leaf(a, fr.f, fr.l, comp); continue; }
+    if (fr.d == 0) { heap_sort_all(a + fr.f, a + fr.l, comp); continue; }
+    const long cut = ranked_partition(a, fr.f, fr.l, comp, Lp, Rp);
+    stack[sp++] = Frame{cut, fr.l, fr.d - 1};
+    stack[sp++] = Frame{fr.f, cut, fr.d - 1};
+  }
+}
+
 }  // namespace lsort

@@ -383,6 +383,11 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
     int maxPts = 0;
     for (int l = 0; l < G.nlevels; l++) maxPts = std::max(maxPts, G.lv[l].ptsCap);
     h->octree_ptscap = std::min(6144, maxPts);
+    // two quad-tree workgroups per CU (the launch is latency-bound: frames x levels workgroups, all resident at once) need
+    // <= 80 KB each including k_octree's static LDS; give up a few point slots rather than half the residency
+    const long fixed = (long)h->octree_nmax * (long)(2 * sizeof(QNode) + 8 + 16 + 4 * 4) + 2048;
+    const long fit = (80 * 1024 - fixed) / 8;
+    if (fit >= 4096 && h->octree_ptscap > fit) h->octree_ptscap = (int)fit;
   }
   h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4) + (size_t)h->octree_ptscap * 8;
   DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
@@ -752,6 +757,28 @@ void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, in
   for (int i = 0; i < n; i++) v[i] = ((unsigned long long)(uint32_t)count[i] << 28) | ((unsigned long long)(uint16_t)ulx[i] << 12) | (unsigned long long)i;
   lsort::sort(v.data(), (long)n, lsort::Less<12>());
   for (int i = 0; i < n; i++) perm[i] = (int)(v[i] & 0xFFFull);
+}
+void dvs_test_sort_nodes_ranked(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm) {
+  std::vector<unsigned long long> v(n);
+  std::vector<int> lp(n + 1), rp(n + 1);
+  for (int i = 0; i < n; i++) v[i] = ((unsigned long long)(uint32_t)count[i] << 28) | ((unsigned long long)(uint16_t)ulx[i] << 12) | (unsigned long long)i;
+  lsort::sort_ranked(v.data(), (long)n, lsort::Less<12>(), lp.data(), rp.data());
+  for (int i = 0; i < n; i++) perm[i] = (int)(v[i] & 0xFFFull);
+}
+dvs_status dvs_test_sort_nodes_device(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm) {
+  DVS_ARG(n >= 0 && n <= kMaxQuota && (n == 0 || (count && ulx && perm)));
+  if (n == 0) return DVS_OK;
+  std::vector<unsigned long long> v(n);
+  for (int i = 0; i < n; i++) v[i] = ((unsigned long long)(uint32_t)count[i] << 28) | ((unsigned long long)(uint16_t)ulx[i] << 12) | (unsigned long long)i;
+  unsigned long long* d = nullptr;
+  DVS_HIP(hipMalloc(&d, sizeof(unsigned long long) * n));
+  hipError_t e = hipMemcpy(d, v.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_test_sort, dim3(1), dim3(256), 0, 0, d, n); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpy(v.data(), d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  DVS_HIP(e);
+  for (int i = 0; i < n; i++) perm[i] = (int)(v[i] & 0xFFFull);
+  return DVS_OK;
 }
 void dvs_test_sincosf(float a, float* s, float* c) { *s = gsc::sinf_(a); *c = gsc::cosf_(a); }
 // geometry without touching the GPU: fills level sizes / cell grid / quotas for a resolution

@@ -801,6 +801,128 @@ __device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T
   return carry;
 }
 
+// ---- workgroup std::sort (lsort.h, "restated so that it parallelises"): ranges are partitioned one wavefront each, round by
+// round (the ranges of a round are disjoint), leaves of <= 16 elements are placed by rank, one lane per element.
+// a: m packed 64-bit elements in LDS, key = a >> 12.  Lp / Rp: scratch of m ints each (LDS).  Result in place.
+constexpr int kSortRanges = 128;  // > kMaxQuota / 17 live ranges of more than 16 elements
+struct SortShared { uint32_t rng[2][kSortRanges]; int cnt[2]; };
+
+__device__ __forceinline__ int qs_wave_partition(unsigned long long* a, int* Lp, int* Rp, int f, int l, int lane) {
+  const lsort::Less<12> less;
+  if (lane == 0) lsort::move_median_to_first(a + f, a + f + 1, a + f + (l - f) / 2, a + l - 1, less);
+  wave_lds_fence();
+  const unsigned long long pk = a[f] >> 12;
+  const unsigned long long ltm = (1ull << lane) - 1ull;
+  int nge = 0, nle = 0;
+  for (int c = f + 1; c < l; c += 64) {
+    const int i = c + lane;
+    const bool v = i < l;
+    const unsigned long long k = v ? a[i] >> 12 : 0ull;
+    const bool ge = v && !(k < pk), le = v && !(pk < k);
+    const unsigned long long mg = __ballot(ge), ml = __ballot(le);
+    if (ge) Lp[f + nge + __popcll(mg & ltm)] = i;
+    if (le) Rp[f + nle + __popcll(ml & ltm)] = i;  // ascending; k-th from the right = Rp[f + nle - 1 - k]
+    nge += __popcll(mg); nle += __popcll(ml);
+  }
+  wave_lds_fence();
+  const int mm = min(nge, nle);
+  int K = 0;
+  for (int c = 0; c < mm; c += 64) {
+    const int k = c + lane;
+    const unsigned long long mk = __ballot(k < mm && Lp[f + k] < Rp[f + nle - 1 - k]);
+    K += __popcll(mk);
+    if (mk != ~0ull) break;  // the pairs that swap are a prefix
+  }
+  for (int c = 0; c < K; c += 64) {
+    const int k = c + lane;
+    if (k < K) {
+      const int i = Lp[f + k], j = Rp[f + nle - 1 - k];
+      const unsigned long long x = a[i], y = a[j];
+      a[i] = y; a[j] = x;
+    }
+  }
+  const int big = 0x7fffffff;
+  const int lK = K < nge ? Lp[f + K] : big;
+  const int rprev = K > 0 ? Rp[f + nle - K] : big;
+  wave_lds_fence();
+  return min(lK, rprev);
+}
+
+__device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int* Lp, int* Rp, SortShared& ss) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // leaf descriptor per element, kept in Lp (a finished range's scratch is never used again): first | end << 16
+  auto emit = [&](int f, int l, int d, int nxt) {
+    if (l - f > 16) {
+      if (lane == 0) ss.rng[nxt][atomicAdd(&ss.cnt[nxt], 1)] = (uint32_t)f | ((uint32_t)l << 12) | ((uint32_t)d << 24);
+    } else if (lane < l - f) {
+      Lp[f + lane] = f | (l << 16);
+    }
+  };
+  if (tid == 0) { ss.cnt[0] = 0; ss.cnt[1] = 0; }
+  __syncthreads();
+  if (wv == 0) {
+    int lg = 0;
+    for (int q = m; q > 1; q >>= 1) lg++;
+    emit(0, m, 2 * lg, 0);
+  }
+  __syncthreads();
+  for (int cur = 0;; cur ^= 1) {
+    const int cnt = ss.cnt[cur];
+    if (cnt == 0) break;
+    for (int ri = wv; ri < cnt; ri += 4) {
+      const uint32_t r = ss.rng[cur][ri];
+      const int f = (int)(r & 0xFFFu), l = (int)((r >> 12) & 0xFFFu), d = (int)(r >> 24);
+      if (d == 0) {  // depth limit: heapsort the range (std::__partial_sort), every element its own leaf
+        if (lane == 0) lsort::heap_sort_all(a + f, a + l, lsort::Less<12>());
+        for (int i = f + lane; i < l; i += 64) Lp[i] = i | ((i + 1) << 16);
+        continue;
+      }
+      const int cut = qs_wave_partition(a, Lp, Rp, f, l, lane);
+      emit(f, cut, d - 1, cur ^ 1);
+      emit(cut, l, d - 1, cur ^ 1);
+    }
+    __syncthreads();
+    if (tid == 0) ss.cnt[cur] = 0;
+    __syncthreads();
+  }
+  // leaves: stable placement by rank
+  constexpr int kPer = (kMaxQuota + 255) / 256;
+  unsigned long long mine[kPer];
+  int np[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; u++) {
+    const int i = tid + 256 * u;
+    np[u] = -1;
+    if (i < m) {
+      const int fl = Lp[i];
+      const int f = fl & 0xFFFF, l = fl >> 16;
+      const unsigned long long e = a[i];
+      const unsigned long long ke = e >> 12;
+      int rnk = f;
+      for (int j = f; j < l; j++) {
+        const unsigned long long kj = a[j] >> 12;
+        rnk += (kj < ke || (kj == ke && j < i)) ? 1 : 0;
+      }
+      mine[u] = e; np[u] = rnk;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kPer; u++)
+    if (np[u] >= 0) a[np[u]] = mine[u];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_test_sort(unsigned long long* __restrict__ v, int m) {
+  __shared__ unsigned long long a[kMaxQuota];
+  __shared__ int Lp[kMaxQuota], Rp[kMaxQuota];
+  __shared__ SortShared ss;
+  for (int i = threadIdx.x; i < m; i += 256) a[i] = v[i];
+  __syncthreads();
+  qt_sort_block(a, m, Lp, Rp, ss);
+  for (int i = threadIdx.x; i < m; i += 256) v[i] = a[i];
+}
+
 __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
@@ -809,6 +931,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int wsum[5];
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
+  __shared__ SortShared s_sort;
   const int tid = threadIdx.x;
   const int level = blockIdx.x, f = blockIdx.y;
   const LevelGeom& L = g->lv[level];
@@ -978,8 +1101,12 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
       }
       for (int k = tid; k < Sb; k += 256) sh.flag[k] = 0;
       __syncthreads();
-      if (tid == 0 && !(g->debug & 1)) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
-      __syncthreads();
+      if (g->debug & 2) {  // diagnostics: the single-lane replica
+        if (tid == 0) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
+        __syncthreads();
+      } else if (!(g->debug & 1)) {
+        qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
+      }
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
       if (tid == 0) s_c = 0;

@@ -82,6 +82,8 @@ def lib():
     L.dvs_match_hamming_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
     L.dvs_match_hamming_thresh.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
+    L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
+    L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int
     L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
     L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):

@@ -227,6 +227,10 @@ dvs_status dvs_ba_pose_to_rt(const double* q_wxyz, const double* trans, double* 
 /* ======================================= host-logic test hooks ================================= */
 /* (no GPU needed) libstdc++ std::sort replica used by the quad-tree, glibc sinf/cosf restatement, geometry tables */
 void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
+/* the same order through the rank-pairing restatement the quad-tree kernel runs (host, sequential) ... */
+void dvs_test_sort_nodes_ranked(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
+/* ... and through the kernel's workgroup sort itself (needs a GPU; n <= 1500) */
+dvs_status dvs_test_sort_nodes_device(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
 void dvs_test_sincosf(float a, float* s, float* c);
 dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
                              int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);

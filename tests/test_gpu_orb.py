@@ -172,3 +172,28 @@ def test_full_hd_3000_features(gpu, oracle):
     img = synth.make_frame(2, cols=1920, rows=1080)
     g, o = _pair(oracle, 3000, 8)
     _assert_same_result(*g(img), *o.extract(img))
+
+
+@pytest.mark.gpu
+def test_workgroup_sort_matches_std_sort(gpu, hiplib, oracle):
+    """The quad-tree's workgroup sort (one wavefront per introsort range, rank-placed leaves) must reproduce std::sort's
+    permutation on tie-heavy keys, including the depth-limit heapsort fallback (ORBextractor.cpp:538-553, 700)."""
+    rng = np.random.default_rng(9)
+    cases = []
+    for n in [1, 2, 16, 17, 18, 33, 64, 65, 100, 257, 434, 1000, 1500]:
+        for kc, kx in [(2, 2), (3, 40), (50, 5), (1000, 1000), (1, 1)]:
+            cases.append((rng.integers(2, 2 + kc, n), rng.integers(0, kx, n) * 7))
+    n = 1024
+    for _ in range(4):   # median-of-3 killers: heapsort fallback
+        base = np.concatenate([np.arange(1, n // 2 + 1, 2), np.arange(n // 2 + 1, n + 1), np.arange(2, n // 2 + 1, 2)])[:n]
+        base = np.resize(base, n)
+        cases.append((base // rng.integers(1, 4), rng.integers(0, 3, n)))
+    cases.append((np.arange(700), np.zeros(700)))
+    cases.append((np.arange(700)[::-1], np.zeros(700)))
+    for count, ulx in cases:
+        count = np.ascontiguousarray(count, np.int32); ulx = np.ascontiguousarray(ulx, np.int32)
+        m = len(count)
+        a = np.zeros(m, np.int32); b = np.zeros(m, np.int32)
+        assert hiplib.dvs_test_sort_nodes_device(count.ctypes.data, ulx.ctypes.data, m, a.ctypes.data) == 0
+        oracle.lib().orc_std_sort_nodes(count.ctypes.data, ulx.ctypes.data, m, b.ctypes.data)
+        assert (a == b).all(), f"n={m}"

@@ -31,11 +31,14 @@ def test_no_gpu_means_error_not_fallback(hiplib):
 
 
 def _sort_both(hiplib, oracle, count, ulx):
+    """(replica, std::sort) permutations; the rank-pairing restatement the kernel runs is checked on the way."""
     count = np.ascontiguousarray(count, np.int32); ulx = np.ascontiguousarray(ulx, np.int32)
     n = len(count)
-    a = np.zeros(n, np.int32); b = np.zeros(n, np.int32)
+    a = np.zeros(n, np.int32); b = np.zeros(n, np.int32); c = np.zeros(n, np.int32)
     hiplib.dvs_test_sort_nodes(count.ctypes.data, ulx.ctypes.data, n, a.ctypes.data)
     oracle.lib().orc_std_sort_nodes(count.ctypes.data, ulx.ctypes.data, n, b.ctypes.data)
+    hiplib.dvs_test_sort_nodes_ranked(count.ctypes.data, ulx.ctypes.data, n, c.ctypes.data)
+    assert (c == b).all(), "rank-pairing restatement differs from std::sort"
     return a, b
 
 
@@ -59,6 +62,15 @@ def test_introsort_replica_matches_std_sort(hiplib, oracle):
     cases.append((killer, np.arange(n) % 5))
     for count, ulx in cases:
         a, b = _sort_both(hiplib, oracle, count, ulx)
+        assert (a == b).all()
+
+
+def test_introsort_random_stress(hiplib, oracle):
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        n = int(rng.integers(0, 1500))
+        kc, kx = int(rng.integers(1, 60)), int(rng.integers(1, 30))
+        a, b = _sort_both(hiplib, oracle, rng.integers(2, 2 + kc, n), rng.integers(0, kx, n) * 11)
         assert (a == b).all()
 
 
