@@ -159,7 +159,8 @@ def main():
                         n=torch.zeros(B + 1, dtype=torch.int32, device=dev),
                         idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
                         dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
-        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), **bufs))
+        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), xstream=torch.cuda.Stream(device=dev),
+                          xdone=torch.cuda.Event(), **bufs))
     cap = pipes[0]["orb"].capacity
     torch.cuda.synchronize()
     state = {"i": 0}
@@ -167,19 +168,27 @@ def main():
     def step():
         i = state["i"]; state["i"] += 1
         P = pipes[i % NP]; Q = pipes[(i - 1) % NP]
+        if i > 0:
+            # the one exchange step (previous step's last-frame descriptors -> slot 0) depends only on the previous step:
+            # it runs on a side stream beside this step's extraction and is joined right before the match
+            X = P["xstream"]
+            X.wait_event(Q["done"])
+            with torch.cuda.stream(X):
+                bd, bn = dvdist.exchange_boundary(Q["desc"][B], Q["n"][B], cap)
+                P["desc"][0].copy_(bd); P["n"][0].copy_(bn)
+                P["xdone"].record(X)
         with torch.cuda.stream(P["stream"]):
             P["orb"].extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][1].data_ptr(),
                                           P["desc"][1].data_ptr(), cap, P["n"][1:].data_ptr())
             if i > 0:
-                P["stream"].wait_event(Q["done"])          # previous step's last-frame descriptors
-                bd, bn = dvdist.exchange_boundary(Q["desc"][B], Q["n"][B], cap)
-                P["desc"][0].copy_(bd); P["n"][0].copy_(bn)
+                P["stream"].wait_event(P["xdone"])
             P["mat"].match_batch_device(P["desc"][1].data_ptr(), P["n"][1:].data_ptr(), cap, P["desc"][0].data_ptr(),
                                         P["n"][0:].data_ptr(), cap, B, P["idx"].data_ptr(), P["dist"].data_ptr())
             P["done"].record(P["stream"])
 
     def sync_all():
         for P in pipes:
+            P["xstream"].synchronize()
             P["stream"].synchronize()
 
     for _ in range(args.warmup):

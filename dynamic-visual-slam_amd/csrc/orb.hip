@@ -464,6 +464,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
       int tail = G.nlevels;  // first level of the merged tail: levels whose cells are < 1/16 of all cells each
       while (tail > 2 && G.lv[tail - 1].nCells * 16 < G.totalCells) tail--;
+      if (const char* te = getenv("DVS_FAST_TAIL")) tail = std::max(1, std::min(G.nlevels, atoi(te)));
       for (int l = 0; l < G.nlevels; l++) {
         const bool merged = l >= tail;
         if (merged && l > tail) continue;
