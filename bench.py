@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--pipelines", type=int, default=1, help="double-buffered batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="build every batch's pyramid inside its own step (default: the next batch's pyramid overlaps this batch's "
+                         "descriptor stage and match, dvs_orb_hint_next_batch_device)")
     args = ap.parse_args()
 
     import torch
@@ -153,38 +156,55 @@ def main():
         orb.set_stream(ts.cuda_stream); mat.set_stream(ts.cuda_stream)
         cap = orb.capacity
         with torch.cuda.stream(ts):
-            # slot 0 = last frame of the previous step (own rank's or the neighbour's), slots 1..B = this step's frames
-            bufs = dict(kps=torch.empty((B + 1, cap, 28), dtype=torch.uint8, device=dev),
-                        desc=torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev),
-                        n=torch.zeros(B + 1, dtype=torch.int32, device=dev),
+            # two output sets used alternately: step i writes set i % 2 and its first match job reads the LAST frame of set
+            # (i - 1) % 2 in place (dvs_match_hamming_sequence_device) — no boundary copy on one GPU
+            bufs = dict(kps=[torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(2)],
+                        desc=[torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)],
+                        n=[torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)],
                         idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
                         dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
         pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), xstream=torch.cuda.Stream(device=dev),
-                          xdone=torch.cuda.Event(), **bufs))
+                          xdone=torch.cuda.Event(), count=0, prev=None, **bufs))
     cap = pipes[0]["orb"].capacity
     torch.cuda.synchronize()
     state = {"i": 0}
+    collective = world > 1 or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
 
     def step():
         i = state["i"]; state["i"] += 1
         P = pipes[i % NP]; Q = pipes[(i - 1) % NP]
+        s = P["count"] % 2; P["count"] += 1
+        prev_desc = prev_n = 0
         if i > 0:
-            # the one exchange step (previous step's last-frame descriptors -> slot 0) depends only on the previous step:
-            # it runs on a side stream beside this step's extraction and is joined right before the match
-            X = P["xstream"]
-            X.wait_event(Q["done"])
-            with torch.cuda.stream(X):
-                bd, bn = dvdist.exchange_boundary(Q["desc"][B], Q["n"][B], cap)
-                P["desc"][0].copy_(bd); P["n"][0].copy_(bn)
-                P["xdone"].record(X)
+            qd, qn = Q["last"]           # last frame of the previous step (this rank's)
+            if collective:
+                # the one exchange step: every rank's last-frame block, this rank needs its predecessor's.  It depends only on
+                # the previous step, so it runs on a side stream beside this step's extraction and is joined before the match
+                X = P["xstream"]
+                X.wait_event(Q["done"])
+                with torch.cuda.stream(X):
+                    bd, bn = dvdist.exchange_boundary(qd, qn, cap)
+                    P["xdone"].record(X)
+                P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
+                prev_desc, prev_n = bd.data_ptr(), bn.data_ptr()
+            else:
+                if NP > 1:
+                    P["stream"].wait_event(Q["done"])
+                prev_desc, prev_n = qd.data_ptr(), qn.data_ptr()
         with torch.cuda.stream(P["stream"]):
-            P["orb"].extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][1].data_ptr(),
-                                          P["desc"][1].data_ptr(), cap, P["n"][1:].data_ptr())
-            if i > 0:
+            if args.prefetch and NP == 1:
+                # streaming: the next batch is already resident, so its pyramid is built beside this batch's FAST
+                # (every step still builds exactly one pyramid; the one of step 0 is built in-step)
+                P["orb"].hint_next_batch_device(d_img.data_ptr())
+            P["orb"].extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
+                                          P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
+            if i > 0 and collective:
                 P["stream"].wait_event(P["xdone"])
-            P["mat"].match_batch_device(P["desc"][1].data_ptr(), P["n"][1:].data_ptr(), cap, P["desc"][0].data_ptr(),
-                                        P["n"][0:].data_ptr(), cap, B, P["idx"].data_ptr(), P["dist"].data_ptr())
+            P["mat"].match_sequence_device(P["desc"][s].data_ptr(), P["n"][s].data_ptr(), cap, B, prev_desc, prev_n,
+                                           P["idx"].data_ptr(), P["dist"].data_ptr())
             P["done"].record(P["stream"])
+        P["last"] = (P["desc"][s][B - 1], P["n"][s][B - 1:B])
+        P["cur"] = s
 
     def sync_all():
         for P in pipes:
@@ -215,8 +235,8 @@ def main():
     P = pipes[0]
     with torch.cuda.stream(P["stream"]):
         for _ in range(args.steps):
-            orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][1].data_ptr(), P["desc"][1].data_ptr(),
-                                     cap, P["n"][1:].data_ptr())
+            orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
+                                     P["desc"][P["cur"]].data_ptr(), cap, P["n"][P["cur"]].data_ptr())
     sync_all()
     stage_ms, stage_calls = orb.stage_times()
     orb.enable_stage_timing(False)
@@ -225,10 +245,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    d_n = pipes[0]["n"]; d_dist = pipes[0]["dist"]
+    d_n = pipes[0]["n"][pipes[0]["cur"]]; d_dist = pipes[0]["dist"]
 
     n_host = d_n.cpu().numpy()
-    matched = int((d_dist[:, :].cpu().numpy()[0, :n_host[1]] < 50).sum())
+    matched = int((d_dist[:, :].cpu().numpy()[0, :n_host[0]] < 50).sum())
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -247,7 +267,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame "
-                                   "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[1]),
+                                   "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[0]),
                        "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,

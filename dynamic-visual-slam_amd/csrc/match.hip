@@ -22,12 +22,15 @@ constexpr int kSplit = 8;   // train-set slices per workgroup (one wavefront eac
 constexpr int kQPL = 2;     // queries per lane: every scalar train row feeds two independent popcount chains
 __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
                                                        const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
-                                                       int* __restrict__ outIdx, int* __restrict__ outDist) {
+                                                       int* __restrict__ outIdx, int* __restrict__ outDist,
+                                                       const u64* __restrict__ t0 = nullptr, const int* __restrict__ nt0 = nullptr) {
   __shared__ int sd[kSplit][64 * kQPL];
   __shared__ int si[kSplit][64 * kQPL];
   const int pair = blockIdx.y;
   const int nq = nqArr ? nqArr[pair] : nqConst;
-  const int nt = ntArr ? ntArr[pair] : ntConst;
+  // job 0's train set may live elsewhere (frame sequences: the previous batch's last frame), t0 / nt0 then replace t / ntArr
+  const bool first = pair == 0 && t0 != nullptr;
+  const int nt = first ? *nt0 : (ntArr ? ntArr[pair] : ntConst);
   const int q0 = blockIdx.x * 64 * kQPL;
   if (q0 >= nq) return;
   const int lane = threadIdx.x & 63;
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   }
   const int chunk = (nt + kSplit - 1) / kSplit;
   const int jb = min(nt, w * chunk), je = min(nt, jb + chunk);
-  const u64* tp = t + (size_t)pair * tStrideRows * 4;
+  const u64* tp = first ? t0 : t + (ptrdiff_t)pair * tStrideRows * 4;
   // running best as ONE word: distance << 23 | train index (nt < 2^23, checked on the host) -> a single v_min_u32 per pair
   // keeps the smallest distance and, on ties, the lowest index; the eight popcounts chain through v_bcnt's accumulator.
   unsigned bestp[kQPL];
@@ -174,6 +177,7 @@ struct dvs_matcher {
   size_t cq = 0, ct = 0, cidx = 0, ccounts = 0, cpairs = 0;
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only buffers of the glue entry points (frontend.hip)
   size_t cscratch[4] = {0, 0, 0, 0};
+  void* d_zero = nullptr;  // 64 zero bytes: the empty predecessor of dvs_match_hamming_sequence_device
 };
 
 namespace {
@@ -247,7 +251,7 @@ void dvs_matcher_destroy(dvs_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3]};
+  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
@@ -282,6 +286,28 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
   hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
                      t_stride_rows, d_idx, d_dist);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_desc, const int32_t* d_n, int32_t stride_rows,
+                                             int32_t nframes, const uint8_t* d_prev_desc, const int32_t* d_prev_n, int32_t* d_idx,
+                                             int32_t* d_dist) {
+  DVS_ARG(m && d_desc && d_n && d_idx && d_dist && nframes >= 0 && stride_rows > 0 && stride_rows < (1 << 23));
+  DVS_ARG((d_prev_desc == nullptr) == (d_prev_n == nullptr));
+  if (nframes == 0) return DVS_OK;
+  DVS_HIP(hipSetDevice(m->device));
+  if (!d_prev_desc) {  // no predecessor: frame 0 matches against nothing (train_idx -1, dist INT32_MAX)
+    if (!m->d_zero) {
+      DVS_HIP(hipMalloc((void**)&m->d_zero, 64));
+      DVS_HIP(hipMemset(m->d_zero, 0, 64));
+    }
+    d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
+  }
+  dim3 grid((stride_rows + 64 * kQPL - 1) / (64 * kQPL), nframes);
+  // train of job p >= 1 = frame p - 1: the base pointers are shifted back by one frame and never dereferenced for job 0
+  hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
+                     (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }

@@ -28,8 +28,10 @@ struct dvs_orb {
   dvs_orb_params prm;
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t pf_stream = nullptr;         // the NEXT batch's pyramid chain (dvs_orb_hint_next_batch_device)
   hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr;
+  hipEvent_t ev_desc = nullptr, ev_prefetch = nullptr;  // descriptor stage reached / next batch's pyramid complete
   hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete
   bool overlap = true;
   int max_batch = 1;
@@ -48,6 +50,12 @@ struct dvs_orb {
   PyrTile* d_pyrtiles = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
   u8 *d_pyr = nullptr, *d_blur = nullptr;
+  // cross-batch software pipeline (dvs_orb_hint_next_batch_device): the NEXT batch's pyramid is built into d_pyr_alt on the
+  // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
+  u8* d_pyr_alt = nullptr;
+  const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
+  bool pf_valid = false;
+  const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
   int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
@@ -67,7 +75,7 @@ namespace {
 
 void free_workspace(dvs_orb* h) {
   void* ptrs[] = {h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_pyr_alt, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
@@ -76,6 +84,7 @@ void free_workspace(dvs_orb* h) {
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
+  h->d_pyr_alt = nullptr; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
   h->rows = h->cols = 0;
@@ -344,6 +353,8 @@ dvs_status upload(T** dptr, const std::vector<T>& v) {
 dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   if (h->rows == rows && h->cols == cols && h->d_geom) return DVS_OK;
   DVS_HIP(hipStreamSynchronize(h->stream));
+  if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
   free_workspace(h);
   Geom G;
   std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
@@ -398,10 +409,42 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   return DVS_OK;
 }
 
+// the level chain: level l from level l-1 (ORBextractor.cpp:1171-1192) into `pyr`, one launch per level on `pst`
+dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr, hipStream_t pst, bool level_events) {
+  const Geom& G = h->geom;
+  for (int l = 1; l < G.nlevels; l++) {
+    const LevelGeom& S = G.lv[l - 1];
+    const LevelGeom& D = G.lv[l];
+    const u8* sp = l == 1 ? src.img0 : pyr + S.off;
+    const uint64_t sfs = l == 1 ? src.fstride0 : G.frameBytes;
+    const int spitch = l == 1 ? (int)src.step0 : S.pitch;
+    dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
+    const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
+    if (aligned && D.gtab >= 0)
+      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
+                         sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
+                         h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+    else
+      hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, D.w, D.h,
+                         D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+    if (level_events) DVS_HIP(hipEventRecord(h->ev_level[l], pst));
+  }
+  return DVS_OK;
+}
+
 // enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`
-dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout) {
+dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout,
+                           const u8* next_img0 = nullptr) {
   const Geom& G = h->geom;
   hipStream_t st = h->stream;
+  // a pyramid prefetched for exactly this batch (same buffer, layout and count)?  then it is already (being) built in d_pyr_alt
+  const bool prefetched = h->pf_valid && h->overlap && h->pf_img == src.img0 && h->pf_step == src.step0 &&
+                          h->pf_fstride == src.fstride0 && h->pf_nimg == nimg;
+  h->pf_valid = false;
+  if (prefetched) {
+    std::swap(h->d_pyr, h->d_pyr_alt);
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
+  }
   src.pyr = h->d_pyr;
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
   //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
@@ -411,40 +454,39 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // SLOWER than the per-level chain running beside FAST (0.29 vs 0.20 ms per 64 frames: the resize arithmetic is VALU-issue
   // bound, so removing the launches and the re-reads buys nothing).  Kept selectable for HBM-traffic experiments.
   const char* casc_env = getenv("DVS_CASCADE");
-  const bool cascade = casc_env && casc_env[0] == '1' && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
-  const bool ov = !cascade && h->overlap && G.nlevels >= 2;
+  const bool cascade = !prefetched && casc_env && casc_env[0] == '1' && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
+  const bool ov = !prefetched && !cascade && h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
-  if (cascade) {
+  if (prefetched) {
+    // nothing to build
+  } else if (cascade) {
     // all levels in ONE launch: each workgroup stages a level-0 region in LDS and walks down the levels (k_pyr_cascade)
     h->timer.begin(DVS_STAGE_PYRAMID, st);
     hipLaunchKernelGGL(k_pyr_cascade, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
                        h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, G.pyrLds);
     h->timer.end(st);
   } else {
-  if (ov) {
-    pst = h->aux_stream;
-    DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
-    DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
+    if (ov) {
+      pst = h->aux_stream;
+      DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
+      DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
+    }
+    h->timer.begin(DVS_STAGE_PYRAMID, pst);
+    DVS_TRY(launch_pyramid_chain(h, src, nimg, h->d_pyr, pst, ov));
+    h->timer.end(pst);
   }
-  h->timer.begin(DVS_STAGE_PYRAMID, pst);
-  for (int l = 1; l < G.nlevels; l++) {
-    const LevelGeom& S = G.lv[l - 1];
-    const LevelGeom& D = G.lv[l];
-    const u8* sp = l == 1 ? src.img0 : h->d_pyr + S.off;
-    const uint64_t sfs = l == 1 ? src.fstride0 : G.frameBytes;
-    const int spitch = l == 1 ? (int)src.step0 : S.pitch;
-    dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
-    const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
-    if (aligned && D.gtab >= 0)
-      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
-                         sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
-                         h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
-    else
-      hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, h->d_pyr + D.off, G.frameBytes, D.w, D.h,
-                         D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
-    if (ov) DVS_HIP(hipEventRecord(h->ev_level[l], pst));
-  }
-  h->timer.end(pst);
+  // the next batch's pyramid (if announced) runs on the auxiliary stream beside THIS batch's FAST: the chain is latency-bound
+  // and FAST is VALU-bound and insensitive to its cache traffic (beside the fetch-bound descriptor stage it doubled that
+  // stage's time), and with this batch's own pyramid prefetched the same way FAST needs no per-level gating at all
+  if (next_img0 && h->overlap && G.nlevels >= 2) {
+    if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes));
+    ImgSrc nsrc = src;
+    nsrc.img0 = next_img0;
+    DVS_HIP(hipEventRecord(h->ev_desc, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
+    DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_desc, 0));
+    DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+    DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
+    h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
   }
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
   {
@@ -549,8 +591,11 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_prefetch, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
     dvs_orb_destroy(h);
     set_error("aux stream / event creation failed");
@@ -571,12 +616,17 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+  if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
   h->timer.resolve();
   free_workspace(h);
-  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
   if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
+  if (h->ev_prefetch) (void)hipEventDestroy(h->ev_prefetch);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -594,6 +644,7 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   DVS_HIP(hipStreamSynchronize(h->stream));
   DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  DVS_HIP(hipStreamSynchronize(h->pf_stream));
   h->overlap = on != 0;
   return DVS_OK;
 }
@@ -609,6 +660,7 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
+  DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
   return DVS_OK;
 }
 
@@ -645,7 +697,15 @@ dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32
   DVS_TRY(ensure_workspace(h, rows, cols));
   if (nimg == 0) return DVS_OK;
   ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr};
-  return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out);
+  const u8* next = h->next_hint;
+  h->next_hint = nullptr;
+  return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out, next);
+}
+
+dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs) {
+  DVS_ARG(h);
+  h->next_hint = d_next_imgs;
+  return DVS_OK;
 }
 
 dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t nimg, int32_t rows, int32_t cols, size_t step,

@@ -68,6 +68,7 @@ def lib():
     L.dvs_orb_level_size.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
     L.dvs_orb_extract_batch.argtypes = [vp, vp, i32, i32, i32, sz, vp, vp, i32, vp]
+    L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
     L.dvs_orb_get_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
@@ -75,6 +76,7 @@ def lib():
     L.dvs_orb_enable_stage_timing.argtypes = [vp, i32]
     L.dvs_orb_get_stage_times.argtypes = [vp, vp, vp, i32]
     L.dvs_matcher_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_match_hamming_sequence_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.dvs_matcher_destroy.argtypes = [vp]; L.dvs_matcher_destroy.restype = None
     L.dvs_matcher_set_stream.argtypes = [vp, vp]
     L.dvs_matcher_synchronize.argtypes = [vp]

@@ -46,6 +46,11 @@ class BFMatcher:
     def match_batch_device(self, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows, npairs, d_idx, d_dist):
         check(self._L.dvs_match_hamming_batch_device(self._h, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows, npairs, d_idx, d_dist))
 
+    def match_sequence_device(self, d_desc, d_n, stride_rows, nframes, d_prev_desc, d_prev_n, d_idx, d_dist):
+        """frame p vs frame p-1 of a device-resident run; frame 0 vs (d_prev_desc, d_prev_n) or nothing (0, 0)"""
+        check(self._L.dvs_match_hamming_sequence_device(self._h, d_desc, d_n, stride_rows, nframes, d_prev_desc or None,
+                                                        d_prev_n or None, d_idx, d_dist))
+
     def set_stream(self, stream_ptr):
         check(self._L.dvs_matcher_set_stream(self._h, stream_ptr))
 

@@ -100,6 +100,11 @@ class ORBextractor:
         self._shape = (rows, cols)
         return nout, kps, desc
 
+    def hint_next_batch_device(self, d_next_imgs):
+        """announce the NEXT batch (device pointer, same layout as the coming extract_batch_device call): its pyramid is built
+        beside this batch's descriptor stage and the match that follows; one-shot, results unchanged"""
+        check(self._L.dvs_orb_hint_next_batch_device(self._h, d_next_imgs))
+
     def extract_batch_device(self, d_imgs, nimg, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout):
         """raw device pointers (ints); asynchronous on the handle's stream"""
         check(self._L.dvs_orb_extract_batch_device(self._h, d_imgs, nimg, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout))

@@ -105,6 +105,14 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
 dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols,
                                         size_t step, size_t frame_stride, dvs_keypoint* d_kps, uint8_t* d_desc,
                                         int32_t capacity, int32_t* d_n_out);
+/* Cross-batch software pipeline for streaming callers that already hold the next batch in device memory: announce it before
+ * the dvs_orb_extract_batch_device call of the CURRENT batch.  That call then also enqueues the next batch's pyramid (same
+ * nimg / rows / cols / step / frame_stride) on the handle's auxiliary stream, beside its own descriptor stage and whatever
+ * the caller enqueues next (the match); the following call, if it is for exactly that buffer, finds its pyramid built and
+ * starts with FAST on all levels at once.  One-shot; results are identical with or without the hint.  The announced images
+ * must not change between the two calls.  (No counterpart in the reference, whose ComputePyramid runs inside operator(),
+ * ORBextractor.cpp:1081; this is the MI355X replacement for running consecutive frames on separate CPU threads.) */
+dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs);
 
 /* parity introspection of the LAST extract call (mvImagePyramid is a public member, ORBextractor.hpp:84) */
 dvs_status dvs_orb_get_level(dvs_orb* h, int32_t frame, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes);
@@ -137,6 +145,13 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
 dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, const int32_t* d_nq, int32_t q_stride_rows,
                                           const uint8_t* d_t, const int32_t* d_nt, int32_t t_stride_rows, int32_t npairs,
                                           int32_t* d_idx, int32_t* d_dist);
+/* The frontend's pattern (frontend.cpp:1096: current frame against the previous one) over a device-resident run of frames:
+ * frame p (rows [0, d_n[p]) of d_desc + p*stride_rows*32) is matched against frame p-1; frame 0 against the caller's
+ * predecessor (d_prev_desc / d_prev_n: e.g. the last frame of the previous batch, wherever it lives — no copy), or against
+ * nothing when both are NULL.  Outputs at d_idx/d_dist + p*stride_rows.  Asynchronous. */
+dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_desc, const int32_t* d_n, int32_t stride_rows,
+                                             int32_t nframes, const uint8_t* d_prev_desc, const int32_t* d_prev_n, int32_t* d_idx,
+                                             int32_t* d_dist);
 /* backend.cpp:1068-1077 shape: every (query, train) pair with distance < max_dist, (query, train)-ordered int32
  * triplets (q, t, dist).  *n_pairs = total found (may exceed cap; only the first cap are written). Host pointers. */
 dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,

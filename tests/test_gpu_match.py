@@ -81,3 +81,26 @@ def test_batch_device(gpu, oracle):
     for p in range(P):
         i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
         assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all()
+
+
+def test_sequence_device(gpu, oracle):
+    """frame p vs frame p-1 in place, frame 0 vs a predecessor that lives in another buffer (or nothing)"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    F, S = 5, 300
+    n = np.array([300, 257, 0, 64, 299], np.int32)
+    D = np.stack([synth.make_descriptors(S, 70 + p) for p in range(F)])
+    D[1, 3] = D[0, 9]; D[1, 4] = D[0, 9]                      # exact matches / ties across consecutive frames
+    prev = synth.make_descriptors(S, 99); nprev = np.array([211], np.int32)
+    dd = DeviceBuffer(D.nbytes).upload(D); dn = DeviceBuffer(F * 4).upload(n)
+    dp = DeviceBuffer(prev.nbytes).upload(prev); dnp = DeviceBuffer(4).upload(nprev)
+    di = DeviceBuffer(F * S * 4); dx = DeviceBuffer(F * S * 4)
+    for with_prev in (True, False):
+        m.match_sequence_device(dd.ptr, dn.ptr, S, F, dp.ptr if with_prev else 0, dnp.ptr if with_prev else 0, di.ptr, dx.ptr)
+        m.synchronize()
+        idx = di.download(np.int32, F * S).reshape(F, S); d = dx.download(np.int32, F * S).reshape(F, S)
+        for p in range(F):
+            t = (prev[:nprev[0]] if with_prev else prev[:0]) if p == 0 else D[p - 1, :n[p - 1]]
+            i2, d2 = oracle.match(D[p, :n[p]], t)
+            assert (idx[p, :n[p]] == i2).all() and (d[p, :n[p]] == d2).all(), (with_prev, p)

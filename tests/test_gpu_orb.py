@@ -197,3 +197,38 @@ def test_workgroup_sort_matches_std_sort(gpu, hiplib, oracle):
         assert hiplib.dvs_test_sort_nodes_device(count.ctypes.data, ulx.ctypes.data, m, a.ctypes.data) == 0
         oracle.lib().orc_std_sort_nodes(count.ctypes.data, ulx.ctypes.data, m, b.ctypes.data)
         assert (a == b).all(), f"n={m}"
+
+
+@pytest.mark.gpu
+def test_next_batch_hint_is_result_neutral(gpu, oracle):
+    """dvs_orb_hint_next_batch_device: the announced batch's pyramid is built beside the current batch's FAST into a second
+    buffer and consumed by the next call.  Results must equal the oracle whether the hint is right, wrong (another buffer is
+    extracted next) or absent, across alternating batches."""
+    from dvslam_amd import ORBextractor
+    from dvslam_amd._lib import DeviceBuffer, KP_DTYPE
+    rows, cols, nf, B = 240, 320, 300, 2
+    frames = [synth.make_frame(t, cols=cols, rows=rows) for t in range(6)]
+    o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
+    refs = [o.extract(f) for f in frames]
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    cap = g.capacity
+    bufs = [DeviceBuffer(B * rows * cols).upload(np.stack(frames[2 * i:2 * i + 2])) for i in range(3)]
+    d_k = DeviceBuffer(B * cap * 28); d_d = DeviceBuffer(B * cap * 32); d_n = DeviceBuffer(B * 4)
+
+    def run(i, hint):
+        if hint is not None:
+            g.hint_next_batch_device(bufs[hint].ptr)
+        g.extract_batch_device(bufs[i].ptr, B, rows, cols, cols, rows * cols, d_k.ptr, d_d.ptr, cap, d_n.ptr)
+        g.synchronize()
+        n3 = d_n.download(np.int32, B); k3 = d_k.download(KP_DTYPE, B * cap).reshape(B, cap)
+        dd = d_d.download(np.uint8, B * cap * 32).reshape(B, cap, 32)
+        for j in range(B):
+            _assert_same_result(int(n3[j]), k3[j, :n3[j]], dd[j, :n3[j]], *refs[2 * i + j])
+
+    run(0, 1)       # builds batch 1's pyramid beside batch 0
+    run(1, 2)       # consumes it, prefetches batch 2
+    run(2, 0)       # consumes, prefetches batch 0
+    run(1, None)    # wrong guess: batch 1 is extracted, the prefetched pyramid of batch 0 is dropped
+    run(0, 0)       # same buffer announced as its own successor (the bench's steady state)
+    run(0, None)    # consumes
+    run(2, None)    # plain call
