@@ -129,11 +129,6 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torchrun (also with one rank): exercise RCCL
-    if world > 1 or launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
     rows, cols, B = 720, 1280, args.batch
     # synthetic sequence: this rank's shard of one global batch (distinct frames per rank)
     frames_idx = list(dvdist.shard_range(world, rank, B))
@@ -150,10 +145,16 @@ def main():
     NP = max(1, args.pipelines)
     pipes = []
     for p in range(NP):
+        # The pipeline overlaps kernels on four streams (main, blur, next-batch pyramid, boundary exchange).  All four are
+        # created by the library, back to back, BEFORE RCCL comes up and none comes from torch's stream pool: HIP maps streams
+        # to hardware queues in creation order, and with the exchange on a torch pool stream or RCCL initialised first the
+        # same job ran anywhere between 48 k and 72 k frames/s depending on GPU_MAX_HW_QUEUES (kernels alone on the GPU took
+        # 1.3-2.5x longer); like this it is 71 k for 4, 6, 8 and 12 queues.
         orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
+        xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # boundary exchange
+        ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
         mat = dvslam_amd.BFMatcher(device=local)
-        ts = torch.cuda.Stream(device=dev)
-        orb.set_stream(ts.cuda_stream); mat.set_stream(ts.cuda_stream)
+        mat.set_stream(ts.cuda_stream)
         cap = orb.capacity
         with torch.cuda.stream(ts):
             # two output sets used alternately: step i writes set i % 2 and its first match job reads the LAST frame of set
@@ -163,8 +164,16 @@ def main():
                         n=[torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)],
                         idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
                         dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
-        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), xstream=torch.cuda.Stream(device=dev),
+        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), xstream=xs,
                           xdone=torch.cuda.Event(), count=0, prev=None, **bufs))
+    torch.cuda.synchronize()
+    # RCCL comes up AFTER the pipeline's handles and streams exist (see the stream comment above)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torchrun (also with one rank): exercise RCCL
+    if world > 1 or launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
     cap = pipes[0]["orb"].capacity
     torch.cuda.synchronize()
     state = {"i": 0}
@@ -221,6 +230,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no synchronisation inside)
     sync_all()
     torch.cuda.synchronize()
     if world > 1:
@@ -274,7 +284,7 @@ def main():
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
             "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
             "stage_ms_per_launch_isolated": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
-            "pipelines_per_gpu": NP,
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4), "pipelines_per_gpu": NP,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]

@@ -66,6 +66,29 @@ int32_t dvs_device_count(void) {
   return n;
 }
 
+dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_stream) {
+  DVS_ARG(out_stream);
+  *out_stream = nullptr;
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  if (high_priority) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    DVS_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+  } else {
+    DVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  }
+  *out_stream = (void*)s;
+  return DVS_OK;
+}
+dvs_status dvs_stream_destroy(void* stream) {
+  if (!stream) return DVS_OK;
+  DVS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  DVS_HIP(hipStreamDestroy((hipStream_t)stream));
+  return DVS_OK;
+}
+
 dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap) {
   DVS_ARG(buf && cap > 0);
   buf[0] = 0;

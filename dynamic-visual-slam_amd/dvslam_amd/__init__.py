@@ -5,7 +5,7 @@ this package only mirrors the reference's three call signatures in Python so the
 like calls into the reference (ORBextractor.hpp:50-60, cv::BFMatcher::match, SlidingWindowBA).
 There is NO CPU fallback: every class raises if the library or a gfx950 device is missing.
 """
-from ._lib import lib, DvsError, KP_DTYPE, device_count, build_library  # noqa: F401
+from ._lib import lib, DvsError, KP_DTYPE, device_count, build_library, stream_create, stream_destroy  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
 from .matcher import BFMatcher  # noqa: F401
 from .ba import BAProblem, SlidingWindowBA  # noqa: F401

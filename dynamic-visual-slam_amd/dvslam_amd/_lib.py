@@ -68,6 +68,8 @@ def lib():
     L.dvs_orb_level_size.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
     L.dvs_orb_extract_batch.argtypes = [vp, vp, i32, i32, i32, sz, vp, vp, i32, vp]
+    L.dvs_stream_create.argtypes = [i32, i32, C.POINTER(vp)]
+    L.dvs_stream_destroy.argtypes = [vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
@@ -113,6 +115,17 @@ def check(code):
 
 def device_count():
     return lib().dvs_device_count()
+
+
+def stream_create(device=0, high_priority=False):
+    """raw hipStream_t (int) created by the library (wrap with torch.cuda.ExternalStream when torch should use it)"""
+    out = C.c_void_p()
+    check(lib().dvs_stream_create(device, 1 if high_priority else 0, C.byref(out)))
+    return int(out.value)
+
+
+def stream_destroy(stream):
+    check(lib().dvs_stream_destroy(stream))
 
 
 def ptr(a):

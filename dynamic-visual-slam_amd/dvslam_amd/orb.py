@@ -113,6 +113,10 @@ class ORBextractor:
     def synchronize(self):
         check(self._L.dvs_orb_synchronize(self._h))
 
+    def get_stream(self):
+        """the hipStream_t (int) the handle currently enqueues on (its own stream unless set_stream was called)"""
+        return int(self._L.dvs_orb_get_stream(self._h) or 0)
+
     def set_stream(self, stream_ptr):
         check(self._L.dvs_orb_set_stream(self._h, stream_ptr))
 

@@ -40,6 +40,11 @@ enum {
 
 const char* dvs_last_error(void);
 int32_t dvs_device_count(void);
+/* A plain HIP stream for the caller's side work (e.g. the multi-GPU boundary exchange), created by this library so that it
+ * can be made right after the handles: HIP maps streams to hardware queues in creation order, and the path's concurrent
+ * streams should be neighbours in that order ("Streams and hardware queues"). */
+dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_stream);
+dvs_status dvs_stream_destroy(void* stream);
 /* "gfx950" etc. for the given device, "" on error */
 dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap);
 
