@@ -260,6 +260,295 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
   }
 }
 
+
+// =============================================================================================================================
+// Device-resident Levenberg-Marquardt step: the linear algebra of dvs_ba_solve — Jacobi scaling, LM
+// diagonal, landmark elimination (Schur complement), the reduced camera system's Cholesky, back-substitution, the model cost
+// change and the candidate point — as kernels over the buffers k_ba_eval / k_ba_reduce leave in HBM.  The host keeps only the
+// trust-region decisions and reads one 64-byte status record per trial step.  All reductions run in a fixed order.
+// =============================================================================================================================
+struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; };
+
+__device__ __forceinline__ double block_sum_fixed(double v, double* sm) {  // 256 threads, fixed tree
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sm[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) sm[tid] += sm[tid + s];
+    __syncthreads();
+  }
+  return sm[0];
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+__device__ __forceinline__ void quat_plus_dev(const double* x, const double* d, double* o) {  // EigenQuaternionManifold::Plus
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { for (int i = 0; i < 4; i++) o[i] = x[i]; return; }
+  const double sn = sin(nd) / nd;
+  const double dx = sn * d[0], dy = sn * d[1], dz = sn * d[2], dw = cos(nd);
+  o[3] = dw * x[3] - dx * x[0] - dy * x[1] - dz * x[2];
+  o[0] = dw * x[0] + dx * x[3] + dy * x[2] - dz * x[1];
+  o[1] = dw * x[1] + dy * x[3] + dz * x[0] - dx * x[2];
+  o[2] = dw * x[2] + dz * x[3] + dx * x[1] - dy * x[0];
+}
+
+// Jacobi scaling 1 / (1 + sqrt(H_jj)), fixed at the first Jacobian
+__global__ void k_lm_scale(int K, int L, const double* __restrict__ Hpp, const double* __restrict__ Hll, double* __restrict__ scale) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < 6 * K) { const int c = j / 6, a = j - 6 * c; scale[j] = 1.0 / (1.0 + sqrt(Hpp[36 * (size_t)c + 7 * a])); }
+  else if (j < 6 * K + 3 * L) { const int k = j - 6 * K, l = k / 3, a = k - 3 * l; scale[j] = 1.0 / (1.0 + sqrt(Hll[9 * (size_t)l + 4 * a])); }
+}
+
+// per landmark: LM diagonal (when refreshed), (V + D/radius)^-1, the scaled W blocks and Y = W V^-1; per camera: its diagonal
+__global__ __launch_bounds__(256) void k_lm_landmarks(int K, int L, const double* __restrict__ Hpp, const double* __restrict__ Hll,
+                                                      const double* __restrict__ W, const int* __restrict__ lmStart,
+                                                      const int* __restrict__ lmObs, const int* __restrict__ cam,
+                                                      const double* __restrict__ scale, double* __restrict__ diag,
+                                                      const unsigned char* __restrict__ active, double radius, int refresh,
+                                                      double* __restrict__ Vinv, double* __restrict__ Ws, double* __restrict__ Y,
+                                                      LmStatus* __restrict__ st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) {
+    const int c = i - L;
+    if (c < K && refresh)
+      for (int a = 0; a < 6; a++) { const int j = 6 * c + a; diag[j] = clampd(Hpp[36 * (size_t)c + 7 * a] * scale[j] * scale[j], 1e-6, 1e32); }
+    return;
+  }
+  const int l = i, j0 = 6 * K + 3 * l;
+  if (refresh) for (int a = 0; a < 3; a++) diag[j0 + a] = clampd(Hll[9 * (size_t)l + 4 * a] * scale[j0 + a] * scale[j0 + a], 1e-6, 1e32);
+  if (!active[j0]) return;
+  double V[9];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) V[3 * a + b] = Hll[9 * (size_t)l + 3 * a + b] * scale[j0 + a] * scale[j0 + b];
+  for (int a = 0; a < 3; a++) V[4 * a] += diag[j0 + a] / radius;
+  const double a_ = V[0], b_ = V[1], c_ = V[2], d_ = V[3], e_ = V[4], f_ = V[5], g_ = V[6], h_ = V[7], i_ = V[8];
+  const double det = a_ * (e_ * i_ - f_ * h_) - b_ * (d_ * i_ - f_ * g_) + c_ * (d_ * h_ - e_ * g_);
+  if (det == 0 || !isfinite(det)) { st->ok = 0; return; }
+  const double id = 1.0 / det;
+  double Vi[9];
+  Vi[0] = (e_ * i_ - f_ * h_) * id; Vi[1] = (c_ * h_ - b_ * i_) * id; Vi[2] = (b_ * f_ - c_ * e_) * id;
+  Vi[3] = (f_ * g_ - d_ * i_) * id; Vi[4] = (a_ * i_ - c_ * g_) * id; Vi[5] = (c_ * d_ - a_ * f_) * id;
+  Vi[6] = (d_ * h_ - e_ * g_) * id; Vi[7] = (b_ * g_ - a_ * h_) * id; Vi[8] = (a_ * e_ - b_ * d_) * id;
+  for (int k = 0; k < 9; k++) Vinv[9 * (size_t)l + k] = Vi[k];
+  for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
+    const int p = lmObs[e], c = cam[p];
+    for (int a = 0; a < 6; a++) {
+      double w[3];
+      for (int b = 0; b < 3; b++) { w[b] = W[18 * (size_t)p + 3 * a + b] * scale[6 * c + a] * scale[j0 + b]; Ws[18 * (size_t)p + 3 * a + b] = w[b]; }
+      for (int b = 0; b < 3; b++) Y[18 * (size_t)p + 3 * a + b] = w[0] * Vi[b] + w[1] * Vi[3 + b] + w[2] * Vi[6 + b];
+    }
+  }
+}
+
+// reduced camera system, one workgroup per 6x6 block (ci, ck):  S = (H_pp + D/radius) - sum_l Y_l,ci W_l,ck^T,  rhs likewise
+__global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int* __restrict__ slotCam, const int* __restrict__ obsOf,
+                                                  const unsigned char* __restrict__ active, const double* __restrict__ Hpp,
+                                                  const double* __restrict__ g, const double* __restrict__ scale,
+                                                  const double* __restrict__ diag, double radius, const double* __restrict__ Ws,
+                                                  const double* __restrict__ Y, double* __restrict__ S, double* __restrict__ rhs) {
+  __shared__ double sm[256];
+  const int ci = blockIdx.x, ck = blockIdx.y;
+  const int cI = slotCam[ci], cK = slotCam[ck];
+  double acc[36], r[6];
+  for (int k = 0; k < 36; k++) acc[k] = 0.0;
+  for (int k = 0; k < 6; k++) r[k] = 0.0;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const int j0 = 6 * K + 3 * l;
+    if (!active[j0]) continue;
+    const int e = obsOf[(size_t)l * K + cI], f = obsOf[(size_t)l * K + cK];
+    if (e < 0 || f < 0) continue;
+    const double* y = Y + 18 * (size_t)e;
+    const double* w = Ws + 18 * (size_t)f;
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < 6; b++) acc[6 * a + b] += y[3 * a] * w[3 * b] + y[3 * a + 1] * w[3 * b + 1] + y[3 * a + 2] * w[3 * b + 2];
+    if (ci == ck) {
+      const double gl0 = g[j0] * scale[j0], gl1 = g[j0 + 1] * scale[j0 + 1], gl2 = g[j0 + 2] * scale[j0 + 2];
+      for (int a = 0; a < 6; a++) r[a] += y[3 * a] * gl0 + y[3 * a + 1] * gl1 + y[3 * a + 2] * gl2;
+    }
+  }
+  for (int k = 0; k < 36; k++) {
+    const double tot = block_sum_fixed(acc[k], sm);
+    if (threadIdx.x == 0) {
+      const int a = k / 6, b = k - 6 * a;
+      double v = 0.0;
+      if (ci == ck) {
+        v = Hpp[36 * (size_t)cI + 6 * a + b] * scale[6 * cI + a] * scale[6 * cI + b];
+        if (a == b) v += diag[6 * cI + a] / radius;
+      }
+      S[(size_t)(6 * ci + a) * n + 6 * ck + b] = v - tot;
+    }
+  }
+  if (ci == ck)
+    for (int a = 0; a < 6; a++) {
+      const double tot = block_sum_fixed(r[a], sm);
+      if (threadIdx.x == 0) rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a] - tot;
+    }
+}
+
+// dense Cholesky + two triangular solves of the n x n reduced system in LDS; every dot product runs in the k order of the
+// host routine (chol_solve), one thread per row of the current column.  Writes the (not yet negated) camera steps.
+__global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
+                                                 const double* __restrict__ rhs, double* __restrict__ step, LmStatus* __restrict__ st) {
+  extern __shared__ double lds[];
+  double* A = lds;
+  double* b = lds + (size_t)n * n;
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n * n; i += 256) A[i] = S[i];
+  for (int i = tid; i < n; i += 256) b[i] = rhs[i];
+  for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < n; j++) {
+    if (tid == 0) {
+      double d = A[(size_t)j * n + j];
+      for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+      if (!(d > 0)) bad = 1;
+      A[(size_t)j * n + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (bad) break;
+    const double d = A[(size_t)j * n + j];
+    for (int i = j + 1 + tid; i < n; i += 256) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+    __syncthreads();
+  }
+  if (bad) { if (tid == 0) st->ok = 0; return; }
+  if (tid == 0) {
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) step[6 * slotCam[i / 6] + i % 6] = b[i];
+}
+
+// landmark steps by back-substitution (already negated), and each landmark's share of step.g and step^T H step
+__global__ __launch_bounds__(256) void k_lm_backsub(int K, int L, const double* __restrict__ Hll, const double* __restrict__ g,
+                                                    const int* __restrict__ lmStart, const int* __restrict__ lmObs,
+                                                    const int* __restrict__ cam, const double* __restrict__ scale,
+                                                    const unsigned char* __restrict__ active, const double* __restrict__ Vinv,
+                                                    const double* __restrict__ Ws, double* __restrict__ step,
+                                                    double* __restrict__ lmPart, LmStatus* __restrict__ st) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const int j0 = 6 * K + 3 * l;
+  double sg = 0.0, sHs = 0.0;
+  if (!active[j0]) {
+    for (int a = 0; a < 3; a++) step[j0 + a] = 0.0;
+  } else {
+    double b[3] = {g[j0] * scale[j0], g[j0 + 1] * scale[j0 + 1], g[j0 + 2] * scale[j0 + 2]};
+    for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
+      const int p = lmObs[e], c = cam[p];
+      for (int m = 0; m < 3; m++) for (int a = 0; a < 6; a++) b[m] -= Ws[18 * (size_t)p + 3 * a + m] * step[6 * c + a];
+    }
+    const double* Vi = Vinv + 9 * (size_t)l;
+    double sl[3];
+    for (int a = 0; a < 3; a++) sl[a] = -(Vi[3 * a] * b[0] + Vi[3 * a + 1] * b[1] + Vi[3 * a + 2] * b[2]);
+    if (!(isfinite(sl[0]) && isfinite(sl[1]) && isfinite(sl[2]))) st->finite = 0;
+    for (int a = 0; a < 3; a++) { step[j0 + a] = sl[a]; sg += sl[a] * g[j0 + a] * scale[j0 + a]; }
+    for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) sHs += sl[a] * scale[j0 + a] * Hll[9 * (size_t)l + 3 * a + bb] * scale[j0 + bb] * sl[bb];
+    for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {  // cross terms 2 step_c^T W step_l with the NEGATED camera step
+      const int p = lmObs[e], c = cam[p];
+      for (int a = 0; a < 6; a++) for (int bb = 0; bb < 3; bb++) sHs += 2.0 * (-step[6 * c + a]) * Ws[18 * (size_t)p + 3 * a + bb] * sl[bb];
+    }
+  }
+  lmPart[2 * (size_t)l] = sg; lmPart[2 * (size_t)l + 1] = sHs;
+}
+
+// negate the camera steps, add the camera terms, reduce: model_cost_change = -(step.g + step^T H step / 2)
+__global__ __launch_bounds__(256) void k_lm_model(int K, int L, const double* __restrict__ Hpp, const double* __restrict__ g,
+                                                  const double* __restrict__ scale, double* __restrict__ step,
+                                                  const double* __restrict__ lmPart, LmStatus* __restrict__ st) {
+  __shared__ double sm[256];
+  const int tid = threadIdx.x;
+  for (int j = tid; j < 6 * K; j += 256) step[j] = -step[j];
+  __syncthreads();
+  double sg = 0.0, sHs = 0.0, fin = 0.0;
+  for (int j = tid; j < 6 * K; j += 256) { sg += step[j] * g[j] * scale[j]; if (!isfinite(step[j])) fin = 1.0; }
+  for (int c = tid; c < K; c += 256)
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
+      sHs += step[6 * c + a] * scale[6 * c + a] * Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + b] * step[6 * c + b];
+  for (int l = tid; l < L; l += 256) { sg += lmPart[2 * (size_t)l]; sHs += lmPart[2 * (size_t)l + 1]; }
+  const double tg = block_sum_fixed(sg, sm), th = block_sum_fixed(sHs, sm), tf = block_sum_fixed(fin, sm);
+  if (tid == 0) {
+    if (tf > 0.0) st->finite = 0;
+    st->model_change = -(tg + 0.5 * th);
+  }
+}
+
+// candidate point x + Plus(step * scale) into the evaluation buffers; partial sums of |x - cand|^2 and |x|^2 per workgroup
+__global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double* __restrict__ q0, const double* __restrict__ t0,
+                                                      const double* __restrict__ X0, const double* __restrict__ step,
+                                                      const double* __restrict__ scale, const unsigned char* __restrict__ active,
+                                                      double* __restrict__ q, double* __restrict__ t, double* __restrict__ X,
+                                                      double* __restrict__ part) {
+  __shared__ double sm[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double sn = 0.0, xn = 0.0;
+  if (i < K) {
+    const int c = i;
+    double cq[4], ct[3];
+    if (active[6 * c]) {
+      const double d[3] = {step[6 * c] * scale[6 * c], step[6 * c + 1] * scale[6 * c + 1], step[6 * c + 2] * scale[6 * c + 2]};
+      quat_plus_dev(q0 + 4 * c, d, cq);
+      for (int k = 0; k < 3; k++) ct[k] = t0[3 * c + k] + step[6 * c + 3 + k] * scale[6 * c + 3 + k];
+      for (int k = 0; k < 4; k++) { sn += (q0[4 * c + k] - cq[k]) * (q0[4 * c + k] - cq[k]); xn += q0[4 * c + k] * q0[4 * c + k]; }
+      for (int k = 0; k < 3; k++) { sn += (t0[3 * c + k] - ct[k]) * (t0[3 * c + k] - ct[k]); xn += t0[3 * c + k] * t0[3 * c + k]; }
+    } else {
+      for (int k = 0; k < 4; k++) cq[k] = q0[4 * c + k];
+      for (int k = 0; k < 3; k++) ct[k] = t0[3 * c + k];
+    }
+    for (int k = 0; k < 4; k++) q[4 * c + k] = cq[k];
+    for (int k = 0; k < 3; k++) t[3 * c + k] = ct[k];
+  } else if (i < K + L) {
+    const int l = i - K, j0 = 6 * K + 3 * l;
+    for (int k = 0; k < 3; k++) {
+      double v = X0[3 * l + k];
+      if (active[j0]) { const double c = v + step[j0 + k] * scale[j0 + k]; sn += (v - c) * (v - c); xn += v * v; v = c; }
+      X[3 * l + k] = v;
+    }
+  }
+  const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __restrict__ part, const double* __restrict__ cost,
+                                                  LmStatus* __restrict__ st) {
+  __shared__ double sm[256];
+  double sn = 0.0, xn = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { sn += part[2 * i]; xn += part[2 * i + 1]; }
+  const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
+  if (threadIdx.x == 0) { st->sn = a; st->xn = b; st->cand_cost = *cost; }
+}
+
+// Ceres' gradient max-norm: |x - Plus(x, -g)|_inf over the active blocks, and the cost of the accepted point
+__global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __restrict__ q0, const double* __restrict__ g,
+                                                 const unsigned char* __restrict__ active, const double* __restrict__ cost,
+                                                 LmStatus* __restrict__ st) {
+  __shared__ double sm[256];
+  const int tid = threadIdx.x;
+  double m = 0.0;
+  for (int c = tid; c < K; c += 256) if (active[6 * c]) {
+    const double d[3] = {-g[6 * c], -g[6 * c + 1], -g[6 * c + 2]};
+    double qp[4];
+    quat_plus_dev(q0 + 4 * c, d, qp);
+    for (int i = 0; i < 4; i++) m = fmax(m, fabs(q0[4 * c + i] - qp[i]));
+    for (int i = 0; i < 3; i++) m = fmax(m, fabs(g[6 * c + 3 + i]));
+  }
+  for (int l = tid; l < L; l += 256) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) m = fmax(m, fabs(g[6 * K + 3 * l + i]));
+  __syncthreads();
+  sm[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
+  if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; }
+}
+
+__global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; }
+
 }  // namespace dvs
 
 using namespace dvs;
@@ -282,6 +571,14 @@ struct dvs_ba {
   double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr, *d_costCam = nullptr;
   int* d_ticket = nullptr;
   double *d_raw = nullptr;  // R*(2+8+6+6)
+  // device LM (dvs_ba_solve_device): accepted point, scaling, LM diagonal, step, per-landmark inverses, scaled W, Y = W V^-1,
+  // reduced system, observation-of-(landmark, camera) table
+  double *d_q0 = nullptr, *d_t0 = nullptr, *d_X0 = nullptr, *d_scale = nullptr, *d_diag = nullptr, *d_step = nullptr, *d_Vinv = nullptr,
+         *d_Ws = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_lmPart = nullptr, *d_normPart = nullptr;
+  int *d_obsOf = nullptr, *d_slotCam = nullptr;
+  unsigned char* d_active = nullptr;
+  dvs::LmStatus* d_status = nullptr;
+  dvs::LmStatus* h_status = nullptr;  // pinned
 };
 
 namespace {
@@ -290,6 +587,12 @@ void ba_free(dvs_ba* h) {
   void* ptrs[] = {h->d_q, h->d_t, h->d_X, h->d_uv, h->d_cam, h->d_lm, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_pf,
                   h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw, h->d_costCam, h->d_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  void* lmp[] = {h->d_q0, h->d_t0, h->d_X0, h->d_scale, h->d_diag, h->d_step, h->d_Vinv, h->d_Ws, h->d_Y, h->d_S, h->d_rhs, h->d_lmPart,
+                 h->d_normPart, h->d_obsOf, h->d_slotCam, h->d_active, h->d_status};
+  for (void* p : lmp) if (p) (void)hipFree(p);
+  if (h->h_status) (void)hipHostFree(h->h_status);
+  h->d_q0 = h->d_t0 = h->d_X0 = h->d_scale = h->d_diag = h->d_step = h->d_Vinv = h->d_Ws = h->d_Y = h->d_S = h->d_rhs = h->d_lmPart = h->d_normPart = nullptr;
+  h->d_obsOf = h->d_slotCam = nullptr; h->d_active = nullptr; h->d_status = nullptr; h->h_status = nullptr;
   h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
   h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
   h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr; h->d_ticket = nullptr;
@@ -746,6 +1049,140 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double g
   h->q = q; h->t = t; h->X = X;
   DVS_TRY(upload_params(h, q, t, X));
   DVS_HIP(hipStreamSynchronize(h->stream));
+  return DVS_OK;
+}
+
+// The same trust-region loop as dvs_ba_solve with every O(R) step on the device (kernels above): per trial step the host
+// enqueues system -> Cholesky -> back-substitution -> candidate -> cost evaluation, reads ONE status record, decides.
+dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, double gtol, double ptol, dvs_ba_summary* summary) {
+  DVS_ARG(h && summary && max_iterations >= 0);
+  memset(summary, 0, sizeof(*summary));
+  summary->termination = 2;
+  DVS_HIP(hipSetDevice(h->device));
+  const int K = h->K, L = h->L, R = h->R, NT = 6 * K + 3 * L;
+  if (R == 0) { set_error("no observations"); return DVS_ERR_ARG; }
+  // active blocks, camera slots, observation table
+  std::vector<unsigned char> lmUsed(L, 0), camUsed(K, 0), active(NT, 0);
+  for (int p = 0; p < R; p++) { lmUsed[h->lm[p]] = 1; camUsed[h->cam[p]] = 1; }
+  std::vector<int> slotCam;
+  for (int c = 0; c < K; c++) if (!h->pose_fixed[c] && camUsed[c]) { slotCam.push_back(c); for (int a = 0; a < 6; a++) active[6 * c + a] = 1; }
+  for (int l = 0; l < L; l++) if (!h->lm_fixed[l] && lmUsed[l]) for (int a = 0; a < 3; a++) active[6 * K + 3 * l + a] = 1;
+  const int nc = (int)slotCam.size(), n = 6 * nc;
+  if (K > 64 || nc > 16 || nc == 0) {
+    set_error("dvs_ba_solve_device handles sliding windows (<= 64 cameras, 1..16 of them free); this problem has %d / %d", K, nc);
+    return DVS_ERR_UNSUPPORTED;
+  }
+  std::vector<int> obsOf((size_t)L * K, -1);
+  for (int l = 0; l < L; l++)
+    for (int e = h->lmStart[l]; e < h->lmStart[l + 1]; e++) {
+      const int p = h->lmObs[e];
+      int& slot = obsOf[(size_t)l * K + h->cam[p]];
+      if (slot >= 0) { set_error("landmark %d is observed twice in camera %d: use dvs_ba_solve", l, h->cam[p]); return DVS_ERR_UNSUPPORTED; }
+      slot = p;
+    }
+  hipStream_t st = h->stream;
+  if (!h->d_status) {
+    const size_t Rz = std::max(R, 1);
+    DVS_HIP(hipMalloc((void**)&h->d_q0, (size_t)std::max(K, 1) * 32)); DVS_HIP(hipMalloc((void**)&h->d_t0, (size_t)std::max(K, 1) * 24));
+    DVS_HIP(hipMalloc((void**)&h->d_X0, (size_t)std::max(L, 1) * 24));
+    DVS_HIP(hipMalloc((void**)&h->d_scale, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_diag, (size_t)NT * 8));
+    DVS_HIP(hipMalloc((void**)&h->d_step, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_Vinv, (size_t)std::max(L, 1) * 72));
+    DVS_HIP(hipMalloc((void**)&h->d_Ws, Rz * 144)); DVS_HIP(hipMalloc((void**)&h->d_Y, Rz * 144));
+    DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, 96 * 8));
+    DVS_HIP(hipMalloc((void**)&h->d_lmPart, (size_t)std::max(L, 1) * 16));
+    DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
+    DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
+    DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
+    DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
+    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (96 * 96 + 96) * 8));
+  }
+  DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_active, active.data(), (size_t)NT, hipMemcpyHostToDevice, st));
+  DVS_TRY(upload_params(h, h->q, h->t, h->X));
+  DVS_HIP(hipMemcpyAsync(h->d_q0, h->d_q, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_X0, h->d_X, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+  LmStatus* S = h->h_status;
+  auto fetch_status = [&]() -> dvs_status {
+    DVS_HIP(hipMemcpyAsync(S, h->d_status, sizeof(LmStatus), hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+    return DVS_OK;
+  };
+  auto evaluate_full = [&]() -> dvs_status {  // Jacobian blocks, gradient, cost of the point in the evaluation buffers
+    DVS_TRY(enqueue_eval(h, 1 | 2, true));
+    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status);
+    return fetch_status();
+  };
+  hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
+  DVS_TRY(evaluate_full());
+  double x_cost = S->x_cost, gmax = S->gmax;
+  summary->initial_cost = x_cost;
+  double min_cost = x_cost;
+  hipLaunchKernelGGL(k_lm_scale, dim3((NT + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_scale);
+
+  double radius = 1e4, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  int iteration = 0, invalid = 0;
+  const int nparts = (K + L + 255) / 256;
+  summary->termination = 1;
+  while (true) {
+    if (iteration >= max_iterations) { summary->termination = 1; break; }
+    if (gmax <= gtol) { summary->termination = 0; break; }
+    if (radius < 1e-32) { summary->termination = 0; break; }
+    iteration++;
+    hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
+    hipLaunchKernelGGL(k_lm_landmarks, dim3((L + K + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_W, h->d_lmStart, h->d_lmObs,
+                       h->d_cam, h->d_scale, h->d_diag, h->d_active, radius, reuse_diagonal ? 0 : 1, h->d_Vinv, h->d_Ws, h->d_Y, h->d_status);
+    reuse_diagonal = true;
+    hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
+                       h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
+    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), ((size_t)n * n + n) * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
+    hipLaunchKernelGGL(k_lm_backsub, dim3((L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
+                       h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
+    hipLaunchKernelGGL(k_lm_model, dim3(1), dim3(256), 0, st, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step, h->d_lmPart, h->d_status);
+    hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,
+                       h->d_q, h->d_t, h->d_X, h->d_normPart);
+    DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
+    hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, h->d_status);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(fetch_status());
+    const bool valid = S->ok && S->finite && S->model_change > 0.0;
+    if (!valid) {
+      if (++invalid >= 5) { summary->termination = 2; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;
+      continue;
+    }
+    invalid = 0;
+    if (sqrt(S->sn) <= ptol * (sqrt(S->xn) + ptol)) { summary->termination = 0; break; }
+    const double cost_change = x_cost - S->cand_cost;
+    if (fabs(cost_change) <= ftol * x_cost) { summary->termination = 0; break; }
+    const double rel = cost_change / S->model_change;
+    if (rel > 1e-3) {
+      DVS_HIP(hipMemcpyAsync(h->d_q0, h->d_q, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
+      DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
+      DVS_HIP(hipMemcpyAsync(h->d_X0, h->d_X, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+      DVS_TRY(evaluate_full());
+      x_cost = S->x_cost; gmax = S->gmax;
+      summary->num_successful_steps++;
+      min_cost = std::min(min_cost, x_cost);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+    }
+  }
+  summary->num_iterations = iteration;
+  summary->final_cost = min_cost;
+  // the accepted point becomes the problem's parameters (host mirror and evaluation buffers)
+  DVS_HIP(hipMemcpyAsync(h->d_q, h->d_q0, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_t, h->d_t0, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+  DVS_HIP(hipMemcpyAsync(h->q.data(), h->d_q0, (size_t)K * 32, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(h->t.data(), h->d_t0, (size_t)K * 24, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(h->X.data(), h->d_X0, (size_t)L * 24, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
   return DVS_OK;
 }
 

@@ -101,6 +101,7 @@ def lib():
         L.dvs_ba_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
         L.dvs_ba_evaluate_device.argtypes = [vp, i32]
         L.dvs_ba_solve.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(BaSummary)]
+        L.dvs_ba_solve_device.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(BaSummary)]
         L.dvs_ba_get_parameters.argtypes = [vp, vp, vp, vp]
         L.dvs_ba_pose_from_rt.argtypes = [vp, vp, vp, vp]
         L.dvs_ba_pose_to_rt.argtypes = [vp, vp, vp, vp]

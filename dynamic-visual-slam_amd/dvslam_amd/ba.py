@@ -1,6 +1,6 @@
 import ctypes as C
 import numpy as np
-from ._lib import lib, check, ptr, BaSummary
+from ._lib import lib, check, ptr, BaSummary, DvsError
 
 TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
 
@@ -64,6 +64,12 @@ class BAProblem:
         check(self._L.dvs_ba_solve(self._h, max_iterations, ftol, gtol, ptol, C.byref(s)))
         return s
 
+    def solve_device(self, max_iterations=10, ftol=1e-6, gtol=1e-10, ptol=1e-8):
+        """dvs_ba_solve_device: the same trust-region loop with the Schur complement / Cholesky / back-substitution on the GPU"""
+        s = BaSummary()
+        check(self._L.dvs_ba_solve_device(self._h, max_iterations, ftol, gtol, ptol, C.byref(s)))
+        return s
+
     def parameters(self):
         q = np.zeros((self.K, 4)); t = np.zeros((self.K, 3)); X = np.zeros((self.L, 3))
         check(self._L.dvs_ba_get_parameters(self._h, ptr(q), ptr(t), ptr(X)))
@@ -111,7 +117,12 @@ class SlidingWindowBA:
                     lm_idx=np.array(lm, np.int32), uv=np.array(uv, np.float64), pose_fixed=pose_fixed, lm_fixed=np.array(fixed, np.uint8),
                     fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy, sigma=self.sigma, huber=1.345)
         p = BAProblem(prob, self.device)
-        s = p.solve(max_iterations, 1e-6, 1e-10, 1e-8)                             # options at :839-847
+        try:                                                                        # options at :839-847
+            s = p.solve_device(max_iterations, 1e-6, 1e-10, 1e-8)
+        except DvsError as e:                                                       # shapes outside the device solver's window limits
+            if e.code != -2:
+                raise
+            s = p.solve(max_iterations, 1e-6, 1e-10, 1e-8)
         res["success"] = s.termination == 0                                        # :860
         res["final_cost"] = s.final_cost
         res["iterations_completed"] = s.num_successful_steps                       # :862

@@ -117,8 +117,12 @@ class SlidingWindowBA {
     dvs_ba_summary s{};
     bool ok = dvs_ba_create(device_, &h) == DVS_OK &&
               dvs_ba_set_problem(h, K, q.data(), t.data(), L, X.data(), (int)cam.size(), cam.data(), lmi.data(), uv.data(), pose_fixed.data(),
-                                 lm_fixed.data(), fx_, fy_, cx_, cy_, sigma_, 1.345) == DVS_OK &&
-              dvs_ba_solve(h, max_iterations, 1e-6, 1e-10, 1e-8, &s) == DVS_OK;
+                                 lm_fixed.data(), fx_, fy_, cx_, cy_, sigma_, 1.345) == DVS_OK;
+    if (ok) {  // linear algebra on the device for sliding-window shapes, GPU evaluation + host Schur complement otherwise
+      dvs_status st = dvs_ba_solve_device(h, max_iterations, 1e-6, 1e-10, 1e-8, &s);
+      if (st == DVS_ERR_UNSUPPORTED) st = dvs_ba_solve(h, max_iterations, 1e-6, 1e-10, 1e-8, &s);
+      ok = st == DVS_OK;
+    }
     if (!ok) {  // the reference never throws: exceptions become success=false + message (:890-895)
       res.message = std::string("Bundle adjustment exception: ") + dvs_last_error();
       res.optimization_time = elapsed();

@@ -238,6 +238,13 @@ dvs_status dvs_ba_evaluate_device(dvs_ba* h, int32_t iters);
  * bundle_adjustment.hpp:839-847.  Parameters are updated in place; read them back with dvs_ba_get_parameters. */
 dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double function_tolerance, double gradient_tolerance,
                         double parameter_tolerance, dvs_ba_summary* summary);
+/* The same solve with the linear algebra on the device (Jacobi scaling, LM diagonal, Schur complement, Cholesky of the
+ * reduced camera system, back-substitution, model cost change, candidate point): one 64-byte status record crosses PCIe per
+ * trial step instead of the W blocks.  Same trust-region decisions, fixed-order reductions; sums are associated differently
+ * from dvs_ba_solve, so costs agree to rounding (tests: 1e-9 relative), not bit for bit.  Sliding-window shapes only:
+ * <= 64 cameras, 1..16 of them free, a landmark observed at most once per camera; DVS_ERR_UNSUPPORTED otherwise. */
+dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double function_tolerance, double gradient_tolerance,
+                               double parameter_tolerance, dvs_ba_summary* summary);
 dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X);
 /* CameraPose::fromRt / toRt (bundle_adjustment.hpp:138-165, 192-212): caller-convention (R row-major 3x3, t) <->
  * optimiser (q_wxyz, translation).  Host arithmetic used by the SlidingWindowBA adapter. */

@@ -65,12 +65,15 @@ def test_empty_and_degenerate_inputs(gpu, oracle):
     assert out["message"] == "No valid observation constraints" and not out["success"]
 
 
+@pytest.mark.parametrize("solver", ["host_schur", "device"])
 @pytest.mark.parametrize("K,L,seed,iters", [(5, 200, 7, 60), (10, 2000, 42, 20), (3, 60, 9, 10)])
-def test_lm_solve_parity(gpu, oracle, K, L, seed, iters):
+def test_lm_solve_parity(gpu, oracle, K, L, seed, iters, solver):
+    """dvs_ba_solve (GPU evaluation + host Schur) and dvs_ba_solve_device (everything but the decisions on the GPU) against
+    the oracle's restatement of the Ceres trust-region loop"""
     from dvslam_amd import BAProblem
     P = synth.make_ba_problem(K=K, L=L, seed=seed)
     g = BAProblem(P); o = oracle.OracleBA(P)
-    s = g.solve(iters); s2 = o.solve(iters)
+    s = (g.solve if solver == "host_schur" else g.solve_device)(iters); s2 = o.solve(iters)
     assert s.termination == s2.termination and s.num_successful_steps == s2.num_successful_steps and s.num_iterations == s2.num_iterations
     assert abs(s.initial_cost - s2.initial_cost) <= RTOL * s2.initial_cost
     assert abs(s.final_cost - s2.final_cost) <= 1e-6 * s2.final_cost, "BA final cost within relative 1e-6 (BASELINE.md §4)"
@@ -85,10 +88,28 @@ def test_lm_solve_parity(gpu, oracle, K, L, seed, iters):
 def test_noise_free_fixed_point(gpu):
     from dvslam_amd import BAProblem
     P = synth.make_ba_problem(K=4, L=50, seed=6, pixel_noise=0.0, outlier_frac=0.0, pose_noise=(0.0, 0.0), lm_noise=0.0)
-    g = BAProblem(P)
-    assert g.evaluate()[0] < 1e-18
-    s = g.solve(10)
-    assert s.termination == 0 and s.final_cost < 1e-18
+    for solver in ("solve", "solve_device"):
+        g = BAProblem(P)
+        assert g.evaluate()[0] < 1e-18
+        s = getattr(g, solver)(10)
+        assert s.termination == 0 and s.final_cost < 1e-18
+
+
+def test_device_solver_matches_host_schur_solver(gpu):
+    """same decisions, same cost to rounding, parameters handed back through get_parameters; unsupported shapes say so"""
+    from dvslam_amd import BAProblem, DvsError
+    P = synth.make_ba_problem(K=10, L=2000, seed=42)
+    a = BAProblem(P); b = BAProblem(P)
+    sa = a.solve(10); sb = b.solve_device(10)
+    assert (sa.termination, sa.num_successful_steps, sa.num_iterations) == (sb.termination, sb.num_successful_steps, sb.num_iterations)
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * sa.final_cost
+    qa, ta, Xa = a.parameters(); qb, tb, Xb = b.parameters()
+    assert np.abs(qa - qb).max() < 1e-7
+    assert abs(b.evaluate()[0] - sb.final_cost) <= 1e-12 * sb.final_cost      # the evaluation buffers hold the accepted point
+    big = synth.make_ba_problem(K=20, L=100, seed=3)                            # 19 free cameras > 16
+    with pytest.raises(DvsError) as e:
+        BAProblem(big).solve_device(5)
+    assert e.value.code == -2                                                   # DVS_ERR_UNSUPPORTED
 
 
 def test_sliding_window_adapter_round_trip(gpu, oracle):
