@@ -194,6 +194,102 @@ __global__ __launch_bounds__(256) void k_assoc_argmin(const long long* __restric
   best[i] = bl;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Keyframe.msg on the wire: publishKeyframe (frontend.cpp:699-776) fused with the CDR serialisation
+// rmw_fastrtps applies to dynamic_visual_slam_interfaces/msg/Keyframe (XCDR1, little endian, alignment relative to the byte
+// after the 4-byte encapsulation header).  With 32-byte descriptors every array element has a fixed stride, so the payload is
+// written in place by the threads that back-project the keypoints:
+//   P+0   int32 stamp.sec | uint32 stamp.nanosec | uint32 len | header.frame_id chars + NUL
+//   o1 = align8(12 + len): uint64 frame_id | translation x y z | rotation x y z w           (f64)
+//   o2 = o1 + 64:          uint32 #landmarks | (pad to 8) | { uint64 landmark_id, x, y, z } * m              32 B each
+//   o3 = o2 + 8 + 32 m:    uint32 #observations | (pad to 8) | { uint64 landmark_id, pixel_x, pixel_y (f64), uint32 32, desc[32] },
+//                          stride 64 (the 4 pad bytes before the next uint64 are not written after the last element)
+// m = 0: the two counts sit at o2 and o2 + 4 and the payload ends at o2 + 8 (padding is only emitted in front of an element).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct KfHead { int32_t sec; uint32_t nanosec; uint32_t slen; uint32_t o1; unsigned long long keyframe_id; double pose[7]; char frame_id[64]; };
+
+__device__ __forceinline__ void put_u64(uint8_t* p, unsigned long long v) {  // 4-byte aligned destinations
+  reinterpret_cast<uint32_t*>(p)[0] = (uint32_t)v; reinterpret_cast<uint32_t*>(p)[1] = (uint32_t)(v >> 32);
+}
+__device__ __forceinline__ void put_f64(uint8_t* p, double v) { put_u64(p, (unsigned long long)__double_as_longlong(v)); }
+
+__global__ __launch_bounds__(256) void k_publish_keyframe(KfHead H, const dvs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                          int n, const uint16_t* __restrict__ depth, uint64_t dstep, float fx, float fy,
+                                                          float cx, float cy, const double* __restrict__ Rt, uint8_t* __restrict__ out,
+                                                          unsigned long long cap, unsigned long long* __restrict__ outSize,
+                                                          int* __restrict__ nOut) {
+  __shared__ int wsum[5];
+  __shared__ int s_m;
+  const int tid = threadIdx.x;
+  uint8_t* P = out + 4;
+  const uint32_t o2 = H.o1 + 64;
+  // pass 1: how many keypoints survive the depth gate (the observation array's offset depends on it)
+  int cnt = 0;
+  for (int i = tid; i < n; i += 256) {
+    const int x = round_half_away(kps[i].x), y = round_half_away(kps[i].y);
+    const float Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+    cnt += ((double)Z > 0.3 && (double)Z < 3.0) ? 1 : 0;
+  }
+  int tot;
+  (void)blk_excl_scan(cnt, wsum, tot);
+  if (tid == 0) s_m = tot;
+  __syncthreads();
+  const int m = s_m;
+  const unsigned long long total = 4ull + (m == 0 ? o2 + 8ull : o2 + 8ull + 32ull * m + 8ull + 64ull * (m - 1) + 60ull);
+  if (tid == 0) { *outSize = total; *nOut = m; }
+  if (total > cap) return;  // the host reports DVS_ERR_CAPACITY from outSize
+  if (tid == 0) {
+    out[0] = 0; out[1] = 1; out[2] = 0; out[3] = 0;  // CDR_LE encapsulation, no options
+    reinterpret_cast<int32_t*>(P)[0] = H.sec; reinterpret_cast<uint32_t*>(P)[1] = H.nanosec; reinterpret_cast<uint32_t*>(P)[2] = H.slen;
+    for (uint32_t k = 0; k < H.slen; k++) P[12 + k] = (uint8_t)H.frame_id[k];
+    for (uint32_t k = 12 + H.slen; k < H.o1; k++) P[k] = 0;  // alignment padding
+    put_u64(P + H.o1, H.keyframe_id);
+    for (int k = 0; k < 7; k++) put_f64(P + H.o1 + 8 + 8 * k, H.pose[k]);
+    reinterpret_cast<uint32_t*>(P + o2)[0] = (uint32_t)m;
+    if (m == 0) reinterpret_cast<uint32_t*>(P + o2)[1] = 0u;
+    else {
+      reinterpret_cast<uint32_t*>(P + o2)[1] = 0u;  // pad
+      const uint32_t o3 = o2 + 8 + 32 * m;
+      reinterpret_cast<uint32_t*>(P + o3)[0] = (uint32_t)m; reinterpret_cast<uint32_t*>(P + o3)[1] = 0u;
+    }
+  }
+  if (m == 0) return;
+  const uint32_t lm0 = o2 + 8, ob0 = o2 + 8 + 32 * m + 8;
+  // pass 2: ordered compaction, landmark + observation records
+  int carry = 0;
+  for (int b = 0; b < n; b += 256) {
+    const int i = b + tid;
+    bool keep = false;
+    float X = 0, Y = 0, Z = 0, px = 0, py = 0;
+    if (i < n) {
+      px = kps[i].x; py = kps[i].y;
+      const int x = round_half_away(px), y = round_half_away(py);
+      Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+      X = __fdiv_rn(__fmul_rn(__fsub_rn(px, cx), Z), fx);
+      Y = __fdiv_rn(__fmul_rn(__fsub_rn(py, cy), Z), fy);
+      keep = (double)Z > 0.3 && (double)Z < 3.0;
+    }
+    int t2;
+    const int pos = carry + blk_excl_scan(keep ? 1 : 0, wsum, t2);
+    if (keep) {
+      const double v0 = X, v1 = Y, v2 = Z;
+      uint8_t* L = P + lm0 + 32 * (size_t)pos;
+      put_u64(L, (unsigned long long)i);                                     // landmark_id = keypoint index (:758)
+#pragma unroll
+      for (int r = 0; r < 3; r++) put_f64(L + 8 + 8 * r, (Rt[3 * r] * v0 + Rt[3 * r + 1] * v1 + Rt[3 * r + 2] * v2) + Rt[9 + r]);
+      uint8_t* O = P + ob0 + 64 * (size_t)pos;
+      put_u64(O, (unsigned long long)i);
+      put_f64(O + 8, (double)px); put_f64(O + 16, (double)py);               // float -> float64 fields (:764-765)
+      reinterpret_cast<uint32_t*>(O + 24)[0] = 32u;
+      const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + 32 * (size_t)i);
+#pragma unroll
+      for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(O + 28)[k] = d[k];
+      if (pos + 1 < m) reinterpret_cast<uint32_t*>(O + 60)[0] = 0u;          // pad in front of the next element
+    }
+    carry += t2;
+  }
+}
 }  // namespace dvs
 
 using namespace dvs;
@@ -370,6 +466,134 @@ dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float*
   DVS_HIP(hipGetLastError());
   DVS_HIP(hipMemcpyAsync(best, d_best, (size_t)nobs * 4, hipMemcpyDeviceToHost, st));
   DVS_HIP(hipStreamSynchronize(st));
+  return DVS_OK;
+}
+
+
+// ---- Keyframe.msg (row N3)
+static dvs_status kf_head(const dvs_keyframe_header* hdr, KfHead* H) {
+  DVS_ARG(hdr && hdr->frame_id);
+  const size_t sl = strlen(hdr->frame_id);
+  if (sl + 1 > sizeof(H->frame_id)) { set_error("header.frame_id longer than %zu characters", sizeof(H->frame_id) - 1); return DVS_ERR_ARG; }
+  memset(H, 0, sizeof(*H));
+  H->sec = hdr->stamp_sec; H->nanosec = hdr->stamp_nanosec; H->slen = (uint32_t)sl + 1;
+  memcpy(H->frame_id, hdr->frame_id, sl + 1);
+  H->o1 = (12 + H->slen + 7u) & ~7u;
+  H->keyframe_id = hdr->keyframe_id;
+  for (int k = 0; k < 3; k++) H->pose[k] = hdr->translation[k];
+  for (int k = 0; k < 4; k++) H->pose[3 + k] = hdr->rotation_xyzw[k];
+  return DVS_OK;
+}
+
+size_t dvs_keyframe_cdr_capacity(const char* header_frame_id, int32_t n) {
+  const size_t sl = header_frame_id ? strlen(header_frame_id) + 1 : 1;
+  const size_t o2 = ((12 + sl + 7) & ~(size_t)7) + 64;
+  return 4 + (n <= 0 ? o2 + 8 : o2 + 8 + 32 * (size_t)n + 8 + 64 * (size_t)(n - 1) + 60);
+}
+
+dvs_status dvs_publish_keyframe_device(dvs_matcher* ctx, const dvs_keyframe_header* hdr, const dvs_keypoint* d_kps, const uint8_t* d_desc,
+                                       int32_t n, const uint16_t* d_depth, int32_t rows, int32_t cols, size_t step_bytes, float fx, float fy,
+                                       float cx, float cy, const double* R, const double* t, uint8_t* d_out, size_t cap,
+                                       uint64_t* d_out_size, int32_t* d_n_out) {
+  DVS_ARG(ctx && n >= 0 && d_out && d_out_size && d_n_out && R && t && rows > 0 && cols > 0 && step_bytes >= (size_t)cols * 2);
+  DVS_ARG(n == 0 || (d_kps && d_desc && d_depth));
+  KfHead H;
+  DVS_TRY(kf_head(hdr, &H));
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  double* d_Rt;
+  DVS_TRY(matcher_scratch(ctx, 3, 96, (void**)&d_Rt));
+  double Rt[12];
+  memcpy(Rt, R, 72); memcpy(Rt + 9, t, 24);
+  DVS_HIP(hipMemcpyAsync(d_Rt, Rt, 96, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_publish_keyframe, dim3(1), dim3(256), 0, st, H, d_kps, d_desc, n, d_depth, (uint64_t)step_bytes, fx, fy, cx, cy, d_Rt,
+                     d_out, (unsigned long long)cap, (unsigned long long*)d_out_size, d_n_out);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_publish_keyframe(dvs_matcher* ctx, const dvs_keyframe_header* hdr, const dvs_keypoint* kps, const uint8_t* desc, int32_t n,
+                                const uint16_t* depth, int32_t rows, int32_t cols, size_t step_bytes, float fx, float fy, float cx, float cy,
+                                const double* R, const double* t, uint8_t* out, size_t cap, size_t* out_size, int32_t* n_landmarks) {
+  DVS_ARG(ctx && hdr && out && out_size && n >= 0 && rows > 0 && cols > 0 && R && t);
+  DVS_ARG(n == 0 || (kps && desc && depth));
+  const size_t need = dvs_keyframe_cdr_capacity(hdr->frame_id, n);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  uint8_t* base;
+  const size_t kb = ((size_t)n * sizeof(dvs_keypoint) + 63) & ~(size_t)63, db = ((size_t)n * 32 + 63) & ~(size_t)63,
+               zb = ((size_t)rows * cols * 2 + 63) & ~(size_t)63, ob = (need + 63) & ~(size_t)63;
+  DVS_TRY(matcher_scratch(ctx, 0, kb + db + zb + ob + 64, (void**)&base));
+  dvs_keypoint* d_k = (dvs_keypoint*)base; uint8_t* d_d = base + kb; uint16_t* d_z = (uint16_t*)(base + kb + db);
+  uint8_t* d_o = base + kb + db + zb; uint64_t* d_sz = (uint64_t*)(d_o + ob); int32_t* d_m = (int32_t*)(d_sz + 1);
+  if (n) {
+    DVS_HIP(hipMemcpyAsync(d_k, kps, (size_t)n * sizeof(dvs_keypoint), hipMemcpyHostToDevice, st));
+    DVS_HIP(hipMemcpyAsync(d_d, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    DVS_HIP(hipMemcpy2DAsync(d_z, (size_t)cols * 2, depth, step_bytes, (size_t)cols * 2, rows, hipMemcpyHostToDevice, st));
+  }
+  DVS_TRY(dvs_publish_keyframe_device(ctx, hdr, d_k, d_d, n, d_z, rows, cols, (size_t)cols * 2, fx, fy, cx, cy, R, t, d_o, need, d_sz, d_m));
+  uint64_t sz = 0; int32_t m = 0;
+  DVS_HIP(hipMemcpyAsync(&sz, d_sz, 8, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(&m, d_m, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  *out_size = (size_t)sz;
+  if (n_landmarks) *n_landmarks = m;
+  if (sz > cap) { set_error("keyframe payload needs %llu bytes, buffer has %zu", (unsigned long long)sz, cap); return DVS_ERR_CAPACITY; }
+  DVS_HIP(hipMemcpy(out, d_o, (size_t)sz, hipMemcpyDeviceToHost));
+  return DVS_OK;
+}
+
+// the backend's side of the topic (keyframeCallback, backend.cpp): flat arrays ready for upload; host parsing, bounds checked
+dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_header* hdr, char* frame_id_buf, size_t frame_id_cap,
+                                   uint64_t* landmark_ids, double* landmark_xyz, uint64_t* obs_landmark_ids, double* obs_pixels,
+                                   uint8_t* obs_desc, int32_t cap_n, int32_t* n_landmarks, int32_t* n_observations) {
+  DVS_ARG(buf && hdr && n_landmarks && n_observations && cap_n >= 0);
+  *n_landmarks = *n_observations = 0;
+  if (len < 4 || buf[0] != 0 || buf[1] != 1) { set_error("not a little-endian CDR payload"); return DVS_ERR_ARG; }
+  const uint8_t* P = buf + 4;
+  const size_t L = len - 4;
+  size_t o = 0;
+  auto need = [&](size_t nbytes) { return o + nbytes <= L; };
+  auto align = [&](size_t a) { o = (o + a - 1) & ~(a - 1); };
+  auto rd32 = [&](uint32_t* v) { align(4); if (!need(4)) return false; memcpy(v, P + o, 4); o += 4; return true; };
+  auto rd64 = [&](void* v) { align(8); if (!need(8)) return false; memcpy(v, P + o, 8); o += 8; return true; };
+  uint32_t sec, nsec, slen;
+  bool ok = rd32(&sec) && rd32(&nsec) && rd32(&slen);
+  if (!ok || slen == 0 || !need(slen) || P[o + slen - 1] != 0) { set_error("truncated or malformed header"); return DVS_ERR_ARG; }
+  hdr->stamp_sec = (int32_t)sec; hdr->stamp_nanosec = nsec;
+  if (frame_id_buf) {
+    if (slen > frame_id_cap) { set_error("frame_id needs %u bytes", slen); return DVS_ERR_CAPACITY; }
+    memcpy(frame_id_buf, P + o, slen);
+    hdr->frame_id = frame_id_buf;
+  } else hdr->frame_id = nullptr;
+  o += slen;
+  ok = rd64(&hdr->keyframe_id);
+  for (int k = 0; k < 3 && ok; k++) ok = rd64(&hdr->translation[k]);
+  for (int k = 0; k < 4 && ok; k++) ok = rd64(&hdr->rotation_xyzw[k]);
+  uint32_t nl = 0, no = 0;
+  ok = ok && rd32(&nl);
+  if (!ok || nl > (L - o) / 32) { set_error("truncated landmark array"); return DVS_ERR_ARG; }
+  if ((int64_t)nl > cap_n) { *n_landmarks = (int32_t)nl; set_error("%u landmarks, arrays hold %d", nl, cap_n); return DVS_ERR_CAPACITY; }
+  for (uint32_t i = 0; i < nl && ok; i++) {
+    uint64_t id; double x[3];
+    ok = rd64(&id) && rd64(&x[0]) && rd64(&x[1]) && rd64(&x[2]);
+    if (ok) { if (landmark_ids) landmark_ids[i] = id; if (landmark_xyz) memcpy(landmark_xyz + 3 * (size_t)i, x, 24); }
+  }
+  ok = ok && rd32(&no);
+  if (!ok || no > (L - o) / 28) { set_error("truncated observation array"); return DVS_ERR_ARG; }
+  if ((int64_t)no > cap_n) { *n_landmarks = (int32_t)nl; *n_observations = (int32_t)no; set_error("%u observations, arrays hold %d", no, cap_n); return DVS_ERR_CAPACITY; }
+  for (uint32_t i = 0; i < no && ok; i++) {
+    uint64_t id; double px, py; uint32_t dl;
+    ok = rd64(&id) && rd64(&px) && rd64(&py) && rd32(&dl);
+    if (!ok) break;
+    if (dl != 32 || !need(32)) { set_error("observation %u carries a %u-byte descriptor (ORB rows are 32 bytes)", i, dl); return DVS_ERR_ARG; }
+    if (obs_landmark_ids) obs_landmark_ids[i] = id;
+    if (obs_pixels) { obs_pixels[2 * (size_t)i] = px; obs_pixels[2 * (size_t)i + 1] = py; }
+    if (obs_desc) memcpy(obs_desc + 32 * (size_t)i, P + o, 32);
+    o += 32;
+  }
+  if (!ok) { set_error("truncated payload"); return DVS_ERR_ARG; }
+  *n_landmarks = (int32_t)nl; *n_observations = (int32_t)no;
   return DVS_OK;
 }
 

@@ -24,6 +24,11 @@ class OrbParams(C.Structure):
                 ("min_th_fast", C.c_int32), ("gauss_kernel", C.c_int32 * 7), ("max_batch", C.c_int32)]
 
 
+class KeyframeHeader(C.Structure):
+    _fields_ = [("stamp_sec", C.c_int32), ("stamp_nanosec", C.c_uint32), ("frame_id", C.c_char_p), ("keyframe_id", C.c_uint64),
+                ("translation", C.c_double * 3), ("rotation_xyzw", C.c_double * 4)]
+
+
 class BaSummary(C.Structure):
     _fields_ = [("termination", C.c_int32), ("num_successful_steps", C.c_int32), ("num_iterations", C.c_int32),
                 ("reserved", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]

@@ -1,6 +1,6 @@
 import ctypes as C
 import numpy as np
-from ._lib import lib, check, ptr, KP_DTYPE
+from ._lib import lib, check, ptr, KP_DTYPE, KeyframeHeader
 
 
 class FrontendGlue:
@@ -17,6 +17,9 @@ class FrontendGlue:
         L.dvs_filter_matches.argtypes = [vp, vp, vp, i32, f32, vp, C.POINTER(i32)]
         L.dvs_backproject.argtypes = [vp, vp, i32, vp, i32, i32, sz, f32, f32, f32, f32, vp, vp, vp, vp, C.POINTER(i32)]
         L.dvs_associate.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl, vp]
+        L.dvs_keyframe_cdr_capacity.argtypes = [C.c_char_p, i32]; L.dvs_keyframe_cdr_capacity.restype = sz
+        L.dvs_publish_keyframe.argtypes = [vp, C.POINTER(KeyframeHeader), vp, vp, i32, vp, i32, i32, sz, f32, f32, f32, f32, vp, vp, vp, sz,
+                                           C.POINTER(sz), C.POINTER(i32)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -59,6 +62,31 @@ class FrontendGlue:
                                       ptr(R), ptr(t), ptr(w), ptr(oi), C.byref(m)))
         return w[:m.value], oi[:m.value]
 
+    @staticmethod
+    def _header(stamp, frame_id, keyframe_id, t, q_xyzw):
+        h = KeyframeHeader()
+        h.stamp_sec, h.stamp_nanosec = int(stamp[0]), int(stamp[1])
+        h.frame_id = frame_id.encode() if isinstance(frame_id, str) else frame_id
+        h.keyframe_id = int(keyframe_id)
+        for k in range(3):
+            h.translation[k] = float(t[k])
+        for k in range(4):
+            h.rotation_xyzw[k] = float(q_xyzw[k])
+        return h
+
+    def publish_keyframe(self, kps, desc, depth, fx, fy, cx, cy, R, t, stamp=(0, 0), frame_id="camera_link", keyframe_id=0,
+                         q_xyzw=(0.0, 0.0, 0.0, 1.0)):
+        """publishKeyframe (frontend.cpp:699-776) as the Keyframe.msg CDR payload: returns (bytes, n_landmarks)"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE); n = len(kps)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        depth = np.asarray(depth); R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64).reshape(3)
+        hdr = self._header(stamp, frame_id, keyframe_id, t, q_xyzw)
+        cap = self._L.dvs_keyframe_cdr_capacity(hdr.frame_id, n)
+        out = np.zeros(cap, np.uint8); size = C.c_size_t(); m = C.c_int32()
+        check(self._L.dvs_publish_keyframe(self._h, C.byref(hdr), ptr(kps), ptr(desc), n, ptr(depth), depth.shape[0], depth.shape[1],
+                                           depth.strides[0], fx, fy, cx, cy, ptr(R), ptr(t), ptr(out), cap, C.byref(size), C.byref(m)))
+        return out[:size.value].tobytes(), m.value
+
     def associate(self, obs_desc, obs_px, lm_desc, lm_xyz, R, t, fx, fy, cx, cy, max_desc=50.0, max_reproj=5.0):
         obs_desc = np.ascontiguousarray(obs_desc, np.uint8).reshape(-1, 32); obs_px = np.ascontiguousarray(obs_px, np.float32).reshape(-1, 2)
         lm_desc = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32); lm_xyz = np.ascontiguousarray(lm_xyz, np.float32).reshape(-1, 3)
@@ -67,3 +95,20 @@ class FrontendGlue:
         check(self._L.dvs_associate(self._h, ptr(obs_desc), ptr(obs_px), len(obs_desc), ptr(lm_desc), ptr(lm_xyz), len(lm_desc), ptr(R), ptr(t),
                                     fx, fy, cx, cy, max_desc, max_reproj, ptr(best)))
         return best
+
+
+def unpack_keyframe(payload, cap_n=4096):
+    """dvs_keyframe_unpack_cdr (host code, no GPU): dict of the message's fields as flat arrays"""
+    L = lib()
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
+    L.dvs_keyframe_unpack_cdr.argtypes = [vp, sz, C.POINTER(KeyframeHeader), vp, sz, vp, vp, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    buf = np.frombuffer(payload, np.uint8)
+    hdr = KeyframeHeader(); fid = C.create_string_buffer(256)
+    lid = np.zeros(cap_n, np.uint64); xyz = np.zeros((cap_n, 3)); oid = np.zeros(cap_n, np.uint64); px = np.zeros((cap_n, 2))
+    desc = np.zeros((cap_n, 32), np.uint8); nl = C.c_int32(); no = C.c_int32()
+    check(L.dvs_keyframe_unpack_cdr(buf.ctypes.data, len(buf), C.byref(hdr), C.cast(fid, vp), 256, ptr(lid), ptr(xyz), ptr(oid), ptr(px), ptr(desc),
+                                    cap_n, C.byref(nl), C.byref(no)))
+    return dict(stamp=(hdr.stamp_sec, hdr.stamp_nanosec), frame_id=fid.value.decode(), keyframe_id=hdr.keyframe_id,
+                translation=np.array(hdr.translation[:]), rotation_xyzw=np.array(hdr.rotation_xyzw[:]),
+                landmark_ids=lid[:nl.value], landmark_xyz=xyz[:nl.value], obs_landmark_ids=oid[:no.value], obs_pixels=px[:no.value],
+                obs_desc=desc[:no.value])

@@ -190,6 +190,36 @@ dvs_status dvs_filter_matches(dvs_matcher* ctx, const int32_t* train_idx, const 
 dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n, const uint16_t* depth, int32_t rows, int32_t cols,
                            size_t step_bytes, float fx, float fy, float cx, float cy, const double* R, const double* t, double* world_xyz,
                            int32_t* out_index, int32_t* n_out);
+/* ---- Keyframe.msg on the wire (dynamic_visual_slam_interfaces/msg/{Keyframe,Landmark,Observation}.msg) ------------------------
+ * The frontend publishes one Keyframe per keyframe on /frontend/keyframe (frontend.cpp:200, 699-790) and the backend consumes it;
+ * rmw serialises it as little-endian CDR.  dvs_publish_keyframe* run publishKeyframe's loop (depth gate, back-projection,
+ * landmark_id = keypoint index, float64 pixels, 32-byte descriptor) and write that CDR payload directly, so an adapter hands
+ * the bytes to rclcpp::SerializedMessage / publish_serialized_message without touching 2000 keypoints on the host. */
+typedef struct dvs_keyframe_header {
+  int32_t stamp_sec;           /* header.stamp */
+  uint32_t stamp_nanosec;
+  const char* frame_id;        /* header.frame_id ("camera_link", frontend.cpp:727); <= 63 characters */
+  uint64_t keyframe_id;        /* Keyframe.frame_id */
+  double translation[3];       /* pose.translation x y z  (t_, optical frame) */
+  double rotation_xyzw[4];     /* pose.rotation x y z w   (Eigen::Quaterniond(R_).normalized()) */
+} dvs_keyframe_header;
+/* payload bytes if all n keypoints pass the depth gate (the size of the buffer to provide) */
+size_t dvs_keyframe_cdr_capacity(const char* header_frame_id, int32_t n);
+/* device-resident inputs (extractor outputs, 16UC1 depth), payload into d_out; *d_out_size = bytes needed (> cap: nothing
+ * written), *d_n_out = landmarks.  R (row-major 3x3), t: host.  Asynchronous on the context's stream. */
+dvs_status dvs_publish_keyframe_device(dvs_matcher* ctx, const dvs_keyframe_header* hdr, const dvs_keypoint* d_kps, const uint8_t* d_desc,
+                                       int32_t n, const uint16_t* d_depth, int32_t rows, int32_t cols, size_t step_bytes, float fx, float fy,
+                                       float cx, float cy, const double* R, const double* t, uint8_t* d_out, size_t cap,
+                                       uint64_t* d_out_size, int32_t* d_n_out);
+/* host pointers in, payload in `out` */
+dvs_status dvs_publish_keyframe(dvs_matcher* ctx, const dvs_keyframe_header* hdr, const dvs_keypoint* kps, const uint8_t* desc, int32_t n,
+                                const uint16_t* depth, int32_t rows, int32_t cols, size_t step_bytes, float fx, float fy, float cx, float cy,
+                                const double* R, const double* t, uint8_t* out, size_t cap, size_t* out_size, int32_t* n_landmarks);
+/* the subscriber's side: a received payload as flat arrays (any output pointer may be NULL); hdr->frame_id points into
+ * frame_id_buf.  Host code, no GPU.  DVS_ERR_CAPACITY (with the counts set) when an array holds fewer than cap_n entries. */
+dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_header* hdr, char* frame_id_buf, size_t frame_id_cap,
+                                   uint64_t* landmark_ids, double* landmark_xyz, uint64_t* obs_landmark_ids, double* obs_pixels,
+                                   uint8_t* obs_desc, int32_t cap_n, int32_t* n_landmarks, int32_t* n_observations);
 /* associateObservation + reprojectPoint (backend.cpp:1064-1173) for all observations of one category against a snapshot of
  * that category's landmarks (arrays in the database's iteration order): best[i] = index of the candidate with Hamming
  * distance < max_descriptor_distance and the smallest reprojection error < max_reprojection_distance (first on ties), or -1.

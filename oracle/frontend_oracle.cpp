@@ -112,4 +112,104 @@ void orc_associate(const uint8_t* obs_desc, const float* obs_px, int nobs, const
     best[i] = bl;
   }
 }
+
+// ---- Keyframe.msg as rmw_fastrtps puts it on the wire (row N3).  The message is built as OBJECTS exactly like publishKeyframe
+// does (frontend.cpp:699-776: per keypoint a Landmark and an Observation pushed onto two vectors), then serialised by a generic
+// CDR stream that aligns on write (Fast-CDR, XCDR1: little endian, alignment origin = the byte after the 4-byte encapsulation
+// header, strings = uint32 length including the NUL + bytes, sequences = uint32 count + elements, structs = their fields in
+// declaration order).  Field order follows dynamic_visual_slam_interfaces/msg/{Keyframe,Landmark,Observation}.msg,
+// std_msgs/Header (stamp{int32 sec, uint32 nanosec}, string frame_id), geometry_msgs/Transform (Vector3 translation,
+// Quaternion rotation x y z w) and geometry_msgs/Point.  Fast-CDR / rosidl are absent from the image => parity unpinned.
+}  // extern "C"  (C++ helpers)
+#include <string>
+#include <vector>
+namespace {
+struct CdrOut {
+  std::vector<uint8_t> b;
+  size_t origin = 0;
+  void align(size_t a) { while ((b.size() - origin) % a) b.push_back(0); }
+  template <class T> void put(T v) { align(sizeof(T)); const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
+  void str(const std::string& s) { put<uint32_t>((uint32_t)s.size() + 1); b.insert(b.end(), s.begin(), s.end()); b.push_back(0); }
+};
+struct CdrIn {
+  const uint8_t* p; size_t n, o = 0; bool ok = true;
+  void align(size_t a) { o = (o + a - 1) / a * a; }
+  template <class T> T get() { align(sizeof(T)); T v{}; if (o + sizeof(T) > n) { ok = false; return v; } memcpy(&v, p + o, sizeof(T)); o += sizeof(T); return v; }
+};
+struct LandmarkMsg { uint64_t landmark_id; double x, y, z; };
+struct ObservationMsg { uint64_t landmark_id; double pixel_x, pixel_y; std::vector<uint8_t> descriptor; };
+}  // namespace
+extern "C" {
+
+// returns the payload size (written to out if it fits in cap); *n_lm = landmarks in the message
+size_t orc_publish_keyframe_cdr(int32_t sec, uint32_t nanosec, const char* header_frame_id, uint64_t keyframe_id, const double* trans,
+                                const double* rot_xyzw, const orc_kp* kps, const uint8_t* desc, int n, const uint16_t* depth,
+                                size_t step_bytes, float fx, float fy, float cx, float cy, const double* R, const double* t, uint8_t* out,
+                                size_t cap, int32_t* n_lm) {
+  std::vector<LandmarkMsg> landmarks;
+  std::vector<ObservationMsg> observations;
+  for (int i = 0; i < n; i++) {  // frontend.cpp:732-776
+    const float px = kps[i].x, py = kps[i].y;
+    const int x = static_cast<int>(std::round(px)), y = static_cast<int>(std::round(py));
+    const float pt_depth = *(const uint16_t*)((const uint8_t*)depth + (size_t)y * step_bytes + 2 * (size_t)x) * 0.001f;
+    const float X = (px - cx) * pt_depth / fx, Y = (py - cy) * pt_depth / fy, Z = pt_depth;
+    if (Z > 0.3 && Z < 3.0) {
+      const double v[3] = {X, Y, Z};
+      double w[3];
+      for (int r = 0; r < 3; r++) w[r] = (R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2]) + t[r];
+      landmarks.push_back(LandmarkMsg{(uint64_t)i, w[0], w[1], w[2]});
+      ObservationMsg o{(uint64_t)i, (double)px, (double)py, {}};
+      o.descriptor.assign(desc + 32 * (size_t)i, desc + 32 * (size_t)i + 32);
+      observations.push_back(o);
+    }
+  }
+  CdrOut c;
+  c.b = {0x00, 0x01, 0x00, 0x00};  // CDR_LE, no options
+  c.origin = 4;
+  c.put<int32_t>(sec); c.put<uint32_t>(nanosec); c.str(header_frame_id);           // std_msgs/Header
+  c.put<uint64_t>(keyframe_id);                                                     // uint64 frame_id
+  for (int k = 0; k < 3; k++) c.put<double>(trans[k]);                              // geometry_msgs/Transform
+  for (int k = 0; k < 4; k++) c.put<double>(rot_xyzw[k]);
+  c.put<uint32_t>((uint32_t)landmarks.size());                                      // Landmark[] landmarks
+  for (const LandmarkMsg& l : landmarks) { c.put<uint64_t>(l.landmark_id); c.put<double>(l.x); c.put<double>(l.y); c.put<double>(l.z); }
+  c.put<uint32_t>((uint32_t)observations.size());                                   // Observation[] observations
+  for (const ObservationMsg& o : observations) {
+    c.put<uint64_t>(o.landmark_id); c.put<double>(o.pixel_x); c.put<double>(o.pixel_y);
+    c.put<uint32_t>((uint32_t)o.descriptor.size());
+    c.b.insert(c.b.end(), o.descriptor.begin(), o.descriptor.end());
+  }
+  if (n_lm) *n_lm = (int32_t)landmarks.size();
+  if (c.b.size() <= cap && out) memcpy(out, c.b.data(), c.b.size());
+  return c.b.size();
+}
+
+// generic reader: returns 0 on success; arrays hold cap_n entries; descriptors of any length are accepted but only 32-byte ones copied
+int orc_unpack_keyframe_cdr(const uint8_t* buf, size_t len, int32_t* sec, uint32_t* nanosec, char* frame_id, size_t frame_id_cap,
+                            uint64_t* keyframe_id, double* trans, double* rot_xyzw, uint64_t* lm_ids, double* lm_xyz, uint64_t* obs_ids,
+                            double* obs_px, uint8_t* obs_desc, int cap_n, int32_t* n_lm, int32_t* n_obs) {
+  if (len < 4 || buf[0] != 0 || buf[1] != 1) return -1;
+  CdrIn c{buf + 4, len - 4};
+  *sec = c.get<int32_t>(); *nanosec = c.get<uint32_t>();
+  const uint32_t sl = c.get<uint32_t>();
+  if (!c.ok || sl == 0 || c.o + sl > c.n || sl > frame_id_cap) return -2;
+  memcpy(frame_id, c.p + c.o, sl); c.o += sl;
+  *keyframe_id = c.get<uint64_t>();
+  for (int k = 0; k < 3; k++) trans[k] = c.get<double>();
+  for (int k = 0; k < 4; k++) rot_xyzw[k] = c.get<double>();
+  const uint32_t nl = c.get<uint32_t>();
+  if (!c.ok || (int64_t)nl > cap_n) return -3;
+  for (uint32_t i = 0; i < nl; i++) { lm_ids[i] = c.get<uint64_t>(); for (int k = 0; k < 3; k++) lm_xyz[3 * (size_t)i + k] = c.get<double>(); }
+  const uint32_t no = c.get<uint32_t>();
+  if (!c.ok || (int64_t)no > cap_n) return -4;
+  for (uint32_t i = 0; i < no; i++) {
+    obs_ids[i] = c.get<uint64_t>(); obs_px[2 * (size_t)i] = c.get<double>(); obs_px[2 * (size_t)i + 1] = c.get<double>();
+    const uint32_t dl = c.get<uint32_t>();
+    if (!c.ok || c.o + dl > c.n) return -5;
+    if (dl == 32) memcpy(obs_desc + 32 * (size_t)i, c.p + c.o, 32);
+    c.o += dl;
+  }
+  if (!c.ok) return -6;
+  *n_lm = (int32_t)nl; *n_obs = (int32_t)no;
+  return 0;
+}
 }

@@ -209,7 +209,35 @@ def _glue_lib():
     L.orc_filter_matches.restype = i32; L.orc_filter_matches.argtypes = [vp, vp, i32, f32, vp]
     L.orc_backproject.restype = i32; L.orc_backproject.argtypes = [vp, i32, vp, sz, f32, f32, f32, f32, vp, vp, vp, vp]
     L.orc_associate.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl, vp]
+    L.orc_publish_keyframe_cdr.restype = sz
+    L.orc_publish_keyframe_cdr.argtypes = [i32, C.c_uint32, C.c_char_p, C.c_uint64, vp, vp, vp, vp, i32, vp, sz, f32, f32, f32, f32, vp, vp, vp, sz, vp]
+    L.orc_unpack_keyframe_cdr.restype = i32
+    L.orc_unpack_keyframe_cdr.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     return L
+
+
+def publish_keyframe(kps, desc, depth, fx, fy, cx, cy, R, t, stamp=(0, 0), frame_id="camera_link", keyframe_id=0, q_xyzw=(0, 0, 0, 1)):
+    """oracle: Keyframe.msg built as objects and serialised by a generic CDR stream -> (bytes, n_landmarks)"""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+    R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64).reshape(3); q = np.ascontiguousarray(q_xyzw, np.float64)
+    n = len(kps); cap = 256 + 96 * (n + 1); out = np.zeros(cap, np.uint8); m = C.c_int32()
+    size = _glue_lib().orc_publish_keyframe_cdr(int(stamp[0]), int(stamp[1]), frame_id.encode(), int(keyframe_id), _p(t), _p(q), _p(kps), _p(desc), n,
+                                                _p(depth), depth.shape[1] * 2, fx, fy, cx, cy, _p(R), _p(t), _p(out), cap, C.byref(m))
+    assert size <= cap
+    return out[:size].tobytes(), m.value
+
+
+def unpack_keyframe(payload, cap_n=4096):
+    buf = np.frombuffer(payload, np.uint8)
+    sec = C.c_int32(); nsec = C.c_uint32(); fid = C.create_string_buffer(256); kid = C.c_uint64()
+    tr = np.zeros(3); rot = np.zeros(4); lid = np.zeros(cap_n, np.uint64); xyz = np.zeros((cap_n, 3)); oid = np.zeros(cap_n, np.uint64)
+    px = np.zeros((cap_n, 2)); desc = np.zeros((cap_n, 32), np.uint8); nl = C.c_int32(); no = C.c_int32()
+    rc = _glue_lib().orc_unpack_keyframe_cdr(buf.ctypes.data, len(buf), C.byref(sec), C.byref(nsec), C.cast(fid, C.c_void_p), 256, C.byref(kid), _p(tr), _p(rot),
+                                             _p(lid), _p(xyz), _p(oid), _p(px), _p(desc), cap_n, C.byref(nl), C.byref(no))
+    assert rc == 0, rc
+    return dict(stamp=(sec.value, nsec.value), frame_id=fid.value.decode(), keyframe_id=kid.value, translation=tr, rotation_xyzw=rot,
+                landmark_ids=lid[:nl.value], landmark_xyz=xyz[:nl.value], obs_landmark_ids=oid[:no.value], obs_pixels=px[:no.value],
+                obs_desc=desc[:no.value])
 
 
 def bgr_to_gray(bgr, variant=0):

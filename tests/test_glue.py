@@ -86,3 +86,96 @@ def test_association_parity(gpu, oracle, nobs, nlm, seed):
     assert (got == ref).all()
     if nlm > 100:
         assert (ref >= 0).sum() > 0.2 * min(nobs, nlm) and (ref < 0).sum() > 0
+
+
+# ---------------------------------------------------------------- Keyframe.msg on the wire (row N3) ------------------------------
+def _hand_cdr(stamp, frame_id, kf_id, trans, rot, landmarks, observations):
+    """Third, independent statement of the layout, straight from the CDR rules: align every primitive to its size relative to
+    the byte after the 4-byte encapsulation header."""
+    import struct
+    b = bytearray()
+
+    def put(fmt, v):
+        size = struct.calcsize(fmt)
+        while len(b) % size:
+            b.append(0)
+        b.extend(struct.pack("<" + fmt, v))
+
+    put("i", stamp[0]); put("I", stamp[1])
+    put("I", len(frame_id) + 1); b.extend(frame_id.encode() + b"\0")
+    put("Q", kf_id)
+    for v in trans: put("d", v)
+    for v in rot: put("d", v)
+    put("I", len(landmarks))
+    for lid, x, y, z in landmarks:
+        put("Q", lid); put("d", x); put("d", y); put("d", z)
+    put("I", len(observations))
+    for lid, u, v, d in observations:
+        put("Q", lid); put("d", u); put("d", v); put("I", len(d)); b.extend(bytes(d))
+    return bytes([0, 1, 0, 0]) + bytes(b)
+
+
+def _kf_case(n, seed, all_invalid=False):
+    kps, desc, depth = _scene(seed, max(n, 8))
+    kps, desc = kps[:n], desc[:n]
+    if all_invalid:
+        depth[:] = 0
+    R = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]) @ np.diag([1.0, 1.0, 1.0])
+    t = np.array([0.25, -1.5, 3.0])
+    return kps, desc, depth, R, t
+
+
+def test_keyframe_cdr_oracle_known_answer_and_host_unpack(oracle, hiplib):
+    from oracle_bindings import KP_DTYPE
+    from dvslam_amd.glue import unpack_keyframe
+    from dvslam_amd import DvsError
+    kps = np.zeros(3, KP_DTYPE)
+    kps["x"] = [10.0, 30.25, 50.0]; kps["y"] = [20.0, 40.5, 60.0]
+    depth = np.zeros((100, 100), np.uint16)
+    depth[20, 10] = 1500; depth[41, 30] = 100; depth[60, 50] = 2000       # keypoint 1: 0.1 m -> rejected; (40.5 rounds to 41)
+    desc = (np.arange(96, dtype=np.uint8).reshape(3, 32) * 3 + 1).astype(np.uint8)
+    R = np.eye(3); t = np.array([1.0, 2.0, 3.0]); q = (0.0, 0.0, 0.0, 1.0)
+    fx = fy = np.float32(500.0); cx = np.float32(5.0); cy = np.float32(15.0)
+
+    def world(i):
+        z = np.float32(depth[int(np.floor(kps["y"][i] + 0.5)), int(np.floor(kps["x"][i] + 0.5))]) * np.float32(0.001)
+        x = (kps["x"][i] - cx) * z / fx; y = (kps["y"][i] - cy) * z / fy
+        return (float(x) + 1.0, float(y) + 2.0, float(z) + 3.0)
+
+    for fid in ["camera_link", "", "abc", "abcd", "abcdefg"]:            # every alignment phase of the uint64 behind the string
+        want = _hand_cdr((7, 99), fid, 42, t, q, [(0,) + world(0), (2,) + world(2)],
+                         [(0, 10.0, 20.0, desc[0]), (2, 50.0, 60.0, desc[2])])
+        got, m = oracle.publish_keyframe(kps, desc, depth, 500.0, 500.0, 5.0, 15.0, R, t, (7, 99), fid, 42, q)
+        assert m == 2 and got == want, fid
+        u = unpack_keyframe(got)                                            # the library's subscriber-side parser (host code)
+        o = oracle.unpack_keyframe(got)
+        assert u["frame_id"] == fid == o["frame_id"] and u["keyframe_id"] == 42 and u["stamp"] == (7, 99)
+        for k in ("translation", "rotation_xyzw", "landmark_ids", "landmark_xyz", "obs_landmark_ids", "obs_pixels", "obs_desc"):
+            assert np.array_equal(u[k], o[k]), k
+        assert list(u["landmark_ids"]) == [0, 2] and np.array_equal(u["obs_desc"][1], desc[2])
+    empty, m0 = oracle.publish_keyframe(kps[:0], desc[:0], depth, 500.0, 500.0, 5.0, 15.0, R, t, (1, 2), "camera_link", 3, q)
+    assert m0 == 0 and empty == _hand_cdr((1, 2), "camera_link", 3, t, q, [], [])
+    assert len(unpack_keyframe(empty)["landmark_ids"]) == 0
+    with pytest.raises(DvsError):
+        unpack_keyframe(got[:-5])                                           # truncated descriptor
+    with pytest.raises(DvsError):
+        unpack_keyframe(b"\x00\x00\x00\x00" + got[4:])                      # big-endian flag: refused
+    assert hiplib.dvs_keyframe_cdr_capacity(b"camera_link", 2) == len(_hand_cdr((7, 99), "camera_link", 42, t, q, [(0, 0, 0, 0)] * 2, [(0, 0, 0, desc[0])] * 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,fid,all_invalid", [(700, 0, "camera_link", False), (1, 3, "a", False), (0, 1, "camera_link", False),
+                                                    (257, 5, "", False), (300, 2, "camera_link", True), (2024, 9, "optical_frame_12", False)])
+def test_publish_keyframe_parity(gpu, oracle, n, seed, fid, all_invalid):
+    from dvslam_amd import FrontendGlue
+    from dvslam_amd.glue import unpack_keyframe
+    kps, desc, depth, R, t = _kf_case(n, seed, all_invalid)
+    q = (0.0, 0.0, np.sqrt(0.5), np.sqrt(0.5))
+    g = FrontendGlue()
+    got, m = g.publish_keyframe(kps, desc, depth, 600.0, 601.0, 320.5, 240.25, R, t, (12, 345678), fid, 77, q)
+    want, m2 = oracle.publish_keyframe(kps, desc, depth, 600.0, 601.0, 320.5, 240.25, R, t, (12, 345678), fid, 77, q)
+    assert m == m2 and got == want
+    u = unpack_keyframe(got)
+    w, oi = oracle.backproject(kps, depth, 600.0, 601.0, 320.5, 240.25, R, t) if n else (np.zeros((0, 3)), np.zeros(0, np.int32))
+    assert np.array_equal(u["landmark_ids"], oi.astype(np.uint64)) and np.array_equal(u["landmark_xyz"], w)
+    assert np.array_equal(u["obs_desc"], desc[oi]) and np.array_equal(u["obs_pixels"][:, 0], kps["x"][oi].astype(np.float64))
