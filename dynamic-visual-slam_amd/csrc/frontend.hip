@@ -290,6 +290,45 @@ __global__ __launch_bounds__(256) void k_publish_keyframe(KfHead H, const dvs_ke
     carry += t2;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Harris corner measure as cv::ORB scores its keypoints (HARRIS_SCORE, OpenCV features2d orb.cpp HarrisResponses; SURVEY.md §8f
+// row N4): 3x3 Sobel-like integer gradients over a blockSize x blockSize window around the keypoint, a = sum Ix^2, b = sum Iy^2,
+// c = sum Ix Iy (int32, exact), response = (a*b - c*c - k (a+b)^2) * scale^4 in float with scale = 1 / (4 blockSize 255).
+// One wavefront per keypoint, one lane per window pixel (blockSize <= 8).  Points closer than blockSize/2 + 1 to the border
+// have no defined response in OpenCV (it reads outside the layer); they get 0 here.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ img, int rows, int cols, uint64_t step, const int* __restrict__ xs,
+                                                const int* __restrict__ ys, int n, int blockSize, float k, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int r = blockSize / 2;
+  const int x0 = xs[i], y0 = ys[i];
+  const bool inside = x0 - r - 1 >= 0 && y0 - r - 1 >= 0 && x0 - r + blockSize <= cols - 1 && y0 - r + blockSize <= rows - 1;
+  int a = 0, b = 0, c = 0;
+  if (inside && lane < blockSize * blockSize) {
+    const int wy = lane / blockSize, wx = lane - wy * blockSize;
+    const uint8_t* p = img + (uint64_t)(y0 - r + wy) * step + (x0 - r + wx);
+    const int64_t st = (int64_t)step;
+    const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-st + 1] - (int)p[-st - 1]) + ((int)p[st + 1] - (int)p[st - 1]);
+    const int Iy = ((int)p[st] - (int)p[-st]) * 2 + ((int)p[st - 1] - (int)p[-st - 1]) + ((int)p[st + 1] - (int)p[-st + 1]);
+    a = Ix * Ix; b = Iy * Iy; c = Ix * Iy;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  if (lane == 0) {
+    float resp = 0.f;
+    if (inside) {
+      const float scale = __fdiv_rn(1.f, __fmul_rn((float)((1 << 2) * blockSize), 255.f));
+      const float s4 = __fmul_rn(__fmul_rn(__fmul_rn(scale, scale), scale), scale);
+      const float fa = (float)a, fb = (float)b, fc = (float)c;
+      const float sum = __fadd_rn(fa, fb);
+      resp = __fmul_rn(__fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(k, sum), sum)), s4);
+    }
+    out[i] = resp;
+  }
+}
 }  // namespace dvs
 
 using namespace dvs;
@@ -594,6 +633,40 @@ dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_
   }
   if (!ok) { set_error("truncated payload"); return DVS_ERR_ARG; }
   *n_landmarks = (int32_t)nl; *n_observations = (int32_t)no;
+  return DVS_OK;
+}
+
+
+// ---- Harris responses (row N4)
+dvs_status dvs_harris_responses_device(dvs_matcher* ctx, const uint8_t* d_img, int32_t rows, int32_t cols, size_t step, const int32_t* d_x,
+                                       const int32_t* d_y, int32_t n, int32_t block_size, float k, float* d_response) {
+  DVS_ARG(ctx && n >= 0 && rows > 0 && cols > 0 && step >= (size_t)cols && block_size >= 1 && block_size <= 8);
+  if (n == 0) return DVS_OK;
+  DVS_ARG(d_img && d_x && d_y && d_response);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipLaunchKernelGGL(k_harris, dim3((n + 3) / 4), dim3(256), 0, matcher_stream(ctx), d_img, rows, cols, (uint64_t)step, d_x, d_y, n, block_size, k,
+                     d_response);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_harris_responses(dvs_matcher* ctx, const uint8_t* img, int32_t rows, int32_t cols, size_t step, const int32_t* x,
+                                const int32_t* y, int32_t n, int32_t block_size, float k, float* response) {
+  DVS_ARG(ctx && n >= 0 && rows > 0 && cols > 0 && step >= (size_t)cols && block_size >= 1 && block_size <= 8);
+  if (n == 0) return DVS_OK;
+  DVS_ARG(img && x && y && response);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  uint8_t* base;
+  const size_t ib = ((size_t)rows * cols + 63) & ~(size_t)63, nb = ((size_t)n * 4 + 63) & ~(size_t)63;
+  DVS_TRY(matcher_scratch(ctx, 0, ib + 3 * nb, (void**)&base));
+  int32_t* d_x = (int32_t*)(base + ib); int32_t* d_y = (int32_t*)(base + ib + nb); float* d_r = (float*)(base + ib + 2 * nb);
+  DVS_HIP(hipMemcpy2DAsync(base, cols, img, step, cols, rows, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_x, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_y, y, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DVS_TRY(dvs_harris_responses_device(ctx, base, rows, cols, (size_t)cols, d_x, d_y, n, block_size, k, d_r));
+  DVS_HIP(hipMemcpyAsync(response, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
   return DVS_OK;
 }
 

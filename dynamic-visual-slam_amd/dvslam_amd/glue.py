@@ -17,6 +17,7 @@ class FrontendGlue:
         L.dvs_filter_matches.argtypes = [vp, vp, vp, i32, f32, vp, C.POINTER(i32)]
         L.dvs_backproject.argtypes = [vp, vp, i32, vp, i32, i32, sz, f32, f32, f32, f32, vp, vp, vp, vp, C.POINTER(i32)]
         L.dvs_associate.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, dbl, vp]
+        L.dvs_harris_responses.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, i32, f32, vp]
         L.dvs_keyframe_cdr_capacity.argtypes = [C.c_char_p, i32]; L.dvs_keyframe_cdr_capacity.restype = sz
         L.dvs_publish_keyframe.argtypes = [vp, C.POINTER(KeyframeHeader), vp, vp, i32, vp, i32, i32, sz, f32, f32, f32, f32, vp, vp, vp, sz,
                                            C.POINTER(sz), C.POINTER(i32)]
@@ -61,6 +62,13 @@ class FrontendGlue:
         check(self._L.dvs_backproject(self._h, ptr(kps), n, ptr(depth), depth.shape[0], depth.shape[1], depth.strides[0], fx, fy, cx, cy,
                                       ptr(R), ptr(t), ptr(w), ptr(oi), C.byref(m)))
         return w[:m.value], oi[:m.value]
+
+    def harris_responses(self, img, xs, ys, block_size=7, k=0.04):
+        """cv::ORB's HARRIS_SCORE measure at integer pixel positions of one image (pyramid layer)"""
+        img = np.asarray(img); xs = np.ascontiguousarray(xs, np.int32); ys = np.ascontiguousarray(ys, np.int32)
+        out = np.zeros(len(xs), np.float32)
+        check(self._L.dvs_harris_responses(self._h, ptr(img), img.shape[0], img.shape[1], img.strides[0], ptr(xs), ptr(ys), len(xs), block_size, k, ptr(out)))
+        return out
 
     @staticmethod
     def _header(stamp, frame_id, keyframe_id, t, q_xyzw):

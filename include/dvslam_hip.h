@@ -220,6 +220,14 @@ dvs_status dvs_publish_keyframe(dvs_matcher* ctx, const dvs_keyframe_header* hdr
 dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_header* hdr, char* frame_id_buf, size_t frame_id_cap,
                                    uint64_t* landmark_ids, double* landmark_xyz, uint64_t* obs_landmark_ids, double* obs_pixels,
                                    uint8_t* obs_desc, int32_t cap_n, int32_t* n_landmarks, int32_t* n_observations);
+/* Harris corner measure as cv::ORB scores keypoints (ORB::HARRIS_SCORE, the mode test_dbow2_integration.cpp:19 runs with:
+ * OpenCV features2d orb.cpp HarrisResponses — integer 3x3 gradients over a block_size^2 window, response = (ab - c^2 - k(a+b)^2)
+ * / (4 block_size 255)^4 in float; cv::ORB uses block_size 7, k 0.04).  x, y: integer pixel positions in this image (one pyramid
+ * layer).  Points closer than block_size/2 + 1 to the border get 0 (OpenCV reads outside the layer there). block_size <= 8. */
+dvs_status dvs_harris_responses(dvs_matcher* ctx, const uint8_t* img, int32_t rows, int32_t cols, size_t step, const int32_t* x,
+                                const int32_t* y, int32_t n, int32_t block_size, float k, float* response);
+dvs_status dvs_harris_responses_device(dvs_matcher* ctx, const uint8_t* d_img, int32_t rows, int32_t cols, size_t step, const int32_t* d_x,
+                                       const int32_t* d_y, int32_t n, int32_t block_size, float k, float* d_response);
 /* associateObservation + reprojectPoint (backend.cpp:1064-1173) for all observations of one category against a snapshot of
  * that category's landmarks (arrays in the database's iteration order): best[i] = index of the candidate with Hamming
  * distance < max_descriptor_distance and the smallest reprojection error < max_reprojection_distance (first on ties), or -1.

@@ -212,4 +212,33 @@ int orc_unpack_keyframe_cdr(const uint8_t* buf, size_t len, int32_t* sec, uint32
   *n_lm = (int32_t)nl; *n_obs = (int32_t)no;
   return 0;
 }
+
+// cv::ORB's HarrisResponses (OpenCV features2d/src/orb.cpp, un-vendored; restated from the published source) for one layer:
+// the offsets table, the integer gradient sums and the float response expression in the source's evaluation order.
+void orc_harris_responses(const uint8_t* img, int rows, int cols, size_t stepb, const int32_t* xs, const int32_t* ys, int n, int blockSize,
+                          float harris_k, float* out) {
+  const uint8_t* ptr00 = img;
+  const int step = (int)stepb;
+  const int r = blockSize / 2;
+  const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  std::vector<int> ofs(blockSize * blockSize);
+  for (int i = 0; i < blockSize; i++)
+    for (int j = 0; j < blockSize; j++) ofs[i * blockSize + j] = (int)(i * step + j);
+  for (int ptidx = 0; ptidx < n; ptidx++) {
+    const int x0 = xs[ptidx], y0 = ys[ptidx];
+    if (!(x0 - r - 1 >= 0 && y0 - r - 1 >= 0 && x0 - r + blockSize <= cols - 1 && y0 - r + blockSize <= rows - 1)) { out[ptidx] = 0.f; continue; }
+    const uint8_t* ptr0 = ptr00 + (y0 - r) * step + x0 - r;
+    int a = 0, b = 0, c = 0;
+    for (int k = 0; k < blockSize * blockSize; k++) {
+      const uint8_t* ptr = ptr0 + ofs[k];
+      const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
+      const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
+      a += Ix * Ix;
+      b += Iy * Iy;
+      c += Ix * Iy;
+    }
+    out[ptidx] = ((float)a * b - (float)c * c - harris_k * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+  }
+}
 }

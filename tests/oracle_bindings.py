@@ -216,6 +216,15 @@ def _glue_lib():
     return L
 
 
+def harris_responses(img, xs, ys, block_size=7, k=0.04):
+    img = np.ascontiguousarray(img, np.uint8); xs = np.ascontiguousarray(xs, np.int32); ys = np.ascontiguousarray(ys, np.int32)
+    out = np.zeros(len(xs), np.float32)
+    L = _glue_lib()
+    L.orc_harris_responses.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.orc_harris_responses(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(xs), _p(ys), len(xs), block_size, k, _p(out))
+    return out
+
+
 def publish_keyframe(kps, desc, depth, fx, fy, cx, cy, R, t, stamp=(0, 0), frame_id="camera_link", keyframe_id=0, q_xyzw=(0, 0, 0, 1)):
     """oracle: Keyframe.msg built as objects and serialised by a generic CDR stream -> (bytes, n_landmarks)"""
     kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)

@@ -179,3 +179,55 @@ def test_publish_keyframe_parity(gpu, oracle, n, seed, fid, all_invalid):
     w, oi = oracle.backproject(kps, depth, 600.0, 601.0, 320.5, 240.25, R, t) if n else (np.zeros((0, 3)), np.zeros(0, np.int32))
     assert np.array_equal(u["landmark_ids"], oi.astype(np.uint64)) and np.array_equal(u["landmark_xyz"], w)
     assert np.array_equal(u["obs_desc"], desc[oi]) and np.array_equal(u["obs_pixels"][:, 0], kps["x"][oi].astype(np.float64))
+
+
+# ---------------------------------------------------------------- Harris score (row N4) ---------------------------------------
+def _harris_numpy(img, xs, ys, bs=7, k=np.float32(0.04)):
+    """independent statement: whole-image integer gradient maps, box sums, float32 expression in the source's order"""
+    I = img.astype(np.int64)
+    Ix = np.zeros_like(I); Iy = np.zeros_like(I)
+    Ix[1:-1, 1:-1] = (I[1:-1, 2:] - I[1:-1, :-2]) * 2 + (I[:-2, 2:] - I[:-2, :-2]) + (I[2:, 2:] - I[2:, :-2])
+    Iy[1:-1, 1:-1] = (I[2:, 1:-1] - I[:-2, 1:-1]) * 2 + (I[2:, :-2] - I[:-2, :-2]) + (I[2:, 2:] - I[:-2, 2:])
+    r = bs // 2
+    out = np.zeros(len(xs), np.float32)
+    scale = np.float32(1.0) / (np.float32(4 * bs) * np.float32(255.0))
+    s4 = scale * scale * scale * scale
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        if not (x - r - 1 >= 0 and y - r - 1 >= 0 and x - r + bs <= img.shape[1] - 1 and y - r + bs <= img.shape[0] - 1):
+            continue
+        wx = Ix[y - r:y - r + bs, x - r:x - r + bs]; wy = Iy[y - r:y - r + bs, x - r:x - r + bs]
+        a = np.float32(int((wx * wx).sum())); b = np.float32(int((wy * wy).sum())); c = np.float32(int((wx * wy).sum()))
+        s = a + b
+        out[i] = (a * b - c * c - (k * s) * s) * s4
+    return out
+
+
+def test_harris_oracle_known_answers(oracle):
+    ramp = np.tile(np.arange(64, dtype=np.uint8), (48, 1))                 # I = x: Ix = 8, Iy = 0 everywhere
+    r = oracle.harris_responses(ramp, [20, 30], [20, 10])
+    a = np.float32(49 * 64)
+    scale = np.float32(1.0) / (np.float32(28) * np.float32(255.0))
+    want = (a * np.float32(0) - np.float32(0) - (np.float32(0.04) * a) * a) * (scale * scale * scale * scale)
+    assert r[0] == want == r[1] and want < 0
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (90, 120)).astype(np.uint8)
+    img[30:60, 40:80] = 200                                                  # a real corner
+    xs = np.concatenate([rng.integers(0, 120, 300), [40, 79, 3, 4, 115, 116]]); ys = np.concatenate([rng.integers(0, 90, 300), [30, 59, 3, 4, 85, 86]])
+    for bs in (7, 3, 8, 2):
+        assert np.array_equal(oracle.harris_responses(img, xs, ys, bs), _harris_numpy(img, xs, ys, bs)), bs
+    assert oracle.harris_responses(img, [40], [30])[0] > oracle.harris_responses(img, [60], [45])[0] == 0.0  # corner vs flat interior
+
+
+@pytest.mark.gpu
+def test_harris_parity(gpu, oracle):
+    from dvslam_amd import FrontendGlue
+    g = FrontendGlue()
+    frame = synth.make_frame(3, cols=640, rows=480)
+    rng = np.random.default_rng(8)
+    xs = np.concatenate([rng.integers(0, 640, 3000), [0, 3, 4, 635, 636, 639]]); ys = np.concatenate([rng.integers(0, 480, 3000), [0, 3, 4, 475, 476, 479]])
+    for bs in (7, 5, 8, 1):
+        got = g.harris_responses(frame, xs, ys, bs); want = oracle.harris_responses(frame, xs, ys, bs)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), bs
+    assert (g.harris_responses(frame, xs, ys) != 0).sum() > 2500
+    view = frame[:, :333]                                                      # rows wider than the image (step != cols)
+    assert np.array_equal(g.harris_responses(view, xs // 2, ys), oracle.harris_responses(np.ascontiguousarray(view), xs // 2, ys))
