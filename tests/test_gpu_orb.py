@@ -232,3 +232,42 @@ def test_next_batch_hint_is_result_neutral(gpu, oracle):
     run(0, 0)       # same buffer announced as its own successor (the bench's steady state)
     run(0, None)    # consumes
     run(2, None)    # plain call
+
+
+@pytest.mark.gpu
+def test_randomized_configurations(gpu, oracle):
+    """seeded sweep over resolutions (odd and even widths), feature budgets, level counts, scale factors and FAST thresholds,
+    each through the host entry point AND the device-resident batch entry point (tight pitch = cols)"""
+    from dvslam_amd import ORBextractor
+    from dvslam_amd._lib import DeviceBuffer, KP_DTYPE
+    rng = np.random.default_rng(2026)
+    done = 0
+    for it in range(40):
+        rows = int(rng.integers(150, 420)); cols = int(rng.integers(200, 560))
+        if it % 3 == 0:
+            cols &= ~3
+        nl = int(rng.integers(2, 9)); nf = int(rng.integers(60, 900))
+        sf = float(rng.choice([1.2, 1.2, 1.1, 1.3, 1.44]))
+        ini, mn = [(20, 7), (20, 7), (30, 10), (12, 5)][int(rng.integers(0, 4))]
+        img = synth.make_frame(int(rng.integers(0, 40)), cols=cols, rows=rows)
+        try:
+            g = ORBextractor(nf, sf, nl, ini, mn, max_batch=2)
+            n, kps, desc = g(img)
+        except Exception as e:                                   # sizes the reference itself cannot handle (nCols / nIni == 0)
+            assert getattr(e, "code", None) == -2, (rows, cols, nf, nl, sf, e)
+            continue
+        o = oracle.OracleORB(nf, sf, nl, ini, mn)
+        n2, kps2, desc2 = o.extract(img)
+        _assert_same_result(n, kps, desc, n2, kps2, desc2)
+        cap = g.capacity
+        two = np.stack([img, img[::-1].copy()])
+        d_img = DeviceBuffer(two.nbytes).upload(two)
+        d_k = DeviceBuffer(2 * cap * 28); d_d = DeviceBuffer(2 * cap * 32); d_n = DeviceBuffer(8)
+        g.extract_batch_device(d_img.ptr, 2, rows, cols, cols, rows * cols, d_k.ptr, d_d.ptr, cap, d_n.ptr)
+        g.synchronize()
+        n3 = d_n.download(np.int32, 2); k3 = d_k.download(KP_DTYPE, 2 * cap).reshape(2, cap); dd = d_d.download(np.uint8, 2 * cap * 32).reshape(2, cap, 32)
+        _assert_same_result(int(n3[0]), k3[0, :n3[0]], dd[0, :n3[0]], n2, kps2, desc2)
+        _assert_same_result(int(n3[1]), k3[1, :n3[1]], dd[1, :n3[1]], *o.extract(two[1]))
+        g.close()
+        done += 1
+    assert done >= 25
