@@ -57,6 +57,7 @@ struct dvs_orb {
   bool pf_valid = false;
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
+  float4* d_orient = nullptr;  // per keypoint slot: (angle, cos, sin, -) between the two halves of the descriptor stage
   int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
   u8* d_desc = nullptr;
@@ -75,7 +76,7 @@ namespace {
 
 void free_workspace(dvs_orb* h) {
   void* ptrs[] = {h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_pyr_alt, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
@@ -84,7 +85,7 @@ void free_workspace(dvs_orb* h) {
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
-  h->d_pyr_alt = nullptr; h->pf_valid = false; h->next_hint = nullptr;
+  h->d_pyr_alt = nullptr; h->d_orient = nullptr; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
   h->rows = h->cols = 0;
@@ -383,6 +384,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipMalloc((void**)&h->d_candtotal, B * G.nlevels * 4));
   DVS_HIP(hipMalloc((void**)&h->d_lvlcount, B * G.nlevels * 4));
   DVS_HIP(hipMalloc((void**)&h->d_lvlkp, B * (size_t)G.kpBlock * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_orient, B * (size_t)G.kpBlock * sizeof(float4)));
   DVS_HIP(hipMalloc((void**)&h->d_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
   DVS_HIP(hipMalloc((void**)&h->d_desc, B * (size_t)G.outCap * 32));
   DVS_HIP(hipMalloc((void**)&h->d_nout, B * 4));
@@ -548,12 +550,25 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
   h->timer.end(bst);
   if (bst != st) DVS_HIP(hipEventRecord(h->ev_blur, bst));
-  if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
-  // 5. orientation + descriptors + output records
-  h->timer.begin(DVS_STAGE_DESCRIBE, st);
-  hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), (getenv("DVS_DESC_PAD") ? atoi(getenv("DVS_DESC_PAD")) : 0), st, h->d_geom, src, h->d_blur, h->d_lvlkp,
-                     h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
-  h->timer.end(st);
+  // 5. orientation + descriptors + output records.  With the blur on its own stream the orientation half (pyramid + keypoints
+  //    only, fetch-bound) runs while the blur (VALU-bound) is still in flight; the descriptor half joins both.
+  const dim3 dgrid((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg);
+  if (bst != st) {
+    h->timer.begin(DVS_STAGE_DESCRIBE, st);
+    hipLaunchKernelGGL(k_describe<1>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
+                       capacity, h->d_orient);
+    h->timer.end(st);
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
+    h->timer.begin(DVS_STAGE_DESCRIBE, st, false);
+    hipLaunchKernelGGL(k_describe<2>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
+                       capacity, h->d_orient);
+    h->timer.end(st);
+  } else {
+    h->timer.begin(DVS_STAGE_DESCRIBE, st);
+    hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
+                       capacity, h->d_orient);
+    h->timer.end(st);
+  }
   DVS_HIP(hipGetLastError());
   h->last_nimg = nimg;
   h->last_src = src;

@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
                                                  const int* __restrict__ beta) {
+  // the level chain is seven dependent, latency-bound launches that run beside a VALU-saturating kernel (FAST): without issue
+  // priority its waves starve (a 55 us level took 250 us) and the chain spills into the fetch-bound descriptor stage
+  __builtin_amdgcn_s_setprio(3);
   const int gx = blockIdx.x * 64 + threadIdx.x;
   const int x4 = gx * 4;
   const int y0 = (blockIdx.y * 4 + threadIdx.y) * kResizeRows;
@@ -1376,10 +1379,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 //    samples are LDS byte reads.  The pattern is unpacked to floats once per wave.
 constexpr int kDescKP = 8;
 constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinPitch = 48;
+// MODE 0: orientation + descriptors in one launch.  MODE 1 / 2: the same code split at the angle — the orientation half only
+// needs the pyramid and the quad-tree's keypoints, so it can run while the blur is still in flight (it is fetch-bound, the
+// blur VALU-bound), and the descriptor half then only fetches the blurred windows.  orient[slot] = (angle, cos, sin, -).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
                                                   const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
-                                                  int* __restrict__ nOut, int capacity) {
+                                                  int* __restrict__ nOut, int capacity, float4* __restrict__ orient) {
   typedef uint4 __attribute__((aligned(1))) uint4u;
   __shared__ __attribute__((aligned(16))) u8 win[4][2][kWinRows * kWinPitch];
   const int wg = xcd_contiguous_id();
@@ -1389,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
   const int slot0 = (bx * 4 + wv) * kDescKP;
-  if (bx == 0 && threadIdx.x == 0) {
+  if (MODE != 1 && bx == 0 && threadIdx.x == 0) {
     int total = 0;
     for (int l = 0; l < nl; l++) total += cnt[l];
     nOut[f] = min(total, capacity);
@@ -1424,12 +1431,16 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int v = prow - kHalfPatch;
   const int pcol = half ? 1 : -kHalfPatch;
   uint4 d[kDescKP];
+  if constexpr (MODE != 2) {
 #pragma unroll
-  for (int i = 0; i < kDescKP; i++) {
-    const u8* ib = DVS_RLP(imgL, i);
-    const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
-    d[i] = *reinterpret_cast<const uint4u*>(ib + (int64_t)(yi + v) * pi + xi + pcol);
+    for (int i = 0; i < kDescKP; i++) {
+      const u8* ib = DVS_RLP(imgL, i);
+      const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
+      d[i] = *reinterpret_cast<const uint4u*>(ib + (int64_t)(yi + v) * pi + xi + pcol);
+    }
   }
+  float4 ori = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (MODE == 2) ori = orient[(uint64_t)f * g->kpBlock + slot];
   // blurred window of keypoint 0
   const int e0 = lane, e1 = 64 + lane;  // 111 = 37 rows x 3 sixteen-byte pieces
   const int wr0 = e0 / 3, wc0 = e0 - 3 * wr0, wr1 = min(e1 / 3, kWinRows - 1), wc1 = e1 - 3 * (e1 / 3);
@@ -1447,15 +1458,20 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   }
   // a wave's life is one latency chain (slot -> patches / windows -> samples), so every window is requested up front: the
   // first half behind the patches, the second half into the registers the patches free
-  DVS_REQUEST_WINDOW(0) DVS_REQUEST_WINDOW(1) DVS_REQUEST_WINDOW(2) DVS_REQUEST_WINDOW(3)
+  if constexpr (MODE != 1) { DVS_REQUEST_WINDOW(0) DVS_REQUEST_WINDOW(1) DVS_REQUEST_WINDOW(2) DVS_REQUEST_WINDOW(3) }
   // pattern -> floats, once per wave
   float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < 4 && MODE != 1; r++) {
     const int pat = reinterpret_cast<const int*>(c_pattern)[64 * r + lane];
     px0[r] = (float)(int8_t)(pat & 0xff); py0[r] = (float)(int8_t)((pat >> 8) & 0xff);
     px1[r] = (float)(int8_t)((pat >> 16) & 0xff); py1[r] = (float)(int8_t)((pat >> 24) & 0xff);
   }
+  float angleK = 0.f, cosK = 0.f, sinK = 0.f;
+  if constexpr (MODE == 2) {
+    angleK = ori.x; cosK = valid ? ori.y : 1.f; sinK = valid ? ori.z : 0.f;   // keypoint lane & 7 (empty slots: any in-window steering)
+    DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7)
+  } else {
   // ---- IC_Angle (ORBextractor.cpp:76-103): membership and the u weights are per-lane byte tables (Geom::icw):
   // sum u*I = sum (u+15)*I - 15 * sum I, exact integers
   const uint32_t* wt = g->icw[lane];
@@ -1474,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     q[i] = (int)su - kHalfPatch * (int)sm;
     q[kDescKP + i] = v * (int)sm;
   }
-  DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7)
+  if constexpr (MODE == 0) { DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7) }
   // transposing butterfly: after the step with lane bit B, a lane keeps the half of the quantities selected by its bit B
 #define DVS_BFLY(n, o)                                        \
   {                                                           \
@@ -1493,12 +1509,19 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   // lane bits 5 | 4 3 2 = (m01 ? : m10) | keypoint index bits 2 1 0  (bit 4 chose between i and i+4, bit 3 i and i+2, bit 2 i and i+1)
   const int other = __shfl_xor(tot, 32);
   const int m10 = lane < 32 ? tot : other, m01 = lane < 32 ? other : tot;
-  const float angleK = fast_atan2_deg((float)m01, (float)m10);  // keypoint (lane >> 2) & 7
+  angleK = fast_atan2_deg((float)m01, (float)m10);  // keypoint (lane >> 2) & 7
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angleK, factorPI);
-  const float cosK = gsc::cosf_(arad), sinK = gsc::sinf_(arad);
+  cosK = gsc::cosf_(arad); sinK = gsc::sinf_(arad);
+  }
   // ---- steered BRIEF on the blurred level (:107-146), one keypoint after the other
   const unsigned vmask = (unsigned)(__ballot(valid) & 0xffull);
+  if constexpr (MODE == 1) {  // keypoint k's values live in lanes 4k..4k+3
+    const int k = lane >> 2;
+    if (lane < 32 && (lane & 3) == 0 && ((vmask >> k) & 1u)) orient[(uint64_t)f * g->kpBlock + slot0 + k] = make_float4(angleK, cosK, sinK, 0.f);
+    return;
+  }
+  constexpr int kCsLane = MODE == 2 ? 1 : 4;  // lane stride of the per-keypoint (cos, sin, angle)
   const int giL = gi;
   auto brief = [&](const int i, const uint4& wa, const uint4& wb) __attribute__((always_inline)) {
     u8* wl = win[wv][i & 1];
@@ -1507,8 +1530,8 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     const int xi = DVS_RL(x, i);
     const int wxi = xi - ((xi - kWinR) & ~3);
     wave_lds_fence();
-    const float a = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, cosK), 4 * i));
-    const float b = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, sinK), 4 * i));
+    const float a = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, cosK), kCsLane * i));
+    const float b = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, sinK), kCsLane * i));
     const u8* bc = wl + kWinR * kWinPitch + wxi;
     unsigned long long words[4];
 #pragma unroll
@@ -1532,7 +1555,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   brief(0, wq0_0, wq1_0); brief(1, wq0_1, wq1_1); brief(2, wq0_2, wq1_2); brief(3, wq0_3, wq1_3);
   brief(4, wq0_4, wq1_4); brief(5, wq0_5, wq1_5); brief(6, wq0_6, wq1_6); brief(7, wq0_7, wq1_7);
   // ---- keypoints: lane i < 8 writes keypoint i; its angle lives in lane 4 * i
-  const float angle = __shfl(angleK, 4 * (lane & 7));
+  const float angle = __shfl(angleK, kCsLane * (lane & 7));
   if (lane < kDescKP && valid) {
     dvs_keypoint kp;
     kp.x = (float)x; kp.y = (float)y;
