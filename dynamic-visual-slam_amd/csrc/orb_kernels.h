@@ -713,7 +713,8 @@ __device__ __forceinline__ QNode qt_child(const QNode& nd, int q, int cnt) {
 }
 
 struct QtShared {
-  QNode* nodes[2];
+  QNode *n0, *n1;  // the two node arrays; selected by value (a runtime-indexed array member would put the struct in scratch)
+  __device__ __forceinline__ QNode* nodes_(int c) const { return c ? n1 : n0; }
   int* childCnt;   // 4 per node
   int* posArr;     // split node: first list position of its children; unsplit: -(newpos+1)
   int* flag;       // per node: 1 = split in this pass
@@ -746,8 +747,8 @@ __device__ __forceinline__ int qt_mask(const int* childCnt, int k) {
 // children: place unsplit nodes behind the children in old order, write the new node array, re-point
 // the points.  Returns nothing; *pS updated by thread 0.
 __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, uint32_t* pts, int* nodeOf, int n, int* wsum) {
-  const QNode* old = sh.nodes[cur];
-  QNode* nw = sh.nodes[cur ^ 1];
+  const QNode* old = sh.nodes_(cur);
+  QNode* nw = sh.nodes_(cur ^ 1);
   // unsplit nodes: stable compaction behind the children block
   int carry = 0;
   for (int b = 0; b < S; b += 256) {
@@ -789,7 +790,7 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
 
 // creation-ordered list of multi-point nodes among the T freshly created children (positions T-1..0)
 __device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T, int* wsum) {
-  const QNode* nodes = sh.nodes[cur];
+  const QNode* nodes = sh.nodes_(cur);
   int carry = 0;
   for (int b = 0; b < T; b += 256) {
     const int j = b + threadIdx.x;
@@ -806,7 +807,8 @@ __device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T
 
 // ---- workgroup std::sort (lsort.h, "restated so that it parallelises"): ranges are partitioned one wavefront each, round by
 // round (the ranges of a round are disjoint), leaves of <= 16 elements are placed by rank, one lane per element.
-// a: m packed 64-bit elements in LDS, key = a >> 12.  Lp / Rp: scratch of m ints each (LDS).  Result in place.
+// a: m packed 64-bit elements in LDS, key = a >> 12.  Lp / Rp: scratch of m ints each (LDS).  Result in place: the sorted
+// elements' LOW 32 BITS (payload + the low key bits); the upper key bits are dropped.
 constexpr int kSortRanges = 128;  // > kMaxQuota / 17 live ranges of more than 16 elements
 struct SortShared { uint32_t rng[2][kSortRanges]; int cnt[2]; };
 
@@ -888,31 +890,23 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
     if (tid == 0) ss.cnt[cur] = 0;
     __syncthreads();
   }
-  // leaves: stable placement by rank
-  constexpr int kPer = (kMaxQuota + 255) / 256;
-  unsigned long long mine[kPer];
-  int np[kPer];
-#pragma unroll
-  for (int u = 0; u < kPer; u++) {
-    const int i = tid + 256 * u;
-    np[u] = -1;
-    if (i < m) {
-      const int fl = Lp[i];
-      const int f = fl & 0xFFFF, l = fl >> 16;
-      const unsigned long long e = a[i];
-      const unsigned long long ke = e >> 12;
-      int rnk = f;
-      for (int j = f; j < l; j++) {
-        const unsigned long long kj = a[j] >> 12;
-        rnk += (kj < ke || (kj == ke && j < i)) ? 1 : 0;
-      }
-      mine[u] = e; np[u] = rnk;
+  // leaves: stable placement by rank.  Only the payload (low 32 bits: the list index the callers read back) is carried to the
+  // sorted position, through Rp / Lp, so that no element has to be held in registers across the barrier
+  for (int i = tid; i < m; i += 256) {
+    const int fl = Lp[i];
+    const int f = fl & 0xFFFF, l = fl >> 16;
+    const unsigned long long ke = a[i] >> 12;
+    int rnk = f;
+    for (int j = f; j < l; j++) {
+      const unsigned long long kj = a[j] >> 12;
+      rnk += (kj < ke || (kj == ke && j < i)) ? 1 : 0;
     }
+    Rp[i] = rnk;
   }
   __syncthreads();
-#pragma unroll
-  for (int u = 0; u < kPer; u++)
-    if (np[u] >= 0) a[np[u]] = mine[u];
+  for (int i = tid; i < m; i += 256) Lp[Rp[i]] = (int)(unsigned)a[i];
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) a[i] = (unsigned long long)(unsigned)Lp[i];
   __syncthreads();
 }
 
@@ -942,8 +936,8 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
   QtShared sh;
   {
     unsigned char* p = smem;
-    sh.nodes[0] = (QNode*)p; p += sizeof(QNode) * nmax;
-    sh.nodes[1] = (QNode*)p; p += sizeof(QNode) * nmax;
+    sh.n0 = (QNode*)p; p += sizeof(QNode) * nmax;
+    sh.n1 = (QNode*)p; p += sizeof(QNode) * nmax;
     sh.sortbuf = (unsigned long long*)p; p += 8 * nmax;
     sh.childCnt = (int*)p; p += 16 * nmax;
     sh.posArr = (int*)p; p += 4 * nmax;
@@ -1022,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
         nd.brx = (int16_t)(int)__fmul_rn(L.hX, (float)(k + 1));
         nd.uly = 0; nd.bry = (int16_t)L.regionH;
         nd.cnt = sh.childCnt[k]; nd.pt = -1;
-        sh.nodes[0][carry + ex] = nd;
+        sh.nodes_(0)[carry + ex] = nd;
       }
       carry += tot;
     }
@@ -1030,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
       const int pos = sh.posArr[nodeOf[i]];
-      if (sh.nodes[0][pos].cnt == 1) { sh.nodes[0][pos].pt = i; nodeOf[i] = -1; }
+      if (sh.nodes_(0)[pos].cnt == 1) { sh.nodes_(0)[pos].pt = i; nodeOf[i] = -1; }
       else nodeOf[i] = pos;
     }
     __syncthreads();
@@ -1041,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
   while (!finish) {
     const int S = s_S;
     // full sweep: split every multi-point node (:622-681)
-    qt_count_children(sh.nodes[cur], S, sh.childCnt, pts, nodeOf, n);
+    qt_count_children(sh.nodes_(cur), S, sh.childCnt, pts, nodeOf, n);
     int nExpandLocal = 0;
     {
       // children block: node k's children sit in front of the children of all earlier nodes
@@ -1050,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
         const int k = b + tid;
         int e = 0;
         if (k < S) {
-          const bool split = sh.nodes[cur][k].cnt > 1;
+          const bool split = sh.nodes_(cur)[k].cnt > 1;
           sh.flag[k] = split ? 1 : 0;
           if (split) {
             e = __popc(qt_mask(sh.childCnt, k));
@@ -1096,20 +1090,15 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
     while (!finish) {
       const int Sb = s_S;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
-      qt_count_children(sh.nodes[cur], Sb, sh.childCnt, pts, nodeOf, n);
+      qt_count_children(sh.nodes_(cur), Sb, sh.childCnt, pts, nodeOf, n);
       for (int r = tid; r < m; r += 256) {
-        const QNode& nd = sh.nodes[cur][sh.expl[r]];
+        const QNode& nd = sh.nodes_(cur)[sh.expl[r]];
         sh.sortbuf[r] = ((unsigned long long)(uint32_t)nd.cnt << 28) | ((unsigned long long)(uint16_t)nd.ulx << 12) |
                         (unsigned long long)r;
       }
       for (int k = tid; k < Sb; k += 256) sh.flag[k] = 0;
       __syncthreads();
-      if (g->debug & 2) {  // diagnostics: the single-lane replica
-        if (tid == 0) lsort::sort(sh.sortbuf, (long)m, lsort::Less<12>());
-        __syncthreads();
-      } else if (!(g->debug & 1)) {
-        qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
-      }
+      if (!(g->debug & 1)) qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
       if (tid == 0) s_c = 0;
@@ -1153,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom* __restrict__ g, cons
 
   // ---- best point per node (:757-776), list order = output order ----------------------------------
   const int S = (n == 0) ? 0 : s_S;
-  QNode* nodes = sh.nodes[cur];
+  QNode* nodes = sh.nodes_(cur);
   int* best = sh.childCnt;
   for (int k = tid; k < S; k += 256) best[k] = 0;
   __syncthreads();
