@@ -360,13 +360,16 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
     if (e < 0 || f < 0) continue;
     const double* y = Y + 18 * (size_t)e;
     const double* w = Ws + 18 * (size_t)f;
+#pragma unroll
     for (int a = 0; a < 6; a++)
+#pragma unroll
       for (int b = 0; b < 6; b++) acc[6 * a + b] += y[3 * a] * w[3 * b] + y[3 * a + 1] * w[3 * b + 1] + y[3 * a + 2] * w[3 * b + 2];
     if (ci == ck) {
       const double gl0 = g[j0] * scale[j0], gl1 = g[j0 + 1] * scale[j0 + 1], gl2 = g[j0 + 2] * scale[j0 + 2];
       for (int a = 0; a < 6; a++) r[a] += y[3 * a] * gl0 + y[3 * a + 1] * gl1 + y[3 * a + 2] * gl2;
     }
   }
+#pragma unroll
   for (int k = 0; k < 36; k++) {
     const double tot = block_sum_fixed(acc[k], sm);
     if (threadIdx.x == 0) {
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
     }
   }
   if (ci == ck)
+#pragma unroll
     for (int a = 0; a < 6; a++) {
       const double tot = block_sum_fixed(r[a], sm);
       if (threadIdx.x == 0) rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a] - tot;
