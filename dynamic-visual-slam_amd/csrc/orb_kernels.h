@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
   __builtin_amdgcn_s_setprio(3);
   const int gx = blockIdx.x * 64 + threadIdx.x;
   const int x4 = gx * 4;
-  const int y0 = (blockIdx.y * 4 + threadIdx.y) * kResizeRows;
+  // a wavefront is one threadIdx.y row of the (64, 4) block: everything that depends on y only is wave-uniform, and saying so
+  // (v_readfirstlane) moves the row table lookups and the 64-bit row address arithmetic to the scalar unit
+  const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kResizeRows;
   const int f = blockIdx.z;
   if (x4 >= dw || y0 >= dh) return;
   const ResizeGroup t = xt[gx];
