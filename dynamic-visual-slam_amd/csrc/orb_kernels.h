@@ -533,10 +533,11 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
                                                    uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int lane = lane_id();
-  const int ci = cell0 + blockIdx.x * 4 + (threadIdx.x >> 6);  // cells [cell0, cell1) of the level-major cell table
-  if (ci >= cell1) return;
+  const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
+  const int ci = cell0 + blockIdx.x * 4 + wvi;                        // every size derived from them stay on the scalar unit
+  if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
   const int f = blockIdx.y;
-  unsigned char* base = fsm + (threadIdx.x >> 6) * g->fastWaveLds;
+  unsigned char* base = fsm + wvi * g->fastWaveLds;
   const int tileBytes = g->fastRows * P;
   u8* tile = base;
   u8* score = base + tileBytes;
@@ -1232,7 +1233,7 @@ __device__ __forceinline__ uint32_t blur_word_reflect(const u8* row, int xw, int
 
 __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g, const BlurStrip* __restrict__ strips, int nstrips,
                                                      ImgSrc src, u8* __restrict__ blur) {
-  const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: strip geometry in SGPRs
   if (wi >= nstrips) return;
   const BlurStrip s = strips[wi];
   const int lane = lane_id();
@@ -1383,7 +1384,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int wg = xcd_contiguous_id();
   const int f = wg / (int)gridDim.x, bx = wg - f * (int)gridDim.x;
   const int lane = lane_id();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
   const int slot0 = (bx * 4 + wv) * kDescKP;
