@@ -51,6 +51,11 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ int mul_i24(int a, int b) {
   int d;
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -577,10 +582,10 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     const int idx = i0 + lane;
     const bool valid = idx < total;
     const int row = valid ? (int)(((float)idx + 0.5f) * invng) : 0;
-    const int gi = valid ? idx - row * ng : 0;
+    const int gi = valid ? mad_i24(row, -ng, idx) : 0;  // idx - row * ng; 24-bit forms: v_mul_lo_u32 / v_mad_u64_u32 run at 1/4 rate
     const int y = row + 3;
     const int wcol = g0 + gi;  // word column
-    const uint32_t* rp = t32 + y * (P / 4) + wcol;
+    const uint32_t* rp = t32 + mad_i24(y, P / 4, wcol);
     const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
     const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
     const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     };
     int pos = nwork + below(b0) + below(b1) + below(b2) + below(b3);
-    const int cbase = y * P + wcol * 4;
+    const int cbase = mad_i24(y, P, wcol * 4);
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (pass[j]) work[pos++] = (uint16_t)(cbase + j);
