@@ -1268,7 +1268,9 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
     int sy = s.y0 + k - 3;                 // BORDER_REFLECT_101 on rows (H >= 7 always holds for a level)
     sy = sy < 0 ? -sy : sy;
     sy = sy >= H ? 2 * H - 2 - sy : sy;
-    return *reinterpret_cast<const uint32_t*>(img + (uint64_t)sy * pitch + xl);
+    // wave-uniform row offset (SALU) + per-lane column as ONE 32-bit offset from the uniform level base: the 64-bit form compiled
+    // to a quarter-rate v_mad_u64_u32 per load
+    return *reinterpret_cast<const uint32_t*>(img + (uint32_t)(sy * pitch + xl));
   };
   typedef unsigned short us2v __attribute__((ext_vector_type(2)));
   const us2v k01 = {(unsigned short)kv[0], (unsigned short)kv[1]}, k23 = {(unsigned short)kv[2], (unsigned short)kv[3]},
@@ -1323,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 6) % 7][j]), k45, acc, false);  // rows k-2, k-1
             o |= ((acc >> 16) & 0xffu) << (8 * j);
           }
-          u8* orow = dst + (uint64_t)(s.y0 + k - 6) * L.pitch + x;
+          u8* orow = dst + (uint32_t)((s.y0 + k - 6) * L.pitch + x);
           *reinterpret_cast<uint32_t*>(orow) = o;  // the blurred block has the padded pitch too: a tail word may spill into it
         }
       }
