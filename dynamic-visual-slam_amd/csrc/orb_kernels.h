@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
   const int f = blockIdx.z;
   if (x4 >= dw || y0 >= dh) return;
   const ResizeGroup t = xt[gx];
-  const u8* s = src + (uint64_t)f * sfs + t.base;
-  u8* d = dst + (uint64_t)f * dfs + x4;
+  // uniform frame bases + 32-bit per-lane offsets (a level is far smaller than 4 GB): no 64-bit vector multiply-adds
+  const u8* s = src + (uint64_t)f * sfs;
+  u8* d = dst + (uint64_t)f * dfs;
   const bool fastw = t.base + 12 <= sw;
   uint32_t w0[kResizeRows][3], w1[kResizeRows][3];
   int bb[kResizeRows];
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     const int sy = yofs[y];
     bb[r] = beta[y];
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
-    const u8* p0 = s + (uint64_t)r0 * sp;
-    const u8* p1 = s + (uint64_t)r1 * sp;
+    const u8* p0 = s + (uint32_t)(r0 * sp + t.base);
+    const u8* p1 = s + (uint32_t)(r1 * sp + t.base);
     if (fastw) {
       const uint2 a = *reinterpret_cast<const uint2*>(p0);
       const uint2 c = *reinterpret_cast<const uint2*>(p1);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
       out |= (uint32_t)(v & 0xff) << (8 * i);
     }
     // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
-    *reinterpret_cast<uint32_t*>(d + (uint64_t)(y0 + r) * dp) = out;
+    *reinterpret_cast<uint32_t*>(d + (uint32_t)((y0 + r) * dp + x4)) = out;
   }
 }
 
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     for (int i = 0; i < kDescKP; i++) {
       const u8* ib = DVS_RLP(imgL, i);
       const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
-      d[i] = *reinterpret_cast<const uint4u*>(ib + (int64_t)(yi + v) * pi + xi + pcol);
+      d[i] = *reinterpret_cast<const uint4u*>(ib + (uint32_t)(mul_i24(yi + v, pi) + xi + pcol));  // all terms >= 0, 24-bit product
     }
   }
   float4 ori = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1452,8 +1453,8 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     const int bp = DVS_RL(bpL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);                                       \
     const int xa = (xi - kWinR) & ~3; /* dword-aligned window origin; 48 bytes per row cover x-18 .. x+18 */  \
     const u8* o = bb + (int64_t)(yi - kWinR) * bp + xa;                                                        \
-    wq0_##i = *reinterpret_cast<const uint4*>(o + wr0 * bp + 16 * wc0);                                        \
-    wq1_##i = *reinterpret_cast<const uint4*>(o + wr1 * bp + 16 * wc1);                                        \
+    wq0_##i = *reinterpret_cast<const uint4*>(o + (uint32_t)(mul_i24(wr0, bp) + 16 * wc0));                    \
+    wq1_##i = *reinterpret_cast<const uint4*>(o + (uint32_t)(mul_i24(wr1, bp) + 16 * wc1));                    \
   }
   // a wave's life is one latency chain (slot -> patches / windows -> samples), so every window is requested up front: the
   // first half behind the patches, the second half into the registers the patches free
@@ -1539,8 +1540,8 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
       const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
       const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
       const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
-      const int t0 = bc[r0 * kWinPitch + c0];
-      const int t1 = bc[r1 * kWinPitch + c1];
+      const int t0 = bc[mad_i24(r0, kWinPitch, c0)];  // 24-bit multiply-add: the plain product compiles to a quarter-rate v_mul_lo_u32
+      const int t1 = bc[mad_i24(r1, kWinPitch, c1)];
       words[r] = __ballot(t0 < t1);
     }
     if ((vmask >> i) & 1u) {
