@@ -136,9 +136,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
                                                  const int* __restrict__ beta) {
-  // the level chain is seven dependent, latency-bound launches that run beside a VALU-saturating kernel (FAST): without issue
-  // priority its waves starve (a 55 us level took 250 us) and the chain spills into the fetch-bound descriptor stage
-  __builtin_amdgcn_s_setprio(3);
+  // (raising these waves' issue priority over the FAST waves they run beside, s_setprio, was measured: 3 % slower overall)
   const int gx = blockIdx.x * 64 + threadIdx.x;
   const int x4 = gx * 4;
   // a wavefront is one threadIdx.y row of the (64, 4) block: everything that depends on y only is wave-uniform, and saying so
