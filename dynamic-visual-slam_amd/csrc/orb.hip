@@ -534,7 +534,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(256), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
@@ -849,7 +849,7 @@ dvs_status dvs_test_sort_nodes_device(const int32_t* count, const int32_t* ulx, 
   unsigned long long* d = nullptr;
   DVS_HIP(hipMalloc(&d, sizeof(unsigned long long) * n));
   hipError_t e = hipMemcpy(d, v.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_test_sort, dim3(1), dim3(256), 0, 0, d, n); e = hipGetLastError(); }
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_test_sort, dim3(1), dim3(kOctT), 0, 0, d, n); e = hipGetLastError(); }
   if (e == hipSuccess) e = hipMemcpy(v.data(), d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   DVS_HIP(e);
