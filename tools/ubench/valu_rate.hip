@@ -19,7 +19,14 @@ __global__ void k(unsigned* out, int iters) {
     else if (OP == 5) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(r) : "v"(b));                  \
     else if (OP == 6) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(r) : "v"(b));               \
     else if (OP == 7) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r) : "v"(b));                    \
-    else if (OP == 8) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(r) : "v"(b));
+    else if (OP == 8) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(r) : "v"(b));         \
+    else if (OP == 9) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(r) : "v"(b));                   \
+    else if (OP == 10) asm volatile("v_max_i32_e32 %0, %0, %1" : "+v"(r) : "v"(b));                  \
+    else if (OP == 11) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(r));                        \
+    else if (OP == 12) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(r) : "v"(b));                  \
+    else if (OP == 13) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r) : "v"(b));               \
+    else if (OP == 14) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(r) : "v"(b));                   \
+    else if (OP == 15) asm volatile("v_max_i16_e32 %0, %0, %1" : "+v"(r) : "v"(b));
     STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
     STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
   }
@@ -52,5 +59,7 @@ int main() {
   CK(hipMalloc(&d, 64));
   run<0>("v_pk_max_i16", d); run<1>("v_perm_b32", d); run<2>("v_add_u32", d); run<3>("v_dot4_u32_u8", d); run<4>("v_bcnt_u32_b32", d);
   run<5>("v_min3_u32", d); run<6>("v_mad_u32_u24", d); run<7>("v_mul_lo_u32", d); run<8>("v_alignbyte_b32", d);
+  run<9>("v_xor_b32_e32", d); run<10>("v_max_i32_e32", d); run<11>("v_lshlrev_b32_e32", d); run<12>("v_xor_b32_e64", d);
+  run<13>("v_lshl_or_b32", d); run<14>("v_pk_add_u16", d); run<15>("v_max_i16_e32", d);
   return 0;
 }
