@@ -51,12 +51,14 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
 #pragma unroll
   for (int u = 0; u < kQPL; u++) bestp[u] = 0xFFFFFFFFu;
   auto dist = [&](int u, const u64* r) -> unsigned {
-    unsigned d = 0;
+    unsigned d;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const u64 x = a[u][k] ^ r[k];
-      // v_bcnt_u32_b32 d, x, d : popcount with accumulate (hipcc otherwise emits separate v_add3 trees)
-      asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"((unsigned)x));
+      // v_bcnt_u32_b32 d, x, d : popcount with accumulate (hipcc otherwise emits separate v_add3 trees); the first one adds to
+      // the inline constant 0 instead of a zeroed register
+      if (k == 0) asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"((unsigned)x));
+      else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"((unsigned)x));
       asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"((unsigned)(x >> 32)));
     }
     return d;
