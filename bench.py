@@ -255,7 +255,8 @@ def main():
                 P["stream"].wait_event(P["xdone"])
             P["mat"].match_sequence_device(P["desc"][s].data_ptr(), P["n"][s].data_ptr(), cap, B, prev_desc, prev_n,
                                            P["idx"].data_ptr(), P["dist"].data_ptr())
-            P["done"].record(P["stream"])
+            if collective or NP > 1:
+                P["done"].record(P["stream"])   # only the exchange stream / another pipeline ever waits for it
         P["last"] = (P["desc"][s][B - 1], P["n"][s][B - 1:B])
         P["cur"] = s
 

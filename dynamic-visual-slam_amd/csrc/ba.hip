@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
                                                  double* __restrict__ rawRes, double* __restrict__ rawJq,
                                                  double* __restrict__ rawJt, double* __restrict__ rawJX) {
   __shared__ double wred[4][28];
+  __shared__ double stage[256 * 12];  // 24 KB: store staging (see below)
   const BaChunk ch = chunks[blockIdx.x];
   const int tid = threadIdx.x;
   const int c = ch.cam;
@@ -145,20 +146,57 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
   for (int i = 0; i < 12; i++) jp[i] *= sc;
 #pragma unroll
   for (int i = 0; i < 6; i++) jx[i] *= sc;
-  if (act && (flags & 1)) {
-    res[2 * p] = r[0]; res[2 * p + 1] = r[1];
-#pragma unroll
-    for (int i = 0; i < 12; i++) Jp[12 * p + i] = jp[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) Jl[6 * p + i] = jx[i];
-  }
+  // Stores go through LDS: a thread's 2 + 12 + 6 + 18 doubles are array-of-structures records (stride 16 / 96 / 48 / 144 bytes
+  // across lanes — every store instruction would touch 64 cache lines), but the workgroup's <= 256 consecutive observations
+  // form ONE contiguous block of each array, which is then written out with consecutive 8-byte lanes.
   const bool pf = P.pose_fixed[c] != 0;
-  if (act && (flags & 2)) {
-    const bool zero = pf || P.lm_fixed[l] != 0;
+  {
+    double* stg = stage;
+    auto flush = [&](double* dst, int n) {  // n doubles per observation staged at stg[tid * n ..]; barriers on both sides
+      __syncthreads();
+      const int tot = ch.count * n;
+      double* o = dst + (size_t)ch.start * n;
+      for (int k = tid; k < tot; k += 256) o[k] = stg[k];
+      __syncthreads();
+    };
+    if (flags & 1) {
+      if (act) {
 #pragma unroll
-    for (int a = 0; a < 6; a++)
+        for (int i = 0; i < 12; i++) stg[12 * tid + i] = jp[i];
+      }
+      flush(Jp, 12);
+      if (act) {
 #pragma unroll
-      for (int bb = 0; bb < 3; bb++) W[18 * p + 3 * a + bb] = zero ? 0.0 : jp[a] * jx[bb] + jp[6 + a] * jx[3 + bb];
+        for (int i = 0; i < 6; i++) stg[8 * tid + i] = jx[i];
+        stg[8 * tid + 6] = r[0]; stg[8 * tid + 7] = r[1];
+      }
+      __syncthreads();
+      {  // Jl (6 per observation) and res (2 per observation) from the 8-double records
+        const int tot6 = ch.count * 6, tot2 = ch.count * 2;
+        double* o6 = Jl + (size_t)ch.start * 6;
+        double* o2 = res + (size_t)ch.start * 2;
+        for (int k = tid; k < tot6; k += 256) { const int e = k / 6; o6[k] = stg[8 * e + (k - 6 * e)]; }
+        for (int k = tid; k < tot2; k += 256) o2[k] = stg[8 * (k >> 1) + 6 + (k & 1)];
+      }
+      __syncthreads();
+    }
+    if (flags & 2) {
+      const bool zero = pf || P.lm_fixed[l] != 0;
+      for (int half = 0; half < 2; half++) {  // W is 18 doubles per observation: 128 observations per pass fit the buffer
+        if (act && (tid >> 7) == half) {
+          double* sw = stg + 18 * (tid & 127);
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int bb = 0; bb < 3; bb++) sw[3 * a + bb] = zero ? 0.0 : jp[a] * jx[bb] + jp[6 + a] * jx[3 + bb];
+        }
+        __syncthreads();
+        const int first = 128 * half, cntp = min(max(ch.count - first, 0), 128);
+        double* o = W + (size_t)(ch.start + first) * 18;
+        for (int k = tid; k < cntp * 18; k += 256) o[k] = stg[k];
+        __syncthreads();
+      }
+    }
   }
   // camera partials: 21 unique H_pp entries (row-major upper triangle), 6 gradient entries, cost
   double v[28];
@@ -173,10 +211,28 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
     v[27] = act ? 0.5 * rho0 : 0.0;
   }
   const int w = tid >> 6, lane = tid & 63;
+  // 28 wave-wide sums by a TRANSPOSING butterfly: at the step with lane bit B a lane keeps the half of the values its bit B
+  // selects and adds its partner's copies of them, so the cross-lane traffic halves each step — 32 exchanges instead of the
+  // 28 x 6 of one shuffle tree per value (which was 54 % of this kernel's time).  Fixed association: pairwise by lane bits
+  // 5, 4, 3, 2, 1, 0.  Value k ends up in the lanes whose bits 5..1 spell k.
+  {
+    double q[32];
 #pragma unroll
-  for (int k = 0; k < 28; k++) {
-    const double sred = wave_sum(v[k]);
-    if (lane == 0) wred[w][k] = sred;
+    for (int k = 0; k < 32; k++) q[k] = k < 28 ? v[k] : 0.0;
+#define DVS_BFLY64(n, o)                                      \
+    {                                                         \
+      const bool hi = (lane & (o)) != 0;                      \
+      _Pragma("unroll") for (int j = 0; j < (n); j++) {       \
+        const double keep = hi ? q[(n) + j] : q[j];           \
+        const double send = hi ? q[j] : q[(n) + j];           \
+        q[j] = keep + __shfl_xor(send, (o));                  \
+      }                                                       \
+    }
+    DVS_BFLY64(16, 32) DVS_BFLY64(8, 16) DVS_BFLY64(4, 8) DVS_BFLY64(2, 4) DVS_BFLY64(1, 2)
+#undef DVS_BFLY64
+    const double tot = q[0] + __shfl_xor(q[0], 1);
+    const int k = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0 && k < 28) wred[w][k] = tot;
   }
   __syncthreads();
   if (tid < 28) partial[(size_t)blockIdx.x * 28 + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
@@ -785,6 +841,7 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
   DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
   DVS_HIP(hipMalloc((void**)&h->d_costCam, (size_t)std::max(K, 1) * 8)); DVS_HIP(hipMemset(h->d_costCam, 0, (size_t)std::max(K, 1) * 8));
   DVS_HIP(hipMalloc((void**)&h->d_ticket, 4)); DVS_HIP(hipMemset(h->d_ticket, 0, 4));
+  DVS_HIP(hipStreamSynchronize(nullptr));  // the memsets above run on the null stream; the handle's stream is non-blocking
   return DVS_OK;
 }
 

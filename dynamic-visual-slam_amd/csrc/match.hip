@@ -302,7 +302,9 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
   if (!d_prev_desc) {  // no predecessor: frame 0 matches against nothing (train_idx -1, dist INT32_MAX)
     if (!m->d_zero) {
       DVS_HIP(hipMalloc((void**)&m->d_zero, 64));
-      DVS_HIP(hipMemset(m->d_zero, 0, 64));
+      // on the matcher's own (non-blocking) stream, i.e. ordered before the kernel below: a hipMemset on the null stream is not,
+      // and the kernel then read an uninitialised row count (intermittent GPU fault in tests/test_gpu_match.py)
+      DVS_HIP(hipMemsetAsync(m->d_zero, 0, 64, m->stream));
     }
     d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
   }

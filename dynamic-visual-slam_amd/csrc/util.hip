@@ -123,6 +123,7 @@ dvs_status dvs_memcpy_d2h(int32_t device, void* dst, const void* src, size_t byt
 dvs_status dvs_memset(int32_t device, void* dst, int value, size_t bytes) {
   DVS_TRY(dvs::check_device(device));
   DVS_HIP(hipMemset(dst, value, bytes));
+  DVS_HIP(hipStreamSynchronize(nullptr));  // complete before the caller enqueues on a non-blocking stream
   return DVS_OK;
 }
 }
