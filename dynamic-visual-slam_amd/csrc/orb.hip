@@ -54,7 +54,7 @@ struct dvs_orb {
   // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
   u8* d_pyr_alt = nullptr;
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
-  bool env_cascade = false;        // diagnostics (environment, read at creation)
+  int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
   int env_fast_tail = 0;
   bool pf_valid = false;
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
@@ -457,7 +457,10 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // k_pyr_cascade (all levels in one launch, LDS ping-pong) is bit-identical and reads level 0 only ~1.1x, but measured
   // SLOWER than the per-level chain running beside FAST (0.29 vs 0.20 ms per 64 frames: the resize arithmetic is VALU-issue
   // bound, so removing the launches and the re-reads buys nothing).  Kept selectable for HBM-traffic experiments.
-  const bool cascade = !prefetched && h->env_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
+  // few frames (the live one-frame-per-callback pattern): the launch chain, not the arithmetic, sets the latency -> all levels in
+  // one launch (0.31 -> 0.25 ms per 1280x720 frame); batches keep the per-level chain that runs beside FAST
+  const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 4;
+  const bool cascade = !prefetched && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
   const bool ov = !prefetched && !cascade && h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
   if (prefetched) {
@@ -603,10 +606,11 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
-  // diagnostics, read once: DVS_NO_OVERLAP=1 every stage alone on the stream; DVS_CASCADE=1 all-levels-in-one-launch pyramid;
+  // diagnostics, read once: DVS_NO_OVERLAP=1 every stage alone on the stream; DVS_CASCADE=1 / 0 all-levels-in-one-launch pyramid
+  // always / never (default: for <= 4 frames);
   // DVS_FAST_TAIL=l first level of the merged FAST tail launch (in-step pyramid only)
   if (const char* e2 = getenv("DVS_NO_OVERLAP")) h->overlap = !(e2[0] == '1');
-  if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1';
+  if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1' ? 1 : 0;
   if (const char* e4 = getenv("DVS_FAST_TAIL")) h->env_fast_tail = atoi(e4);
   int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
