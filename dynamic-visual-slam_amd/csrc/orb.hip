@@ -538,7 +538,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(nimg <= 4 ? kOctTMax : kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs

@@ -105,6 +105,20 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
 // separated by barriers, i.e. latency-bound: 512 threads shorten it (0.117 -> 0.091 ms alone), but it runs beside the blur and
 // the wave slots it then occupies cost the blur more than the quad-tree gains (81 k -> 79 k frames/s; 1024: 75 k)
 constexpr int kOctT = 256;
+constexpr int kOctTMax = 512;  // few frames: nothing competes for the wave slots, the tree alone decides the latency
+// exclusive scan over blockDim.x (multiple of 64, <= kOctTMax) threads; wsum = kOctTMax / 64 + 1 ints
+__device__ __forceinline__ int block_excl_scan_rt(int v, int* wsum, int& total) {
+  const int nw = (int)blockDim.x >> 6;
+  int incl = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane_id() == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) { int sv = wsum[i]; if (i < w) base += sv; tot += sv; }
+  total = tot;
+  return base + incl - v;
+}
 
 // =============================================================================================
 // pyramid: cv::resize(prev, cur, sz, 0, 0, INTER_LINEAR) on 8UC1 with OpenCV's 11-bit fixed-point
@@ -720,6 +734,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
 // Points never move: each keeps the list position of its node (nodeOf); a node's winner is the max
 // response with the lowest candidate index (:757-776), resolved with one atomicMax per point.
 // =============================================================================================
+#define OCT_T ((int)blockDim.x)  /* threads of a quad-tree workgroup: 256 beside the blur, 512 for few frames (see kOctT) */
 struct QNode { int16_t ulx, uly, brx, bry; int32_t cnt; int32_t pt; };
 
 __device__ __forceinline__ int qt_quadrant(const QNode& nd, int x, int y) {
@@ -754,9 +769,9 @@ struct QtShared {
 // counts children of every multi-point node of the current list
 __device__ __forceinline__ void qt_count_children(const QNode* nodes, int S, int* childCnt, const uint32_t* pts,
                                                   const int* nodeOf, int n) {
-  for (int k = threadIdx.x; k < 4 * S; k += kOctT) childCnt[k] = 0;
+  for (int k = threadIdx.x; k < 4 * S; k += OCT_T) childCnt[k] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += kOctT) {
+  for (int i = threadIdx.x; i < n; i += OCT_T) {
     const int k = nodeOf[i];
     if (k >= 0) {
       const uint32_t p = pts[i];
@@ -779,16 +794,16 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
   QNode* nw = sh.nodes_(cur ^ 1);
   // unsplit nodes: stable compaction behind the children block
   int carry = 0;
-  for (int b = 0; b < S; b += kOctT) {
+  for (int b = 0; b < S; b += OCT_T) {
     const int k = b + threadIdx.x;
     const int u = (k < S && !sh.flag[k]) ? 1 : 0;
     int tot;
-    const int ex = block_excl_scan<kOctT>(u, wsum, tot);
+    const int ex = block_excl_scan_rt(u, wsum, tot);
     if (u) sh.posArr[k] = -((T + carry + ex) + 1);
     carry += tot;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < S; k += kOctT) {
+  for (int k = threadIdx.x; k < S; k += OCT_T) {
     const QNode nd = old[k];
     if (sh.flag[k]) {
       const int base = sh.posArr[k];
@@ -801,7 +816,7 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += kOctT) {
+  for (int i = threadIdx.x; i < n; i += OCT_T) {
     const int k = nodeOf[i];
     if (k < 0) continue;
     const int pa = sh.posArr[k];
@@ -820,12 +835,12 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
 __device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T, int* wsum) {
   const QNode* nodes = sh.nodes_(cur);
   int carry = 0;
-  for (int b = 0; b < T; b += kOctT) {
+  for (int b = 0; b < T; b += OCT_T) {
     const int j = b + threadIdx.x;
     const int pos = T - 1 - j;
     const int fl = (j < T && nodes[pos].cnt > 1) ? 1 : 0;
     int tot;
-    const int ex = block_excl_scan<kOctT>(fl, wsum, tot);
+    const int ex = block_excl_scan_rt(fl, wsum, tot);
     if (fl) sh.expl[carry + ex] = pos;
     carry += tot;
   }
@@ -902,7 +917,7 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
   for (int cur = 0;; cur ^= 1) {
     const int cnt = ss.cnt[cur];
     if (cnt == 0) break;
-    for (int ri = wv; ri < cnt; ri += kOctT / 64) {
+    for (int ri = wv; ri < cnt; ri += OCT_T / 64) {
       const uint32_t r = ss.rng[cur][ri];
       const int f = (int)(r & 0xFFFu), l = (int)((r >> 12) & 0xFFFu), d = (int)(r >> 24);
       if (d == 0) {  // depth limit: heapsort the range (std::__partial_sort), every element its own leaf
@@ -920,7 +935,7 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
   }
   // leaves: stable placement by rank.  Only the payload (low 32 bits: the list index the callers read back) is carried to the
   // sorted position, through Rp / Lp, so that no element has to be held in registers across the barrier
-  for (int i = tid; i < m; i += kOctT) {
+  for (int i = tid; i < m; i += OCT_T) {
     const int fl = Lp[i];
     const int f = fl & 0xFFFF, l = fl >> 16;
     const unsigned long long ke = a[i] >> 12;
@@ -932,29 +947,29 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
     Rp[i] = rnk;
   }
   __syncthreads();
-  for (int i = tid; i < m; i += kOctT) Lp[Rp[i]] = (int)(unsigned)a[i];
+  for (int i = tid; i < m; i += OCT_T) Lp[Rp[i]] = (int)(unsigned)a[i];
   __syncthreads();
-  for (int i = tid; i < m; i += kOctT) a[i] = (unsigned long long)(unsigned)Lp[i];
+  for (int i = tid; i < m; i += OCT_T) a[i] = (unsigned long long)(unsigned)Lp[i];
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kOctT) void k_test_sort(unsigned long long* __restrict__ v, int m) {
+__global__ __launch_bounds__(kOctTMax) void k_test_sort(unsigned long long* __restrict__ v, int m) {
   __shared__ unsigned long long a[kMaxQuota];
   __shared__ int Lp[kMaxQuota], Rp[kMaxQuota];
   __shared__ SortShared ss;
-  for (int i = threadIdx.x; i < m; i += kOctT) a[i] = v[i];
+  for (int i = threadIdx.x; i < m; i += OCT_T) a[i] = v[i];
   __syncthreads();
   qt_sort_block(a, m, Lp, Rp, ss);
-  for (int i = threadIdx.x; i < m; i += kOctT) v[i] = a[i];
+  for (int i = threadIdx.x; i < m; i += OCT_T) v[i] = a[i];
 }
 
-__global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
+__global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
                                                 int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int wsum[kOctT / 64 + 1];
+  __shared__ int wsum[kOctTMax / 64 + 1];
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
   __shared__ SortShared s_sort;
   const int tid = threadIdx.x;
@@ -986,11 +1001,11 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
   // ---- gather: candidate order = cells row-major, pixels row-major inside a cell -------------
   {
     int carry = 0;
-    for (int b = 0; b < L.nCells; b += kOctT) {
+    for (int b = 0; b < L.nCells; b += OCT_T) {
       const int c = b + tid;
       const int v = c < L.nCells ? cc[c] : 0;
       int tot;
-      const int ex = block_excl_scan<kOctT>(v, wsum, tot);
+      const int ex = block_excl_scan_rt(v, wsum, tot);
       if (c < L.nCells) co[c] = carry + ex;
       carry += tot;
     }
@@ -1002,11 +1017,11 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
     // independent lookup per candidate instead of a serial per-cell copy chain.
     const bool coLds = L.nCells <= 4 * nmax;
     int* lco = sh.childCnt;
-    if (coLds) for (int c = tid; c < L.nCells; c += kOctT) lco[c] = co[c];
+    if (coLds) for (int c = tid; c < L.nCells; c += OCT_T) lco[c] = co[c];
     __syncthreads();
     const int* cof = coLds ? lco : co;
     const int total = s_n;
-    for (int i = tid; i < total; i += kOctT) {
+    for (int i = tid; i < total; i += OCT_T) {
       int lo = 0, hi = L.nCells;  // first cell with offset > i
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (cof[mid] <= i) lo = mid + 1; else hi = mid; }
       const int c = lo - 1;
@@ -1023,20 +1038,20 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
   // ---- roots (:559-601) ------------------------------------------------------------------------
   {
     const int nIni = L.nIni;
-    for (int k = tid; k < nIni; k += kOctT) sh.childCnt[k] = 0;
+    for (int k = tid; k < nIni; k += OCT_T) sh.childCnt[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += kOctT) {
+    for (int i = tid; i < n; i += OCT_T) {
       const int r = (int)__fdiv_rn((float)pt_x(pts[i]), L.hX);  // vpIniNodes[kp.pt.x/hX]
       nodeOf[i] = r;  // root index for now
       atomicAdd(&sh.childCnt[r], 1);
     }
     __syncthreads();
     int carry = 0;
-    for (int b = 0; b < nIni; b += kOctT) {
+    for (int b = 0; b < nIni; b += OCT_T) {
       const int k = b + tid;
       const int u = (k < nIni && sh.childCnt[k] > 0) ? 1 : 0;
       int tot;
-      const int ex = block_excl_scan<kOctT>(u, wsum, tot);
+      const int ex = block_excl_scan_rt(u, wsum, tot);
       if (k < nIni) sh.posArr[k] = u ? carry + ex : -1;
       if (u) {
         QNode nd;
@@ -1050,7 +1065,7 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
     }
     if (tid == 0) s_S = carry;
     __syncthreads();
-    for (int i = tid; i < n; i += kOctT) {
+    for (int i = tid; i < n; i += OCT_T) {
       const int pos = sh.posArr[nodeOf[i]];
       if (sh.nodes_(0)[pos].cnt == 1) { sh.nodes_(0)[pos].pt = i; nodeOf[i] = -1; }
       else nodeOf[i] = pos;
@@ -1068,7 +1083,7 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
     {
       // children block: node k's children sit in front of the children of all earlier nodes
       int carry = 0;
-      for (int b = 0; b < S; b += kOctT) {
+      for (int b = 0; b < S; b += OCT_T) {
         const int k = b + tid;
         int e = 0;
         if (k < S) {
@@ -1081,14 +1096,14 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
           }
         }
         int tot;
-        const int ex = block_excl_scan<kOctT>(e, wsum, tot);
+        const int ex = block_excl_scan_rt(e, wsum, tot);
         if (k < S) sh.ecum[k] = carry + ex + e;  // inclusive
         carry += tot;
       }
       if (tid == 0) { s_T = carry; s_nexp = 0; }
       __syncthreads();
       const int T = s_T;
-      for (int k = tid; k < S; k += kOctT)
+      for (int k = tid; k < S; k += OCT_T)
         if (sh.flag[k]) sh.posArr[k] = T - sh.ecum[k];
       if (nExpandLocal) atomicAdd(&s_nexp, nExpandLocal);
       __syncthreads();
@@ -1098,7 +1113,7 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
     int nUnsplit = 0;
     {  // count unsplit nodes = S - (#split); derive from flags
       int loc = 0;
-      for (int k = tid; k < S; k += kOctT) loc += sh.flag[k] ? 0 : 1;
+      for (int k = tid; k < S; k += OCT_T) loc += sh.flag[k] ? 0 : 1;
       if (tid == 0) s_c = 0;
       __syncthreads();
       if (loc) atomicAdd(&s_c, loc);
@@ -1119,12 +1134,12 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
       const int Sb = s_S;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
       qt_count_children(sh.nodes_(cur), Sb, sh.childCnt, pts, nodeOf, n);
-      for (int r = tid; r < m; r += kOctT) {
+      for (int r = tid; r < m; r += OCT_T) {
         const QNode& nd = sh.nodes_(cur)[sh.expl[r]];
         sh.sortbuf[r] = ((unsigned long long)(uint32_t)nd.cnt << 28) | ((unsigned long long)(uint16_t)nd.ulx << 12) |
                         (unsigned long long)r;
       }
-      for (int k = tid; k < Sb; k += kOctT) sh.flag[k] = 0;
+      for (int k = tid; k < Sb; k += OCT_T) sh.flag[k] = 0;
       __syncthreads();
       if (!(g->debug & 1)) qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
@@ -1132,12 +1147,12 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
       if (tid == 0) s_c = 0;
       __syncthreads();
       int below = 0;
-      for (int b = 0; b < m; b += kOctT) {
+      for (int b = 0; b < m; b += OCT_T) {
         const int r = b + tid;
         int e = 0;
         if (r < m) e = __popc(qt_mask(sh.childCnt, sh.expl[(int)(sh.sortbuf[m - 1 - r] & 0xFFFull)]));
         int tot;
-        const int ex = block_excl_scan<kOctT>(e, wsum, tot);
+        const int ex = block_excl_scan_rt(e, wsum, tot);
         if (r < m) {
           const int incl = carry + ex + e;
           sh.ecum[r] = incl;
@@ -1152,7 +1167,7 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
       const int M = c < m ? c + 1 : m;  // break right after the split that reaches N (:746-747)
       const int Tm = sh.ecum[M - 1];
       __syncthreads();
-      for (int r = tid; r < M; r += kOctT) {
+      for (int r = tid; r < M; r += OCT_T) {
         const int k = sh.expl[(int)(sh.sortbuf[m - 1 - r] & 0xFFFull)];
         sh.flag[k] = 1;
         sh.posArr[k] = Tm - sh.ecum[r];
@@ -1172,15 +1187,15 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
   const int S = (n == 0) ? 0 : s_S;
   QNode* nodes = sh.nodes_(cur);
   int* best = sh.childCnt;
-  for (int k = tid; k < S; k += kOctT) best[k] = 0;
+  for (int k = tid; k < S; k += OCT_T) best[k] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += kOctT) {
+  for (int i = tid; i < n; i += OCT_T) {
     const int k = nodeOf[i];
     if (k >= 0) atomicMax((unsigned int*)&best[k], ((uint32_t)pt_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i));
   }
   __syncthreads();
   uint32_t* outp = lvlKp + (uint64_t)f * g->kpBlock + L.kpOff;
-  for (int k = tid; k < S; k += kOctT) {
+  for (int k = tid; k < S; k += OCT_T) {
     const QNode nd = nodes[k];
     const int i = nd.cnt == 1 ? nd.pt : (int)(0xFFFFFFu - ((uint32_t)best[k] & 0xFFFFFFu));
     if (k < N + 4) outp[k] = pts[i];
@@ -1188,6 +1203,7 @@ __global__ __launch_bounds__(kOctT) void k_octree(const Geom* __restrict__ g, co
   if (tid == 0) lvlKpCount[f * g->nlevels + level] = min(S, N + 4);
 }
 
+#undef OCT_T
 // =============================================================================================
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101 on the level itself — OpenCV's 8-bit fixed-point path:
 // horizontal Q8.8 (exact in u16), vertical Q16.16, (acc + 32768) >> 16.  Tile = 64 x 16 outputs.
