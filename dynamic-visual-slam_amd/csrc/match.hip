@@ -18,8 +18,11 @@ namespace dvs {
 
 typedef unsigned long long u64;
 
-constexpr int kSplit = 8;   // train-set slices per workgroup (one wavefront each): finer waves balance the last scheduling round
-constexpr int kQPL = 2;     // queries per lane: every scalar train row feeds two independent popcount chains
+// kSplit: train-set slices per workgroup (one wavefront each): finer waves balance the last scheduling round
+// kQPL:   queries per lane: every scalar train row feeds kQPL independent popcount chains
+// <8, 2> is the throughput shape (batches of jobs); <16, 1> quadruples the wavefronts of a job for the live pattern of ONE
+// 2000 x 2000 job, which otherwise occupies an eighth of the SIMDs (0.041 -> see tools/latency.py)
+template <int kSplit, int kQPL>
 __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
                                                        const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
                                                        int* __restrict__ outIdx, int* __restrict__ outDist,
@@ -285,8 +288,16 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   DVS_ARG(t_stride_rows < (1 << 23));  // k_match packs the train index into 23 bits
   if (npairs == 0) return DVS_OK;
   DVS_HIP(hipSetDevice(m->device));
+  const bool few = (long long)npairs * q_stride_rows <= 16384;  // a few jobs: favour wavefront count over per-wave efficiency
+  if (few) {
+    hipLaunchKernelGGL((k_match<16, 1>), dim3((q_stride_rows + 63) / 64, npairs), dim3(1024), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows,
+                       (const u64*)d_t, d_nt, 0, t_stride_rows, d_idx, d_dist);
+    DVS_HIP(hipGetLastError());
+    return DVS_OK;
+  }
+  constexpr int kSplit = 8, kQPL = 2;
   dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
-  hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
+  hipLaunchKernelGGL((k_match<kSplit, kQPL>), grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
                      t_stride_rows, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
@@ -308,9 +319,10 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
     }
     d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
   }
+  constexpr int kSplit = 8, kQPL = 2;
   dim3 grid((stride_rows + 64 * kQPL - 1) / (64 * kQPL), nframes);
   // train of job p >= 1 = frame p - 1: the base pointers are shifted back by one frame and never dereferenced for job 0
-  hipLaunchKernelGGL(k_match, grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
+  hipLaunchKernelGGL((k_match<kSplit, kQPL>), grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
                      (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
@@ -330,7 +342,11 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
   int* d_dist = d_idx + nq;
   DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
   if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-  hipLaunchKernelGGL(k_match, dim3((nq + 64 * kQPL - 1) / (64 * kQPL), 1), dim3(64 * kSplit), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
+  if (nq <= 16384)
+    hipLaunchKernelGGL((k_match<16, 1>), dim3((nq + 63) / 64, 1), dim3(1024), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
+                     (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
+  else
+    hipLaunchKernelGGL((k_match<8, 2>), dim3((nq + 127) / 128, 1), dim3(512), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   DVS_HIP(hipMemcpyAsync(train_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
