@@ -1013,19 +1013,20 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     __syncthreads();
     const bool inLds = s_n <= ptsLdsCap;
     if (inLds) { pts = ldsPts; nodeOf = ldsNodeOf; }
-    // cell of candidate i = last cell whose offset is <= i (binary search; offsets in LDS when they fit).  One
-    // independent lookup per candidate instead of a serial per-cell copy chain.
-    const bool coLds = L.nCells <= 4 * nmax;
-    int* lco = sh.childCnt;
-    if (coLds) for (int c = tid; c < L.nCells; c += OCT_T) lco[c] = co[c];
-    __syncthreads();
-    const int* cof = coLds ? lco : co;
+    // cell of candidate i: every cell stamps its index over its own slot range (cells hold a handful of candidates each, the
+    // stores are fire-and-forget), then each candidate is one independent lookup — instead of a serial per-cell copy chain
+    // (the first version) or a 10-step binary search over the offsets per candidate (the second).  The stamps live in the
+    // node-of-point array, which is not in use yet.
+    int* cellOf = inLds ? ldsNodeOf : nodeOf;
     const int total = s_n;
+    for (int c = tid; c < L.nCells; c += OCT_T) {
+      const int b0 = co[c], cn = cc[c];
+      for (int k = 0; k < cn; k++) cellOf[b0 + k] = c;
+    }
+    __syncthreads();
     for (int i = tid; i < total; i += OCT_T) {
-      int lo = 0, hi = L.nCells;  // first cell with offset > i
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cof[mid] <= i) lo = mid + 1; else hi = mid; }
-      const int c = lo - 1;
-      const uint32_t v = cnd[(uint64_t)c * L.cellCap + (i - cof[c])];
+      const int c = cellOf[i];
+      const uint32_t v = cnd[(uint64_t)c * L.cellCap + (i - co[c])];
       gpts[i] = v;                      // kept in HBM too: dvs_orb_get_candidates reads it
       if (inLds) ldsPts[i] = v;
     }
