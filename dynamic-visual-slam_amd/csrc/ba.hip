@@ -397,13 +397,32 @@ __global__ __launch_bounds__(256) void k_lm_landmarks(int K, int L, const double
   }
 }
 
+// 32 wave-wide sums by a transposing butterfly (see k_ba_eval): returns this lane's total; value k lives in the lanes whose bits
+// 5..1 spell k (both lanes of the pair hold it).  Fixed association: pairwise by lane bits 5, 4, 3, 2, 1, 0.
+__device__ __forceinline__ double wave_butterfly32(double (&q)[32], int lane) {
+#define DVS_BFLY64(n, o)                                      \
+  {                                                           \
+    const bool hi = (lane & (o)) != 0;                        \
+    _Pragma("unroll") for (int j = 0; j < (n); j++) {         \
+      const double keep = hi ? q[(n) + j] : q[j];             \
+      const double send = hi ? q[j] : q[(n) + j];             \
+      q[j] = keep + __shfl_xor(send, (o));                    \
+    }                                                         \
+  }
+  DVS_BFLY64(16, 32) DVS_BFLY64(8, 16) DVS_BFLY64(4, 8) DVS_BFLY64(2, 4) DVS_BFLY64(1, 2)
+#undef DVS_BFLY64
+  return q[0] + __shfl_xor(q[0], 1);
+}
+__device__ __forceinline__ int butterfly32_index(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
 // reduced camera system, one workgroup per 6x6 block (ci, ck):  S = (H_pp + D/radius) - sum_l Y_l,ci W_l,ck^T,  rhs likewise
 __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int* __restrict__ slotCam, const int* __restrict__ obsOf,
                                                   const unsigned char* __restrict__ active, const double* __restrict__ Hpp,
                                                   const double* __restrict__ g, const double* __restrict__ scale,
                                                   const double* __restrict__ diag, double radius, const double* __restrict__ Ws,
                                                   const double* __restrict__ Y, double* __restrict__ S, double* __restrict__ rhs) {
-  __shared__ double sm[256];
   const int ci = blockIdx.x, ck = blockIdx.y;
   const int cI = slotCam[ci], cK = slotCam[ck];
   double acc[36], r[6];
@@ -425,34 +444,50 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
       for (int a = 0; a < 6; a++) r[a] += y[3 * a] * gl0 + y[3 * a + 1] * gl1 + y[3 * a + 2] * gl2;
     }
   }
+  // 42 block sums: two wave butterflies (32 + 10 values) per wavefront, then the four wavefronts' totals in wave order
+  __shared__ double wtot[4][48];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    double q[32];
 #pragma unroll
-  for (int k = 0; k < 36; k++) {
-    const double tot = block_sum_fixed(acc[k], sm);
-    if (threadIdx.x == 0) {
-      const int a = k / 6, b = k - 6 * a;
-      double v = 0.0;
-      if (ci == ck) {
-        v = Hpp[36 * (size_t)cI + 6 * a + b] * scale[6 * cI + a] * scale[6 * cI + b];
-        if (a == b) v += diag[6 * cI + a] / radius;
-      }
-      S[(size_t)(6 * ci + a) * n + 6 * ck + b] = v - tot;
-    }
+    for (int k = 0; k < 32; k++) q[k] = acc[k];
+    const double t0 = wave_butterfly32(q, lane);
+#pragma unroll
+    for (int k = 0; k < 32; k++) q[k] = k < 4 ? acc[32 + k] : (k < 10 ? r[k - 4] : 0.0);
+    const double t1 = wave_butterfly32(q, lane);
+    const int k = butterfly32_index(lane);
+    if ((lane & 1) == 0) { wtot[wv][k] = t0; if (k < 10) wtot[wv][32 + k] = t1; }
   }
-  if (ci == ck)
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      const double tot = block_sum_fixed(r[a], sm);
-      if (threadIdx.x == 0) rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a] - tot;
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int k = threadIdx.x, a = k / 6, b = k - 6 * a;
+    const double tot = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
+    double v = 0.0;
+    if (ci == ck) {
+      v = Hpp[36 * (size_t)cI + 6 * a + b] * scale[6 * cI + a] * scale[6 * cI + b];
+      if (a == b) v += diag[6 * cI + a] / radius;
     }
+    S[(size_t)(6 * ci + a) * n + 6 * ck + b] = v - tot;
+  } else if (ci == ck && threadIdx.x < 42) {
+    const int a = threadIdx.x - 36, k = 36 + a;
+    const double tot = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
+    rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a] - tot;
+  }
 }
 
-// dense Cholesky + two triangular solves of the n x n reduced system in LDS; every dot product runs in the k order of the
-// host routine (chol_solve), one thread per row of the current column.  Writes the (not yet negated) camera steps.
+// Dense Cholesky + two triangular solves of the n x n reduced system, one workgroup, everything in LDS.
+// Right-looking: at column j every thread forms l_ij = a_ij / sqrt(a_jj) for the rows it needs and subtracts l_ij l_kj from its
+// share of the trailing lower triangle — element (i, k) thus receives the subtractions j = 0, 1, ... in the same order as the
+// host routine's dot products (chol_solve), i.e. the factor is bit-identical to it; L goes to a second array so that a column
+// is never read and rewritten in the same phase (one barrier per column).  Forward substitution is column-oriented in the
+// host's order too; the backward one applies its updates from the last unknown down (a different association: rounding-level).
+// Writes the (not yet negated) camera steps.
 __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
                                                  const double* __restrict__ rhs, double* __restrict__ step, LmStatus* __restrict__ st) {
   extern __shared__ double lds[];
-  double* A = lds;
-  double* b = lds + (size_t)n * n;
+  double* A = lds;                       // working lower triangle (row-major n x n)
+  double* Lm = lds + (size_t)n * n;      // the factor
+  double* b = Lm + (size_t)n * n;
   __shared__ int bad;
   const int tid = threadIdx.x;
   for (int i = tid; i < n * n; i += 256) A[i] = S[i];
@@ -461,28 +496,43 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   if (tid == 0) bad = 0;
   __syncthreads();
   for (int j = 0; j < n; j++) {
-    if (tid == 0) {
-      double d = A[(size_t)j * n + j];
-      for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-      if (!(d > 0)) bad = 1;
-      A[(size_t)j * n + j] = sqrt(d);
+    const double ajj = A[(size_t)j * n + j];
+    if (!(ajj > 0)) { if (tid == 0) bad = 1; break; }  // uniform: every thread reads the same a_jj
+    const double d = sqrt(ajj);
+    const int m = n - j - 1;             // rows / columns j+1 .. n-1 of the trailing block
+    if (tid == 0) Lm[(size_t)j * n + j] = d;
+    for (int i = tid; i < m; i += 256) Lm[(size_t)(j + 1 + i) * n + j] = A[(size_t)(j + 1 + i) * n + j] / d;
+    // trailing update over the lower triangle (i >= k > j), flattened
+    const int cnt = m * (m + 1) / 2;
+    for (int e = tid; e < cnt; e += 256) {
+      int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);   // row of element e in the packed triangle
+      while ((ii + 1) * (ii + 2) / 2 <= e) ii++;
+      while (ii * (ii + 1) / 2 > e) ii--;
+      const int kk = e - ii * (ii + 1) / 2;
+      const int i = j + 1 + ii, k = j + 1 + kk;
+      const double lij = A[(size_t)i * n + j] / d, lkj = A[(size_t)k * n + j] / d;
+      A[(size_t)i * n + k] -= lij * lkj;
     }
     __syncthreads();
-    if (bad) break;
-    const double d = A[(size_t)j * n + j];
-    for (int i = j + 1 + tid; i < n; i += 256) {
-      double s = A[(size_t)i * n + j];
-      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-      A[(size_t)i * n + j] = s / d;
-    }
-    __syncthreads();
-  }
-  if (bad) { if (tid == 0) st->ok = 0; return; }
-  if (tid == 0) {
-    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
-    for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
   }
   __syncthreads();
+  if (bad) { if (tid == 0) st->ok = 0; return; }
+  // forward: L y = b, column by column (row i receives its subtractions in the order k = 0 .. i-1, like the host loop)
+  for (int j = 0; j < n; j++) {
+    const double yj = b[j] / Lm[(size_t)j * n + j];
+    __syncthreads();                      // everyone has read b[j] before thread 0 overwrites it
+    if (tid == 0) b[j] = yj;
+    for (int i = j + 1 + tid; i < n; i += 256) b[i] -= Lm[(size_t)i * n + j] * yj;
+    __syncthreads();
+  }
+  // backward: L^T x = y
+  for (int j = n - 1; j >= 0; j--) {
+    const double xj = b[j] / Lm[(size_t)j * n + j];
+    __syncthreads();
+    if (tid == 0) b[j] = xj;
+    for (int i = tid; i < j; i += 256) b[i] -= Lm[(size_t)j * n + i] * xj;
+    __syncthreads();
+  }
   for (int i = tid; i < n; i += 256) step[6 * slotCam[i / 6] + i % 6] = b[i];
 }
 
@@ -1155,7 +1205,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
     DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
     DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
-    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (96 * 96 + 96) * 8));
+    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 96 * 96 + 96) * 8));
   }
   DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
   DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
@@ -1198,7 +1248,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
-    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), ((size_t)n * n + n) * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
+    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), (2 * (size_t)n * n + n) * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_model, dim3(1), dim3(256), 0, st, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step, h->d_lmPart, h->d_status);
