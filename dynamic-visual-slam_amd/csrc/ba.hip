@@ -476,10 +476,9 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
 }
 
 // Dense Cholesky + two triangular solves of the n x n reduced system, one workgroup, everything in LDS.
-// Right-looking: at column j every thread forms l_ij = a_ij / sqrt(a_jj) for the rows it needs and subtracts l_ij l_kj from its
-// share of the trailing lower triangle — element (i, k) thus receives the subtractions j = 0, 1, ... in the same order as the
-// host routine's dot products (chol_solve), i.e. the factor is bit-identical to it; L goes to a second array so that a column
-// is never read and rewritten in the same phase (one barrier per column).  Forward substitution is column-oriented in the
+// Right-looking: at column j the scaled column l_ij = a_ij / sqrt(a_jj) is written to a second array, then the threads subtract
+// l_ij l_kj from the trailing lower triangle — element (i, k) thus receives the subtractions j = 0, 1, ... in the same order as
+// the host routine's dot products (chol_solve), i.e. the factor is bit-identical to it (two barriers per column).  Forward substitution is column-oriented in the
 // host's order too; the backward one applies its updates from the last unknown down (a different association: rounding-level).
 // Writes the (not yet negated) camera steps.
 __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
@@ -495,6 +494,7 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
   for (int j = 0; j < n; j++) {
     const double ajj = A[(size_t)j * n + j];
     if (!(ajj > 0)) { if (tid == 0) bad = 1; break; }  // uniform: every thread reads the same a_jj
@@ -502,38 +502,37 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
     const int m = n - j - 1;             // rows / columns j+1 .. n-1 of the trailing block
     if (tid == 0) Lm[(size_t)j * n + j] = d;
     for (int i = tid; i < m; i += 256) Lm[(size_t)(j + 1 + i) * n + j] = A[(size_t)(j + 1 + i) * n + j] / d;
-    // trailing update over the lower triangle (i >= k > j), flattened
-    const int cnt = m * (m + 1) / 2;
-    for (int e = tid; e < cnt; e += 256) {
-      int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);   // row of element e in the packed triangle
-      while ((ii + 1) * (ii + 2) / 2 <= e) ii++;
-      while (ii * (ii + 1) / 2 > e) ii--;
-      const int kk = e - ii * (ii + 1) / 2;
-      const int i = j + 1 + ii, k = j + 1 + kk;
-      const double lij = A[(size_t)i * n + j] / d, lkj = A[(size_t)k * n + j] / d;
-      A[(size_t)i * n + k] -= lij * lkj;
+    __syncthreads();
+    // trailing update over the lower triangle (i >= k > j): 16 x 16 thread tiling, no index arithmetic beyond the strides
+    for (int i = ty; i < m; i += 16) {
+      const double li = Lm[(size_t)(j + 1 + i) * n + j];
+      for (int k = tx; k <= i; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
     }
     __syncthreads();
   }
   __syncthreads();
   if (bad) { if (tid == 0) st->ok = 0; return; }
-  // forward: L y = b, column by column (row i receives its subtractions in the order k = 0 .. i-1, like the host loop)
-  for (int j = 0; j < n; j++) {
-    const double yj = b[j] / Lm[(size_t)j * n + j];
-    __syncthreads();                      // everyone has read b[j] before thread 0 overwrites it
-    if (tid == 0) b[j] = yj;
-    for (int i = j + 1 + tid; i < n; i += 256) b[i] -= Lm[(size_t)i * n + j] * yj;
-    __syncthreads();
+  // the two triangular solves are chains of n short steps: one wavefront, wave-level fences instead of workgroup barriers
+  if (tid < 64) {
+    const int lane = tid;
+    // forward: L y = b, column by column (row i receives its subtractions in the order k = 0 .. i-1, like the host loop)
+    for (int j = 0; j < n; j++) {
+      const double yj = b[j] / Lm[(size_t)j * n + j];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane == 0) b[j] = yj;
+      for (int i = j + 1 + lane; i < n; i += 64) b[i] -= Lm[(size_t)i * n + j] * yj;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // backward: L^T x = y
+    for (int j = n - 1; j >= 0; j--) {
+      const double xj = b[j] / Lm[(size_t)j * n + j];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane == 0) b[j] = xj;
+      for (int i = lane; i < j; i += 64) b[i] -= Lm[(size_t)j * n + i] * xj;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < n; i += 64) step[6 * slotCam[i / 6] + i % 6] = b[i];
   }
-  // backward: L^T x = y
-  for (int j = n - 1; j >= 0; j--) {
-    const double xj = b[j] / Lm[(size_t)j * n + j];
-    __syncthreads();
-    if (tid == 0) b[j] = xj;
-    for (int i = tid; i < j; i += 256) b[i] -= Lm[(size_t)j * n + i] * xj;
-    __syncthreads();
-  }
-  for (int i = tid; i < n; i += 256) step[6 * slotCam[i / 6] + i % 6] = b[i];
 }
 
 // landmark steps by back-substitution (already negated), and each landmark's share of step.g and step^T H step
