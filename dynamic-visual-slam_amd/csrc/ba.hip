@@ -387,13 +387,24 @@ __global__ __launch_bounds__(256) void k_lm_landmarks(int K, int L, const double
   Vi[3] = (f_ * g_ - d_ * i_) * id; Vi[4] = (a_ * i_ - c_ * g_) * id; Vi[5] = (c_ * d_ - a_ * f_) * id;
   Vi[6] = (d_ * h_ - e_ * g_) * id; Vi[7] = (b_ * g_ - a_ * h_) * id; Vi[8] = (a_ * e_ - b_ * d_) * id;
   for (int k = 0; k < 9; k++) Vinv[9 * (size_t)l + k] = Vi[k];
-  for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
-    const int p = lmObs[e], c = cam[p];
-    for (int a = 0; a < 6; a++) {
-      double w[3];
-      for (int b = 0; b < 3; b++) { w[b] = W[18 * (size_t)p + 3 * a + b] * scale[6 * c + a] * scale[j0 + b]; Ws[18 * (size_t)p + 3 * a + b] = w[b]; }
-      for (int b = 0; b < 3; b++) Y[18 * (size_t)p + 3 * a + b] = w[0] * Vi[b] + w[1] * Vi[3 + b] + w[2] * Vi[6 + b];
-    }
+}
+
+// per observation: the Jacobi-scaled W block and Y = W V^-1 of its landmark (one thread per observation instead of a loop over
+// a landmark's observations inside k_lm_landmarks: 20 000 threads instead of 2 000)
+__global__ __launch_bounds__(256) void k_lm_observations(int K, int R, const double* __restrict__ W, const int* __restrict__ cam,
+                                                         const int* __restrict__ lm, const double* __restrict__ scale,
+                                                         const unsigned char* __restrict__ active, const double* __restrict__ Vinv,
+                                                         double* __restrict__ Ws, double* __restrict__ Y) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= R) return;
+  const int l = lm[p], c = cam[p], j0 = 6 * K + 3 * l;
+  if (!active[j0]) return;
+  double Vi[9];
+  for (int k = 0; k < 9; k++) Vi[k] = Vinv[9 * (size_t)l + k];
+  for (int a = 0; a < 6; a++) {
+    double w[3];
+    for (int b = 0; b < 3; b++) { w[b] = W[18 * (size_t)p + 3 * a + b] * scale[6 * c + a] * scale[j0 + b]; Ws[18 * (size_t)p + 3 * a + b] = w[b]; }
+    for (int b = 0; b < 3; b++) Y[18 * (size_t)p + 3 * a + b] = w[0] * Vi[b] + w[1] * Vi[3 + b] + w[2] * Vi[6 + b];
   }
 }
 
@@ -1244,6 +1255,8 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
     hipLaunchKernelGGL(k_lm_landmarks, dim3((L + K + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_W, h->d_lmStart, h->d_lmObs,
                        h->d_cam, h->d_scale, h->d_diag, h->d_active, radius, reuse_diagonal ? 0 : 1, h->d_Vinv, h->d_Ws, h->d_Y, h->d_status);
+    hipLaunchKernelGGL(k_lm_observations, dim3((R + 255) / 256), dim3(256), 0, st, K, R, h->d_W, h->d_cam, h->d_lm, h->d_scale, h->d_active, h->d_Vinv,
+                       h->d_Ws, h->d_Y);
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
