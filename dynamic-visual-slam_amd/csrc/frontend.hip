@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_filter_matches(const int* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_backproject(const dvs_keypoint* __restrict__ kps, int n, const uint16_t* __restrict__ depth,
-                                                     uint64_t dstep, float fx, float fy, float cx, float cy, const double* __restrict__ Rt,
+                                                     int rows, int cols, uint64_t dstep, float fx, float fy, float cx, float cy, const double* __restrict__ Rt,
                                                      double* __restrict__ world, int* __restrict__ oindex, int* __restrict__ nOut) {
   __shared__ int wsum[5];
   const int tid = threadIdx.x;
@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void k_backproject(const dvs_keypoint* __restr
     if (i < n) {
       const float px = kps[i].x, py = kps[i].y;
       const int x = round_half_away(px), y = round_half_away(py);
-      Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+      // a keypoint outside the depth image is undefined behaviour in the reference (cv::Mat::at, frontend.cpp:738); here it reads as
+      // depth 0 and is dropped instead of faulting the GPU
+      const bool inb = x >= 0 && y >= 0 && x < cols && y < rows;
+      Z = inb ? __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f) : 0.f;
       X = __fdiv_rn(__fmul_rn(__fsub_rn(px, cx), Z), fx);
       Y = __fdiv_rn(__fmul_rn(__fsub_rn(py, cy), Z), fy);
       keep = (double)Z > 0.3 && (double)Z < 3.0;
@@ -215,7 +218,8 @@ __device__ __forceinline__ void put_u64(uint8_t* p, unsigned long long v) {  // 
 __device__ __forceinline__ void put_f64(uint8_t* p, double v) { put_u64(p, (unsigned long long)__double_as_longlong(v)); }
 
 __global__ __launch_bounds__(256) void k_publish_keyframe(KfHead H, const dvs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                          int n, const uint16_t* __restrict__ depth, uint64_t dstep, float fx, float fy,
+                                                          int n, const uint16_t* __restrict__ depth, int rows, int cols, uint64_t dstep,
+                                                          float fx, float fy,
                                                           float cx, float cy, const double* __restrict__ Rt, uint8_t* __restrict__ out,
                                                           unsigned long long cap, unsigned long long* __restrict__ outSize,
                                                           int* __restrict__ nOut) {
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(256) void k_publish_keyframe(KfHead H, const dvs_ke
   int cnt = 0;
   for (int i = tid; i < n; i += 256) {
     const int x = round_half_away(kps[i].x), y = round_half_away(kps[i].y);
-    const float Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+    const bool inb = x >= 0 && y >= 0 && x < cols && y < rows;  // outside the depth image: dropped (undefined in the reference)
+    const float Z = inb ? __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f) : 0.f;
     cnt += ((double)Z > 0.3 && (double)Z < 3.0) ? 1 : 0;
   }
   int tot;
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(256) void k_publish_keyframe(KfHead H, const dvs_ke
     if (i < n) {
       px = kps[i].x; py = kps[i].y;
       const int x = round_half_away(px), y = round_half_away(py);
-      Z = __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+      const bool inb = x >= 0 && y >= 0 && x < cols && y < rows;
+      Z = inb ? __fmul_rn((float)*(const uint16_t*)((const uint8_t*)depth + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f) : 0.f;
       X = __fdiv_rn(__fmul_rn(__fsub_rn(px, cx), Z), fx);
       Y = __fdiv_rn(__fmul_rn(__fsub_rn(py, cy), Z), fy);
       keep = (double)Z > 0.3 && (double)Z < 3.0;
@@ -460,7 +466,7 @@ dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n,
   DVS_HIP(hipMemcpyAsync(d_k, kps, (size_t)n * sizeof(dvs_keypoint), hipMemcpyHostToDevice, st));
   DVS_HIP(hipMemcpyAsync(d_Rt, Rt, 96, hipMemcpyHostToDevice, st));
   DVS_HIP(hipMemcpy2DAsync(d_dep, (size_t)cols * 2, depth, step_bytes, (size_t)cols * 2, rows, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_backproject, dim3(1), dim3(256), 0, st, d_k, n, d_dep, (uint64_t)cols * 2, fx, fy, cx, cy, d_Rt, d_w, d_oi, d_no);
+  hipLaunchKernelGGL(k_backproject, dim3(1), dim3(256), 0, st, d_k, n, d_dep, rows, cols, (uint64_t)cols * 2, fx, fy, cx, cy, d_Rt, d_w, d_oi, d_no);
   DVS_HIP(hipGetLastError());
   int m = 0;
   DVS_HIP(hipMemcpyAsync(&m, d_no, 4, hipMemcpyDeviceToHost, st));
@@ -545,7 +551,7 @@ dvs_status dvs_publish_keyframe_device(dvs_matcher* ctx, const dvs_keyframe_head
   double Rt[12];
   memcpy(Rt, R, 72); memcpy(Rt + 9, t, 24);
   DVS_HIP(hipMemcpyAsync(d_Rt, Rt, 96, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_publish_keyframe, dim3(1), dim3(256), 0, st, H, d_kps, d_desc, n, d_depth, (uint64_t)step_bytes, fx, fy, cx, cy, d_Rt,
+  hipLaunchKernelGGL(k_publish_keyframe, dim3(1), dim3(256), 0, st, H, d_kps, d_desc, n, d_depth, rows, cols, (uint64_t)step_bytes, fx, fy, cx, cy, d_Rt,
                      d_out, (unsigned long long)cap, (unsigned long long*)d_out_size, d_n_out);
   DVS_HIP(hipGetLastError());
   return DVS_OK;

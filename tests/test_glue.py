@@ -231,3 +231,23 @@ def test_harris_parity(gpu, oracle):
     assert (g.harris_responses(frame, xs, ys) != 0).sum() > 2500
     view = frame[:, :333]                                                      # rows wider than the image (step != cols)
     assert np.array_equal(g.harris_responses(view, xs // 2, ys), oracle.harris_responses(np.ascontiguousarray(view), xs // 2, ys))
+
+
+@pytest.mark.gpu
+def test_out_of_image_keypoints_are_dropped_not_faulted(gpu, oracle):
+    """keypoints whose rounded position lies outside the depth image are undefined behaviour in the reference (cv::Mat::at);
+    the GPU entry points drop them instead of reading out of bounds"""
+    from dvslam_amd import FrontendGlue
+    from dvslam_amd.glue import unpack_keyframe
+    kps, desc, depth = _scene(11, 64)
+    depth[:] = 1500
+    kps["x"][:4] = [-5.0, 100000.0, 10.0, 639.6]; kps["y"][:4] = [10.0, 10.0, -0.6, 479.6]
+    g = FrontendGlue()
+    R = np.eye(3); t = np.zeros(3)
+    from dvslam_amd import DvsError
+    with pytest.raises(DvsError):                       # the host entry point checks its keypoints up front
+        g.backproject(kps, depth, 600.0, 600.0, 320.0, 240.0, R, t)
+    w, oi = g.backproject(kps[4:], depth, 600.0, 600.0, 320.0, 240.0, R, t)
+    assert len(oi) == 60
+    payload, m = g.publish_keyframe(kps, desc, depth, 600.0, 600.0, 320.0, 240.0, R, t)
+    assert m == 60 and list(unpack_keyframe(payload)["landmark_ids"][:2]) == [4, 5]
