@@ -30,10 +30,12 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   __shared__ int sd[kSplit][64 * kQPL];
   __shared__ int si[kSplit][64 * kQPL];
   const int pair = blockIdx.y;
-  const int nq = nqArr ? nqArr[pair] : nqConst;
+  const int nq = nqArr ? min(nqArr[pair], qStrideRows) : nqConst;
   // job 0's train set may live elsewhere (frame sequences: the previous batch's last frame), t0 / nt0 then replace t / ntArr
   const bool first = pair == 0 && t0 != nullptr;
-  const int nt = first ? *nt0 : (ntArr ? ntArr[pair] : ntConst);
+  // counts read from device memory are clamped to the row strides the caller declared (a corrupt count must not walk out of the
+  // buffers); the predecessor block of a sequence has no declared size and is trusted
+  const int nt = first ? *nt0 : (ntArr ? min(ntArr[pair], tStrideRows > 0 ? tStrideRows : ntArr[pair]) : ntConst);
   const int q0 = blockIdx.x * 64 * kQPL;
   if (q0 >= nq) return;
   const int lane = threadIdx.x & 63;
