@@ -1,11 +1,15 @@
 // orb_kernels.h — gfx950 kernels of the ORB extractor (included by orb.hip only).
 //
-// Launch sequence per batch of F frames (grid.z / grid.y = frame):
-//   k_resize        x (nlevels-1)  pyramid, level l from level l-1            ORBextractor.cpp:1169-1194
-//   k_fast_cell     1              FAST-9/16 score + per-cell NMS + fallback  ORBextractor.cpp:805-872
-//   k_octree        1              candidate gather + quad-tree distribution  ORBextractor.cpp:555-779, 874-890
-//   k_blur          1              7x7 fixed-point Gaussian of every level    ORBextractor.cpp:1132-1133
-//   k_describe      1              IC orientation + steered BRIEF + output    ORBextractor.cpp:76-146, 1142-1163
+// Kernels per batch of F frames (grid.z / grid.y = frame); orb.hip (enqueue_extract) holds the schedule:
+//   k_resize4 / k_resize  x (nlevels-1)  pyramid, level l from level l-1 (k_pyr_cascade: all levels in one launch, <= 4 frames)
+//                                                                                   ORBextractor.cpp:1169-1194
+//   k_fast_wave<P> / k_fast_cell         FAST-9/16 score + per-cell NMS + threshold fallback, wavefront (workgroup) per cell
+//                                                                                   ORBextractor.cpp:805-872
+//   k_octree                             candidate gather + quad-tree distribution, workgroup per (frame, level)
+//                                                                                   ORBextractor.cpp:555-779, 874-890
+//   k_blur_stream / k_blur               7x7 fixed-point Gaussian of every level    ORBextractor.cpp:1132-1133
+//   k_describe<0> | <1> + <2>            IC orientation + steered BRIEF + output    ORBextractor.cpp:76-146, 1142-1163
+// The second name of a pair is the generic variant for inputs the fast one does not take (rows not dword aligned).
 //
 // Everything is integer or explicitly-rounded float32/float64 arithmetic; the file is compiled with
 // -ffp-contract=off so no mul/add pair is fused behind our back.
