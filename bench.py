@@ -149,8 +149,8 @@ def ba_bench(dvslam_amd, synth, device, iters=200, W=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--pipelines", type=int, default=1, help="double-buffered batches in flight per GPU")
