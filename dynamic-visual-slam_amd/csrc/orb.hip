@@ -458,8 +458,8 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // SLOWER than the per-level chain running beside FAST (0.29 vs 0.20 ms per 64 frames: the resize arithmetic is VALU-issue
   // bound, so removing the launches and the re-reads buys nothing).  Kept selectable for HBM-traffic experiments.
   // few frames (the live one-frame-per-callback pattern): the launch chain, not the arithmetic, sets the latency -> all levels in
-  // one launch (0.31 -> 0.25 ms per 1280x720 frame); batches keep the per-level chain that runs beside FAST
-  const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 4;
+  // one launch (0.31 -> 0.25 ms per 1280x720 frame); larger batches keep the per-level chain that runs beside FAST
+  const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 8;  // measured: +26 % at 2, +12 % at 8, -2 % at 16 frames
   const bool cascade = !prefetched && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
   const bool ov = !prefetched && !cascade && h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
@@ -538,7 +538,9 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   // 3. quad-tree
   h->timer.begin(DVS_STAGE_OCTREE, st);
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(nimg <= 4 ? kOctTMax : kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
+  // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(G.nlevels * nimg <= 256 ? kOctTMax : kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
