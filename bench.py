@@ -4,8 +4,11 @@ configs[1]) on N MI355X, with the roofline of the dominant kernel and the CPU or
 
 A step = one pass of the hot path over one batch of B synthetic frames already resident in HBM:
 pyramid -> FAST cells -> quad-tree -> blur -> orientation + rBRIEF for B frames, then B brute-force
-match jobs (frame t vs t-1).  N > 1: one process per GPU (torchrun), frames sharded contiguously over
-ranks, one RCCL all_gather of the boundary descriptor block per step (dvslam_amd/dist.py).
+match jobs (frame t vs t-1).  The input streams: the steps rotate over several resident batches of distinct
+frames (more level-0 + pyramid bytes than the 256 MB Infinity Cache holds), and each step announces its real successor.
+N > 1: one process per GPU, frames sharded contiguously over ranks, one RCCL all-gather of the boundary
+descriptor block per step through the C-ABI (dvs_exchange_boundary).  `python bench.py --gpus N` without a
+launcher starts its own N ranks (python -m torch.distributed.run) as a child process before anything touches the GPU.
 Prints ONE JSON line on rank 0."""
 import argparse
 import json
@@ -49,8 +52,9 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frames 1280x720 extract(2000kp)+match vs previous frame, oracle/ C++ -O2, 1 thread"}
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port", "flags": ob.FLAGS, "cpu": ob.cpu_model(),
+            "sample": f"{done} frames 1280x720 extract(2000kp)+match vs previous frame, oracle/ (scalar C++ restatement of the "
+                      "reference path: NOT OpenCV's SIMD kernels), 1 thread"}
 
 
 def cpu_baseline_all_cores(frames, nfeatures, threads, budget_s=8.0):
@@ -81,8 +85,8 @@ def cpu_baseline_all_cores(frames, nfeatures, threads, budget_s=8.0):
     for t in ts:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": sum(counts) / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{sum(counts)} frames 1280x720 extract(2000kp)+match, oracle/ C++ -O2, {threads} threads (one extractor each)"}
+    return {"value": sum(counts) / dt, "unit": "frames/s", "cores": threads, "kind": "port", "flags": ob.FLAGS, "cpu": ob.cpu_model(),
+            "sample": f"{sum(counts)} frames 1280x720 extract(2000kp)+match, oracle/ (scalar C++ restatement), {threads} threads (one extractor each)"}
 
 
 def _replicate_ba(P, W):
@@ -121,7 +125,12 @@ def ba_bench(dvslam_amd, synth, device, iters=200, W=64):
            "residual_blocks_per_s": round(W * R / dtW, 1), "us_per_eval_batched": round(1e6 * dtW / W, 3),
            "single_window_evals_per_s": round(1 / dt1, 1), "single_window_us_per_eval": round(1e6 * dt1, 2), "residual_blocks": R,
            "dtype": "f64", "algorithmic_bytes_per_eval": bytes_eval, "achieved_GBps": round(bytes_eval * W / dtW / 1e9, 2),
-           "roofline_frac_hbm": round(bytes_eval * W / dtW / HBM_PEAK, 5)}
+           "roofline_frac_hbm": round(bytes_eval * W / dtW / HBM_PEAK, 5),
+           # the BASELINE config as stated is ONE window: launch-latency bound; the batched figure is W independent windows
+           "roofline": {"single_window": {"bound": "hbm", "achieved": round(bytes_eval / dt1 / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                          "frac": round(bytes_eval / dt1 / HBM_PEAK, 5), "us_per_eval": round(1e6 * dt1, 2)},
+                        "batched": {"bound": "hbm", "achieved": round(bytes_eval * W / dtW / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                    "frac": round(bytes_eval * W / dtW / HBM_PEAK, 5), "windows_per_launch": W}}}
     t0 = time.perf_counter(); s = g.solve(20); t_host_schur = time.perf_counter() - t0
     gd = dvslam_amd.BAProblem(P, device=device)
     gd.solve_device(1)                       # workspace allocation outside the timing
@@ -138,12 +147,59 @@ def ba_bench(dvslam_amd, synth, device, iters=200, W=64):
     while time.perf_counter() - t0 < 3.0:
         o.evaluate(); n += 1
     cpu_rate = n / (time.perf_counter() - t0)
+    o.evaluate_mt(4, 2)
+    t0 = time.perf_counter(); n4 = 0
+    while time.perf_counter() - t0 < 3.0:
+        o.evaluate_mt(4, 8); n4 += 8
+    cpu_rate4 = n4 / (time.perf_counter() - t0)
     o = ob.OracleBA(P)
     t1 = time.perf_counter(); so = o.solve(20); out["lm_solve"]["ms_cpu_oracle"] = round(1e3 * (time.perf_counter() - t1), 3)
     out["lm_solve"]["cpu_oracle_final_cost"] = so.final_cost
-    out["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "evals/s", "cores": 1, "kind": "port",
+    out["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "evals/s", "cores": 1, "kind": "port", "flags": ob.FLAGS, "cpu": ob.cpu_model(),
                            "sample": f"{n} evaluations of the same window with the oracle (Jet<double,10> autodiff as Ceres does), 1 thread"}
+    out["cpu_baseline_4_threads"] = {"value": round(cpu_rate4, 2), "unit": "evals/s", "cores": 4, "kind": "port", "flags": ob.FLAGS,
+                                     "sample": f"{n4} evaluations, residual blocks split over 4 threads as ceres::Solver::Options::num_threads = 4 "
+                                               "(bundle_adjustment.hpp:842) does"}
     return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU) as a CHILD process —
+    nothing in this process has touched the GPU or imported torch — forward its output and exit with its code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def make_batches(synth, torch, dev, B, NB, rank, rows, cols, distinct):
+    """NB resident batches of B frames.  distinct: every frame of every batch is its own image (batch b = 64 consecutive frames of
+    the synthetic sequence over a scene of its own, seed per (rank, batch)); otherwise round 1's start-up-saving mode (16 frames
+    tiled over ONE batch).  Returns the device tensor [NB, B, rows, cols] and the number of distinct frames."""
+    if not distinct:
+        uniq = min(B, 16)
+        host = [synth.make_frame((rank * B + i) % 64, cols, rows) for i in range(uniq)]
+        d = torch.empty((1, B, rows, cols), dtype=torch.uint8, device=dev)
+        for i in range(B):
+            d[0, i].copy_(torch.from_numpy(host[i % uniq]))
+        return d, uniq
+    d = torch.empty((NB, B, rows, cols), dtype=torch.uint8, device=dev)
+    for b in range(NB):
+        seed = 1234 + 101 * b + 7 * rank
+        for i in range(B):
+            d[b, i].copy_(torch.from_numpy(synth.make_frame(i, cols, rows, seed=seed)))
+        synth._CANVAS_CACHE.clear()
+    return d, NB * B
 
 
 def main():
@@ -154,11 +210,27 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--pipelines", type=int, default=1, help="double-buffered batches in flight per GPU")
+    ap.add_argument("--resident-batches", type=int, default=6,
+                    help="distinct resident input batches the steps rotate over (6 x 64 x 0.92 MB of level 0 + 6 x 180 MB of pyramids and "
+                         "blurred levels per pass: far beyond the 256 MB Infinity Cache)")
+    ap.add_argument("--single-resident-batch", action="store_true", help="round 1's mode: 16 distinct frames tiled over one resident batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build every batch's pyramid inside its own step (default: the next batch's pyramid overlaps this batch's "
-                         "descriptor stage and match, dvs_orb_hint_next_batch_device)")
+                         "FAST, dvs_orb_hint_next_batch_device)")
+    ap.add_argument("--torch-exchange", action="store_true", help="exchange through torch.distributed (dist.py) instead of the C-ABI")
+    ap.add_argument("--dry-launch", action="store_true", help="only start the ranks and report them (no GPU work): launcher self-test")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local, "pid": os.getpid()}), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -166,21 +238,13 @@ def main():
     from dvslam_amd import synth
     from dvslam_amd import dist as dvdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rows, cols, B = 720, 1280, args.batch
-    # synthetic sequence: this rank's shard of one global batch (distinct frames per rank)
-    frames_idx = list(dvdist.shard_range(world, rank, B))
-    uniq = min(B, 16)   # 16 distinct frames tiled over the batch keep start-up short; every frame is processed in full
-    host = [synth.make_frame(frames_idx[i % uniq] % 64, cols, rows) for i in range(uniq)]
-    d_img = torch.empty((B, rows, cols), dtype=torch.uint8, device=dev)
-    for i in range(B):
-        d_img[i].copy_(torch.from_numpy(host[i % uniq]))
+    NB = 1 if args.single_resident_batch else max(1, args.resident_batches)
+    # synthetic input, resident in HBM before the timed region: this rank's shard of NB global batches
+    d_img, frames_distinct = make_batches(synth, torch, dev, B, NB, rank, rows, cols, not args.single_resident_batch)
 
     # Two pipelines (extractor + matcher handle, HBM buffers, torch stream each) take alternate steps, so consecutive
     # batches overlap on the GPU exactly like a double-buffered camera stream would; every step still processes one
@@ -213,20 +277,35 @@ def main():
     torch.cuda.synchronize()
     # RCCL comes up AFTER the pipeline's handles and streams exist (see the stream comment above)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torchrun (also with one rank): exercise RCCL
+    comm = None
+    rccl = None
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
+        if not args.torch_exchange:
+            def bcast_id(ident):   # the out-of-band hand-over of the RCCL unique id: torch.distributed's store
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = dvdist.Comm(local, rank, world, bcast_id)
+            rccl = {"nranks": world, "version": comm.rccl_version, "exchange": "dvs_exchange_boundary: ncclAllGather behind the C-ABI"}
+            print(f"[bench] rank {rank}: RCCL communicator of {world} ranks (version {comm.rccl_version})", file=sys.stderr, flush=True)
+        else:
+            rccl = {"nranks": world, "exchange": "torch.distributed all_gather_into_tensor (dvslam_amd/dist.py)"}
 
     cap = pipes[0]["orb"].capacity
     torch.cuda.synchronize()
     state = {"i": 0}
-    collective = world > 1 or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
+    collective = world > 1 or launched or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
+    if collective and comm is None and not dist.is_initialized():
+        collective = False
 
     def step():
         i = state["i"]; state["i"] += 1
         P = pipes[i % NP]; Q = pipes[(i - 1) % NP]
         s = P["count"] % 2; P["count"] += 1
+        img = d_img[i % NB]; nxt = d_img[(i + 1) % NB]
         prev_desc = prev_n = 0
         if i > 0:
             qd, qn = Q["last"]           # last frame of the previous step (this rank's)
@@ -235,11 +314,15 @@ def main():
                 # the previous step, so it runs on a side stream beside this step's extraction and is joined before the match
                 X = P["xstream"]
                 X.wait_event(Q["done"])
-                with torch.cuda.stream(X):
-                    bd, bn = dvdist.exchange_boundary(qd, qn, cap)
+                if comm is not None:
+                    prev_desc, prev_n = comm.exchange_boundary(X.cuda_stream, qd.data_ptr(), qn.data_ptr(), cap)
                     P["xdone"].record(X)
-                P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
-                prev_desc, prev_n = bd.data_ptr(), bn.data_ptr()
+                else:
+                    with torch.cuda.stream(X):
+                        bd, bn = dvdist.exchange_boundary(qd, qn, cap)
+                        P["xdone"].record(X)
+                    P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
+                    prev_desc, prev_n = bd.data_ptr(), bn.data_ptr()
             else:
                 if NP > 1:
                     P["stream"].wait_event(Q["done"])
@@ -248,8 +331,8 @@ def main():
             if args.prefetch and NP == 1:
                 # streaming: the next batch is already resident, so its pyramid is built beside this batch's FAST
                 # (every step still builds exactly one pyramid; the one of step 0 is built in-step)
-                P["orb"].hint_next_batch_device(d_img.data_ptr())
-            P["orb"].extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
+                P["orb"].hint_next_batch_device(nxt.data_ptr())
+            P["orb"].extract_batch_device(img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
                                           P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
             if i > 0 and collective:
                 P["stream"].wait_event(P["xdone"])
@@ -269,7 +352,7 @@ def main():
         step()
     sync_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -278,7 +361,7 @@ def main():
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no synchronisation inside)
     sync_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -290,10 +373,10 @@ def main():
     #     kernel takes WHILE its neighbours share the machine (rocprofv3's kernel statistics of this command show these)
     orb.enable_stage_timing(True)
     with torch.cuda.stream(P["stream"]):
-        for _ in range(args.steps):
+        for k in range(args.steps):
             if args.prefetch and NP == 1:
-                orb.hint_next_batch_device(d_img.data_ptr())
-            orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
+                orb.hint_next_batch_device(d_img[(k + 1) % NB].data_ptr())
+            orb.extract_batch_device(d_img[k % NB].data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
                                      P["desc"][P["cur"]].data_ptr(), cap, P["n"][P["cur"]].data_ptr())
     sync_all()
     ov_ms, ov_calls = orb.stage_times()
@@ -302,8 +385,8 @@ def main():
     orb.set_overlap(False)
     orb.enable_stage_timing(True)
     with torch.cuda.stream(P["stream"]):
-        for _ in range(args.steps):
-            orb.extract_batch_device(d_img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
+        for k in range(args.steps):
+            orb.extract_batch_device(d_img[k % NB].data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
                                      P["desc"][P["cur"]].data_ptr(), cap, P["n"][P["cur"]].data_ptr())
     sync_all()
     stage_ms, stage_calls = orb.stage_times()
@@ -316,23 +399,25 @@ def main():
     d_n = pipes[0]["n"][pipes[0]["cur"]]; d_dist = pipes[0]["dist"]
 
     n_host = d_n.cpu().numpy()
-    matched = int((d_dist[:, :].cpu().numpy()[0, :n_host[0]] < 50).sum())
+    matched = int((d_dist[:, :].cpu().numpy()[1, :n_host[1]] < 50).sum()) if B > 1 else 0
 
     if rank == 0:
         total_frames = world * B * args.steps
         fps = total_frames / elapsed
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch
-        issue = None     # the bound that actually holds: wave-level VALU instructions per second against the measured issue peak
+        issue = None     # wave-level VALU instructions per second of the dominant kernel against the chip's issue rates
         dom_ms = stage_ms[dom] / max(stage_calls[dom], 1)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             traffic = int(tj["bytes_per_launch"][dom] * B / tj["batch"])
             insts = tj["valu_insts_per_launch"][dom] * B / tj["batch"]
             rate = insts / (dom_ms * 1e-3) / 1e9
-            issue = {"kernel": dom, "valu_wave_insts_per_launch": int(insts), "achieved": round(rate, 1), "peak": tj["valu_issue_peak_G_per_s"],
-                     "unit": "G wave-instr/s", "frac": round(rate / tj["valu_issue_peak_G_per_s"], 4),
-                     "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json; peak measured with tools/ubench/valu_rate.hip"}
+            nominal = 256 * 4 * 2.4 / 2   # 1 024 SIMD-32 x one wave64 instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+            issue = {"kernel": dom, "valu_wave_insts_per_launch": int(insts), "achieved": round(rate, 1), "peak": nominal,
+                     "unit": "G wave-instr/s", "frac": round(rate / nominal, 4),
+                     "measured_class_rates_G_per_s": {"add/xor/max_i16 class": "780-950", "perm/pk16/dot/bcnt/min3/mad24 class": tj["valu_issue_peak_G_per_s"]},
+                     "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json; class rates: tools/ubench/valu_rate.hip, profiles/r01_valu_issue_rates.txt"}
         except Exception:
             pass
         achieved = STAGE_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -341,8 +426,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame "
-                                   "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "keypoints_frame0": int(n_host[0]),
-                       "matches_lt50_frame0": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
+                                   "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "frames_distinct": frames_distinct,
+                       "resident_batches": NB, "keypoints_frame1": int(n_host[min(1, B - 1)]),
+                       "matches_lt50_frame1": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
@@ -350,9 +436,11 @@ def main():
             "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
             "stage_ms_per_launch_isolated": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
             "stage_ms_per_launch_overlapped": {k: round(v / max(ov_calls[k], 1), 4) for k, v in ov_ms.items()},
-            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4), "pipelines_per_gpu": NP,
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4), "pipelines_per_gpu": NP, "rccl": rccl,
         }
         if world == 1 and not args.no_cpu_baseline:
+            import oracle_bindings as ob
+            ob.use_native()   # -O2 -march=native, built here on the host that times it
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]
             out["cpu_baseline"] = cpu_baseline(cb_frames, args.nfeatures)
             out["speedup_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1)
@@ -360,7 +448,10 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cb_frames, args.nfeatures, nthr)
             out["speedup_vs_cpu_all_cores"] = round(fps / out["cpu_baseline_all_cores"]["value"], 1)
             out["ba"] = ba_bench(dvslam_amd, synth, local)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
                                                    const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
                                                    const int* __restrict__ lmObs, const double* __restrict__ res,
                                                    const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
-                                                   int withLm, double* __restrict__ Hpp, double* __restrict__ Hll,
+                                                   int withLm, int costOnly, double* __restrict__ Hpp, double* __restrict__ Hll,
                                                    double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
                                                    int* __restrict__ ticketCounter) {
   const int tid = threadIdx.x;
@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
   // camera fold: 8 cameras per workgroup, thread (c, k) sums the camera's chunk partials in chunk order (k = 27: cost)
   const int cb = (int)blockIdx.x - lmBlocks;
   const int c = cb * 8 + (tid >> 5), k = tid & 31;
-  if (c < K && k < 28) {
+  // costOnly (a trust-region candidate's cost, flags == 0): fold only the cost column — H_pp and g keep the ACCEPTED point's
+  // values, which the next trial step needs again if this candidate is rejected
+  if (c < K && k < 28 && (!costOnly || k == 27)) {
     double sacc = 0;
     for (int ch = camChunkStart[c]; ch < camChunkStart[c + 1]; ch++) sacc += partial[(size_t)ch * 28 + k];
     if (k < 21) {
@@ -699,6 +701,11 @@ struct dvs_ba {
   unsigned char* d_active = nullptr;
   dvs::LmStatus* d_status = nullptr;
   dvs::LmStatus* h_status = nullptr;  // pinned
+  std::vector<double> trace;          // dvs_ba_get_trace: 6 doubles per trust-region iteration of the last solve
+  void log(double radius, int kind, double dc, double dm, double rel, double cand) {
+    const double row[6] = {radius, (double)kind, dc, dm, rel, cand};
+    trace.insert(trace.end(), row, row + 6);
+  }
 };
 
 namespace {
@@ -743,7 +750,7 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
                      raw ? raw + 16 * (size_t)h->R : nullptr);
   hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + (h->K + 7) / 8), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
                      h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_res, h->d_Jl, h->d_partial, h->lmBlocks, withLm ? 1 : 0,
-                     h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_costCam, h->d_ticket);
+                     flags == 0 ? 1 : 0, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_costCam, h->d_ticket);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
@@ -825,6 +832,7 @@ void dvs_ba_destroy(dvs_ba* h) {
 
 dvs_status dvs_ba_set_stream(dvs_ba* h, void* s) {
   DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   h->stream = (hipStream_t)s;
   return DVS_OK;
@@ -973,6 +981,14 @@ dvs_status dvs_ba_evaluate_device(dvs_ba* h, int32_t iters) {
   return DVS_OK;
 }
 
+dvs_status dvs_ba_get_trace(const dvs_ba* h, double* rows, int32_t cap_rows, int32_t* n_rows) {
+  DVS_ARG(h && n_rows && cap_rows >= 0);
+  const int n = (int)(h->trace.size() / 6);
+  *n_rows = n;
+  if (rows) memcpy(rows, h->trace.data(), (size_t)std::min(n, cap_rows) * 6 * sizeof(double));
+  return DVS_OK;
+}
+
 dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X) {
   DVS_ARG(h);
   if (q_wxyz) memcpy(q_wxyz, h->q.data(), h->q.size() * 8);
@@ -1004,6 +1020,7 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double g
     DVS_HIP(hipStreamSynchronize(h->stream));
     return DVS_OK;
   };
+  h->trace.clear();
   std::vector<double> q = h->q, t = h->t, X = h->X;
   DVS_TRY(upload_params(h, q, t, X));
   DVS_TRY(evaluate_full());
@@ -1128,6 +1145,7 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double g
       }
     }
     if (!valid) {
+      h->log(radius, 0, 0, model_cost_change, 0, 0);
       if (++invalid >= 5) { summary->termination = 2; break; }
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;
       continue;
@@ -1148,10 +1166,11 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double g
     double sn = 0;
     for (int c = 0; c < K; c++) if (camSlot[c] >= 0) { for (int i = 0; i < 4; i++) sn += (q[4 * c + i] - cq[4 * c + i]) * (q[4 * c + i] - cq[4 * c + i]); for (int i = 0; i < 3; i++) sn += (t[3 * c + i] - ct[3 * c + i]) * (t[3 * c + i] - ct[3 * c + i]); }
     for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) sn += (X[3 * l + i] - cX[3 * l + i]) * (X[3 * l + i] - cX[3 * l + i]);
-    if (sqrt(sn) <= ptol * (x_norm() + ptol)) { summary->termination = 0; break; }
+    if (sqrt(sn) <= ptol * (x_norm() + ptol)) { h->log(radius, 3, x_cost - cand_cost, model_cost_change, 0, cand_cost); summary->termination = 0; break; }
     const double cost_change = x_cost - cand_cost;
-    if (fabs(cost_change) <= ftol * x_cost) { summary->termination = 0; break; }
+    if (fabs(cost_change) <= ftol * x_cost) { h->log(radius, 4, cost_change, model_cost_change, 0, cand_cost); summary->termination = 0; break; }
     const double rel = cost_change / model_cost_change;
+    h->log(radius, rel > 1e-3 ? 1 : 2, cost_change, model_cost_change, rel, cand_cost);
     if (rel > 1e-3) {
       q = cq; t = ct; X = cX;
       DVS_TRY(evaluate_full());  // parameters on the device already are the candidate
@@ -1201,6 +1220,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
       if (slot >= 0) { set_error("landmark %d is observed twice in camera %d: use dvs_ba_solve", l, h->cam[p]); return DVS_ERR_UNSUPPORTED; }
       slot = p;
     }
+  h->trace.clear();
   hipStream_t st = h->stream;
   if (!h->d_status) {
     const size_t Rz = std::max(R, 1);
@@ -1272,15 +1292,17 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_TRY(fetch_status());
     const bool valid = S->ok && S->finite && S->model_change > 0.0;
     if (!valid) {
+      h->log(radius, 0, 0, S->model_change, 0, 0);
       if (++invalid >= 5) { summary->termination = 2; break; }
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;
       continue;
     }
     invalid = 0;
-    if (sqrt(S->sn) <= ptol * (sqrt(S->xn) + ptol)) { summary->termination = 0; break; }
+    if (sqrt(S->sn) <= ptol * (sqrt(S->xn) + ptol)) { h->log(radius, 3, x_cost - S->cand_cost, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
     const double cost_change = x_cost - S->cand_cost;
-    if (fabs(cost_change) <= ftol * x_cost) { summary->termination = 0; break; }
+    if (fabs(cost_change) <= ftol * x_cost) { h->log(radius, 4, cost_change, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
     const double rel = cost_change / S->model_change;
+    h->log(radius, rel > 1e-3 ? 1 : 2, cost_change, S->model_change, rel, S->cand_cost);
     if (rel > 1e-3) {
       DVS_HIP(hipMemcpyAsync(h->d_q0, h->d_q, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
       DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));

@@ -1,0 +1,168 @@
+// comm.hip — the multi-GPU exchange step of the frontend path behind the C-ABI.
+// The reference is one process per node with no collective (its only "communication" is the DDS topic
+// /frontend/keyframe, frontend.cpp:200,783); sharding frames (or pyramid levels) over the GPUs of a node adds
+// exactly ONE exchange: an all-gather of fixed-size per-rank blocks over RCCL/xGMI.  A C++ host reaches it here;
+// dvslam_amd/dist.py is the gloo test double of the same block layout.
+//
+// RCCL is resolved with dlopen at first use: single-GPU callers never need librccl, and a process that already
+// carries an RCCL (PyTorch bundles one under the same SONAME librccl.so.1) shares that copy instead of loading a second.
+#include <dlfcn.h>
+#include <string.h>
+#include <new>
+#include "common.h"
+
+using namespace dvs;
+
+namespace {
+
+// the handful of RCCL entry points used (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllGather, ncclCommDestroy, ...)
+struct NcclUniqueId { char internal[DVS_COMM_ID_BYTES]; };
+typedef struct ncclComm* NcclComm;
+enum { kNcclSuccess = 0, kNcclUint8 = 1 };  // ncclResult_t::ncclSuccess, ncclDataType_t::ncclUint8 (= ncclChar + 1)
+struct Rccl {
+  void* so = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+dvs_status load_rccl() {
+  if (g_rccl.so) return DVS_OK;
+  const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  void* so = nullptr;
+  for (const char* n : names)
+    if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!so) { set_error("librccl.so.1 not found (%s): the multi-GPU exchange needs RCCL", dlerror()); return DVS_ERR_UNSUPPORTED; }
+  Rccl r;
+  r.so = so;
+  r.GetVersion = (int (*)(int*))dlsym(so, "ncclGetVersion");
+  r.GetUniqueId = (int (*)(NcclUniqueId*))dlsym(so, "ncclGetUniqueId");
+  r.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))dlsym(so, "ncclCommInitRank");
+  r.CommDestroy = (int (*)(NcclComm))dlsym(so, "ncclCommDestroy");
+  r.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(so, "ncclAllGather");
+  r.GetErrorString = (const char* (*)(int))dlsym(so, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+    set_error("librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    return DVS_ERR_UNSUPPORTED;
+  }
+  g_rccl = r;
+  return DVS_OK;
+}
+
+#define DVS_NCCL(call)                                                                                                   \
+  do {                                                                                                                   \
+    int r_ = (call);                                                                                                     \
+    if (r_ != kNcclSuccess) {                                                                                            \
+      set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+      return DVS_ERR_HIP;                                                                                                \
+    }                                                                                                                    \
+  } while (0)
+
+// this rank's boundary block {descriptors[cap x 32], n, padding}: 16-byte copies of the descriptor rows of the last frame
+__global__ void __launch_bounds__(256) k_pack_boundary(const uint4* __restrict__ desc, const int* __restrict__ n, uint4* __restrict__ block,
+                                                       int rows16, int blk16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows16) block[i] = desc[i];
+  else if (i < blk16) block[i] = i == rows16 ? make_uint4((uint32_t)n[0], 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+}
+
+}  // namespace
+
+struct dvs_comm {
+  int device = 0, rank = 0, world = 1;
+  NcclComm comm = nullptr;
+  uint8_t* gather[2] = {nullptr, nullptr};  // [world][block] twice: step i's match may still read one while step i+1 gathers
+  size_t block = 0;
+  int turn = 0;
+};
+
+extern "C" {
+
+size_t dvs_boundary_block_bytes(int32_t cap) { return cap < 0 ? 0 : ((size_t)cap * 32 + 4 + 63) / 64 * 64; }
+
+dvs_status dvs_comm_get_unique_id(uint8_t* id) {
+  DVS_ARG(id);
+  DVS_TRY(load_rccl());
+  NcclUniqueId u;
+  DVS_NCCL(g_rccl.GetUniqueId(&u));
+  memcpy(id, u.internal, DVS_COMM_ID_BYTES);
+  return DVS_OK;
+}
+
+dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t* id, dvs_comm** out) {
+  DVS_ARG(out && id && world >= 1 && rank >= 0 && rank < world);
+  *out = nullptr;
+  DVS_TRY(check_device(device));
+  DVS_TRY(load_rccl());
+  dvs_comm* c = new (std::nothrow) dvs_comm();
+  if (!c) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  c->device = device; c->rank = rank; c->world = world;
+  NcclUniqueId u;
+  memcpy(u.internal, id, DVS_COMM_ID_BYTES);
+  const int r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+  if (r != kNcclSuccess) {
+    set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    delete c;
+    return DVS_ERR_HIP;
+  }
+  *out = c;
+  return DVS_OK;
+}
+
+void dvs_comm_destroy(dvs_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  for (uint8_t* p : c->gather) if (p) (void)hipFree(p);
+  delete c;
+}
+
+int32_t dvs_comm_rank(const dvs_comm* c) { return c ? c->rank : -1; }
+int32_t dvs_comm_world(const dvs_comm* c) { return c ? c->world : 0; }
+int32_t dvs_comm_rccl_version(void) {
+  int v = 0;
+  if (load_rccl() != DVS_OK || !g_rccl.GetVersion || g_rccl.GetVersion(&v) != kNcclSuccess) return 0;
+  return v;
+}
+
+dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+  DVS_ARG(c && d_send && d_recv);
+  DVS_HIP(hipSetDevice(c->device));
+  if (bytes_per_rank == 0) return DVS_OK;
+  DVS_NCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, kNcclUint8, c->comm, (hipStream_t)stream));
+  return DVS_OK;
+}
+
+dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_desc_last, const int32_t* d_n_last, int32_t cap,
+                                 const uint8_t** d_prev_desc, const int32_t** d_prev_n) {
+  DVS_ARG(c && d_desc_last && d_n_last && cap > 0 && d_prev_desc && d_prev_n);
+  DVS_ARG(((uintptr_t)d_desc_last) % 16 == 0);
+  DVS_HIP(hipSetDevice(c->device));
+  const size_t blk = dvs_boundary_block_bytes(cap);
+  if (c->block != blk) {  // (re)allocate the two gather buffers once per capacity: nothing is allocated per step
+    DVS_HIP(hipDeviceSynchronize());
+    for (uint8_t*& p : c->gather) { if (p) DVS_HIP(hipFree(p)); p = nullptr; }
+    for (uint8_t*& p : c->gather) DVS_HIP(hipMalloc((void**)&p, blk * (size_t)c->world));
+    c->block = blk;
+  }
+  uint8_t* g = c->gather[c->turn];
+  c->turn ^= 1;
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* mine = g + (size_t)c->rank * blk;
+  const int rows16 = cap * 2, blk16 = (int)(blk / 16);
+  hipLaunchKernelGGL(k_pack_boundary, dim3((blk16 + 255) / 256), dim3(256), 0, st, (const uint4*)d_desc_last, d_n_last, (uint4*)mine, rows16, blk16);
+  DVS_HIP(hipGetLastError());
+  // in place: this rank's block already sits at its slot of the receive buffer
+  DVS_NCCL(g_rccl.AllGather(mine, g, blk, kNcclUint8, c->comm, st));
+  const int prev = (c->rank + c->world - 1) % c->world;  // the last rank's block of the previous global batch wraps to rank 0
+  *d_prev_desc = g + (size_t)prev * blk;
+  *d_prev_n = (const int32_t*)(g + (size_t)prev * blk + (size_t)cap * 32);
+  return DVS_OK;
+}
+
+}  // extern "C"

@@ -4,10 +4,11 @@
 // backend.cpp:222).  Semantics (OpenCV batchDistance, K = 1): per query the minimum popcount(q XOR t)
 // over train rows scanned in increasing index with a strict '<' update, i.e. lowest index on ties.
 //
-// Kernel shape: workgroup = 64 queries x 4 train quarters.  Each lane keeps its 256-bit query in 4
-// VGPR pairs; the train row index is wave-uniform, so the compiler fetches it with scalar loads and
-// the inner loop is 4 x (v_xor, v_bcnt) per pair.  The 4 waves scan disjoint, ordered quarters of the
-// train set and merge through LDS in quarter order (keeps the lowest-index tie-break exact).
+// Kernel shape (k_match<kSplit, kQPL>): workgroup = 64 * kQPL queries x kSplit train slices, one wavefront per slice.
+// Each lane keeps kQPL 256-bit queries in VGPRs; the train row index is wave-uniform, so train rows arrive by scalar
+// loads (software pipelined) and the inner loop is 8 x (v_xor, v_bcnt accumulate) per query and train row.  The waves
+// scan disjoint, ordered slices of the train set and merge through LDS in slice order (keeps the lowest-index
+// tie-break exact).  <8, 2> is the batch shape, <16, 1> the single-job (latency) shape.
 #include <limits.h>
 #include <string.h>
 #include <new>
@@ -266,12 +267,14 @@ void dvs_matcher_destroy(dvs_matcher* m) {
 
 dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* s) {
   DVS_ARG(m);
+  DVS_HIP(hipSetDevice(m->device));
   DVS_HIP(hipStreamSynchronize(m->stream));
   m->stream = (hipStream_t)s;  // NULL = HIP's legacy default stream
   return DVS_OK;
 }
 dvs_status dvs_matcher_use_own_stream(dvs_matcher* m) {
   DVS_ARG(m);
+  DVS_HIP(hipSetDevice(m->device));
   DVS_HIP(hipStreamSynchronize(m->stream));
   m->stream = m->own_stream;
   return DVS_OK;

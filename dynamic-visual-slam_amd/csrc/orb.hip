@@ -490,7 +490,9 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     nsrc.img0 = next_img0;
     DVS_HIP(hipEventRecord(h->ev_desc, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_desc, 0));
+    h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
     DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+    h->timer.end(h->pf_stream);
     DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
     h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
   }
@@ -662,12 +664,14 @@ int32_t dvs_orb_max_keypoints(const dvs_orb* h) { return h ? h->prm.nfeatures + 
 
 dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
   DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   h->stream = (hipStream_t)s;  // NULL is a real stream: HIP's legacy default stream
   return DVS_OK;
 }
 dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   DVS_HIP(hipStreamSynchronize(h->aux_stream));
   DVS_HIP(hipStreamSynchronize(h->pf_stream));
@@ -676,6 +680,7 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
 }
 dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
   DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   h->stream = h->own_stream;
   return DVS_OK;

@@ -82,6 +82,10 @@ dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_s
   *out_stream = (void*)s;
   return DVS_OK;
 }
+dvs_status dvs_stream_synchronize(void* stream) {
+  DVS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return DVS_OK;
+}
 dvs_status dvs_stream_destroy(void* stream) {
   if (!stream) return DVS_OK;
   DVS_HIP(hipStreamSynchronize((hipStream_t)stream));

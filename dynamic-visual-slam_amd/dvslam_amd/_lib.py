@@ -75,6 +75,7 @@ def lib():
     L.dvs_orb_extract_batch.argtypes = [vp, vp, i32, i32, i32, sz, vp, vp, i32, vp]
     L.dvs_stream_create.argtypes = [i32, i32, C.POINTER(vp)]
     L.dvs_stream_destroy.argtypes = [vp]
+    L.dvs_stream_synchronize.argtypes = [vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
@@ -90,6 +91,15 @@ def lib():
     L.dvs_match_hamming.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.dvs_match_hamming_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
     L.dvs_match_hamming_thresh.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_comm_get_unique_id.argtypes = [vp]
+    L.dvs_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    L.dvs_comm_destroy.argtypes = [vp]; L.dvs_comm_destroy.restype = None
+    L.dvs_comm_rank.argtypes = [vp]
+    L.dvs_comm_world.argtypes = [vp]
+    L.dvs_comm_rccl_version.restype = i32
+    L.dvs_boundary_block_bytes.argtypes = [i32]; L.dvs_boundary_block_bytes.restype = sz
+    L.dvs_exchange_boundary.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.dvs_comm_all_gather.argtypes = [vp, vp, vp, vp, sz]
     L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
     L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
     L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int
@@ -108,6 +118,7 @@ def lib():
         L.dvs_ba_solve.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(BaSummary)]
         L.dvs_ba_solve_device.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(BaSummary)]
         L.dvs_ba_get_parameters.argtypes = [vp, vp, vp, vp]
+        L.dvs_ba_get_trace.argtypes = [vp, vp, i32, C.POINTER(i32)]
         L.dvs_ba_pose_from_rt.argtypes = [vp, vp, vp, vp]
         L.dvs_ba_pose_to_rt.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -128,6 +139,10 @@ def stream_create(device=0, high_priority=False):
     out = C.c_void_p()
     check(lib().dvs_stream_create(device, 1 if high_priority else 0, C.byref(out)))
     return int(out.value)
+
+
+def stream_synchronize(stream):
+    check(lib().dvs_stream_synchronize(stream))
 
 
 def stream_destroy(stream):

@@ -70,6 +70,15 @@ class BAProblem:
         check(self._L.dvs_ba_solve_device(self._h, max_iterations, ftol, gtol, ptol, C.byref(s)))
         return s
 
+    def trace(self):
+        """dvs_ba_get_trace: [iterations, 6] = radius, kind (0 invalid, 1 accepted, 2 rejected, 3 ptol, 4 ftol), cost change,
+        model cost change, relative decrease, candidate cost of the last solve"""
+        n = C.c_int32()
+        check(self._L.dvs_ba_get_trace(self._h, None, 0, C.byref(n)))
+        rows = np.zeros((n.value, 6))
+        check(self._L.dvs_ba_get_trace(self._h, ptr(rows), n.value, C.byref(n)))
+        return rows
+
     def parameters(self):
         q = np.zeros((self.K, 4)); t = np.zeros((self.K, 3)); X = np.zeros((self.L, 3))
         check(self._L.dvs_ba_get_parameters(self._h, ptr(q), ptr(t), ptr(X)))
@@ -137,14 +146,3 @@ class SlidingWindowBA:
             res["optimized_landmarks"][(lid, cat[lid])] = Xo[slot].copy()
         p.close()
         return res
-
-
-def smoke_check():
-    """tiny BA evaluation on the GPU checked against the oracle (used by __graft_entry__.smoke)"""
-    import oracle_bindings as ob
-    from . import synth
-    P = synth.make_ba_problem(K=3, L=40, seed=11)
-    g = BAProblem(P); o = ob.OracleBA(P)
-    c1 = g.evaluate()[0]; c2 = o.evaluate()[0]
-    assert abs(c1 - c2) <= 1e-12 * abs(c2), (c1, c2)
-    print(f"smoke BA ok: cost {c1:.6f}")

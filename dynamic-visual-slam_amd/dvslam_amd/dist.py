@@ -1,11 +1,21 @@
 """Multi-GPU sharding of the frontend path: frames are sharded contiguously over the
 ranks (rank r owns frames [r*B, (r+1)*B) of every global batch), extraction needs no communication,
 and the ONE exchange step is the boundary descriptor block: the match job (t, t-1) with t = r*B needs
-the descriptors of frame r*B - 1, which the previous rank produced.  One all_gather of the fixed-size
-block {n, descriptors[cap x 32]} per step (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+the descriptors of frame r*B - 1, which the previous rank produced.  One all-gather of the fixed-size
+block {descriptors[cap x 32], n} per step.
+
+Two implementations of the same block layout:
+* `Comm` — the product path: dvs_comm_* / dvs_exchange_boundary of the C-ABI (RCCL ncclAllGather over xGMI on the
+  caller's HIP stream, gather buffers owned by the communicator, nothing allocated per step).  This is what a C++ host
+  calls and what bench.py runs on GPUs.
+* `BoundaryExchanger` / `exchange_boundary` — the torch.distributed test double (gloo in the CPU tests), with the block
+  and the gather buffer preallocated once."""
+import ctypes as C
 import os
 import torch
 import torch.distributed as dist
+
+ID_BYTES = 128
 
 
 def shard_range(world: int, rank: int, frames_per_rank: int):
@@ -13,15 +23,30 @@ def shard_range(world: int, rank: int, frames_per_rank: int):
     return range(rank * frames_per_rank, (rank + 1) * frames_per_rank)
 
 
+def level_shards(level_pixels, world: int):
+    """SURVEY.md §8e "Partitioning", small batches: pyramid levels -> ranks, balanced by pixel count (longest-processing-time
+    greedy: levels in decreasing size, each to the least loaded rank; ties -> lowest rank).  Returns one bit mask of levels per
+    rank; every level is owned by exactly one rank.  720p, 8 ranks: {L0} {L1} {L2} {L3} {L4} {L5} {L6} {L7}; 4 ranks:
+    {L0} {L1} {L2,L7} {L3,L4,L5,L6} by the greedy rule."""
+    load = [0] * world
+    masks = [0] * world
+    for l in sorted(range(len(level_pixels)), key=lambda i: (-level_pixels[i], i)):
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += level_pixels[l]
+        masks[r] |= 1 << l
+    return masks
+
+
 def _block_bytes(cap: int) -> int:
-    """descriptors first (so every rank's descriptor rows start 64-byte aligned inside the gathered buffer), then n, padded"""
+    """descriptors first (so every rank's descriptor rows start 64-byte aligned inside the gathered buffer), then n, padded;
+    = dvs_boundary_block_bytes(cap)"""
     return (cap * 32 + 4 + 63) // 64 * 64
 
 
-def pack_boundary(desc_last: torch.Tensor, n_last: torch.Tensor) -> torch.Tensor:
-    """desc_last: [cap, 32] uint8, n_last: int32 scalar / 1-element tensor -> one flat uint8 block"""
+def pack_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """desc_last: [cap, 32] uint8, n_last: int32 scalar / 1-element tensor -> one flat uint8 block (into `out` if given)"""
     cap = desc_last.shape[0]
-    block = torch.zeros(_block_bytes(cap), dtype=torch.uint8, device=desc_last.device)
+    block = out if out is not None else torch.zeros(_block_bytes(cap), dtype=torch.uint8, device=desc_last.device)
     block[:cap * 32].copy_(desc_last.reshape(-1))
     block[cap * 32:cap * 32 + 4].copy_(n_last.reshape(1).to(torch.int32).view(torch.uint8))
     return block
@@ -33,15 +58,76 @@ def unpack_boundary(block: torch.Tensor, cap: int):
     return block[:cap * 32].view(cap, 32), n
 
 
+class BoundaryExchanger:
+    """torch.distributed form of the exchange step with everything preallocated: the gather buffer [world][block] twice (a
+    step's match may still read one while the next step gathers into the other); this rank packs straight into its slot."""
+
+    def __init__(self, cap: int, device, group=None):
+        self.cap, self.group = cap, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.blk = _block_bytes(cap)
+        self.bufs = [torch.zeros(self.world * self.blk, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.turn = 0
+
+    def __call__(self, desc_last: torch.Tensor, n_last: torch.Tensor):
+        out = self.bufs[self.turn]
+        self.turn ^= 1
+        mine = out[self.rank * self.blk:(self.rank + 1) * self.blk]
+        pack_boundary(desc_last, n_last, mine)
+        if self.world > 1 or (dist.is_initialized() and os.environ.get("DVS_FORCE_COLLECTIVE") == "1"):
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        prev = (self.rank - 1) % self.world
+        return unpack_boundary(out[prev * self.blk:(prev + 1) * self.blk], self.cap)
+
+
+_exchangers = {}
+
+
 def exchange_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, cap: int, group=None):
-    """all_gather every rank's last-frame block; return (desc, n) of the PREVIOUS rank (the last rank's
+    """all-gather every rank's last-frame block; return (desc, n) of the PREVIOUS rank (the last rank's
     block of the previous global batch wraps around to rank 0, like a streaming sequence would)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1 and not (dist.is_initialized() and os.environ.get("DVS_FORCE_COLLECTIVE") == "1"):
         return desc_last, n_last.reshape(-1)[0]   # one rank: the predecessor is the caller's own last frame, in place
-    mine = pack_boundary(desc_last, n_last)
-    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    prev = (rank - 1) % world
-    return unpack_boundary(out[prev * mine.numel():(prev + 1) * mine.numel()], cap)
+    key = (cap, str(desc_last.device), id(group), world)
+    if key not in _exchangers:
+        _exchangers[key] = BoundaryExchanger(cap, desc_last.device, group)
+    return _exchangers[key](desc_last, n_last)
+
+
+class Comm:
+    """dvs_comm of the C-ABI: RCCL communicator + the boundary exchange on a raw HIP stream.  `bcast_id(id_bytes_or_None)`
+    is the caller's out-of-band broadcast of the 128-byte unique id from rank 0 (bench.py: torch.distributed's store)."""
+
+    def __init__(self, device: int, rank: int, world: int, bcast_id):
+        from ._lib import lib, check
+        self._L, self._check = lib(), check
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * ID_BYTES)()
+            check(self._L.dvs_comm_get_unique_id(buf))
+            ident = bytes(buf)
+        ident = bcast_id(ident)
+        assert isinstance(ident, (bytes, bytearray)) and len(ident) == ID_BYTES
+        h = C.c_void_p()
+        check(self._L.dvs_comm_create(device, rank, world, (C.c_uint8 * ID_BYTES).from_buffer_copy(ident), C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    @property
+    def rccl_version(self):
+        return int(self._L.dvs_comm_rccl_version())
+
+    def exchange_boundary(self, stream: int, d_desc_last: int, d_n_last: int, cap: int):
+        """-> (device pointer of the predecessor's descriptors, device pointer of its count); asynchronous on `stream`"""
+        pd, pn = C.c_void_p(), C.c_void_p()
+        self._check(self._L.dvs_exchange_boundary(self.h, stream, d_desc_last, d_n_last, cap, C.byref(pd), C.byref(pn)))
+        return pd.value, pn.value
+
+    def all_gather(self, stream: int, d_send: int, d_recv: int, nbytes: int):
+        self._check(self._L.dvs_comm_all_gather(self.h, stream, d_send, d_recv, nbytes))
+
+    def close(self):
+        if self.h:
+            self._L.dvs_comm_destroy(self.h)
+            self.h = None

@@ -70,4 +70,16 @@ class BFMatcher {
   dvs_matcher* m_ = nullptr;
 };
 
+#ifdef DVSLAM_WITH_OPENCV
+// cv::BFMatcher's own constructor signature for the reference's two member declarations (frontend.cpp:220
+// `matcher_(cv::NORM_HAMMING)`, backend.cpp:222 `descriptor_matcher_(cv::NORM_HAMMING, false)`): changing the member's TYPE
+// from cv::BFMatcher to dvslam::HammingBFMatcher is the whole matcher-side integration; every match() call compiles unchanged.
+class HammingBFMatcher : public BFMatcher {
+ public:
+  explicit HammingBFMatcher(int normType = cv::NORM_HAMMING, bool crossCheck = false) : BFMatcher(0) {
+    CV_Assert(normType == cv::NORM_HAMMING && !crossCheck);  // the only configuration the reference uses
+  }
+};
+#endif
+
 }  // namespace dvslam

@@ -8,6 +8,7 @@
 // Error behaviour mirrors the reference: operator() returns -1 for an empty image
 // (ORBextractor.cpp:1090-1091), otherwise the number of keypoints; other failures throw.
 #pragma once
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -81,13 +82,15 @@ class OrbExtractor {
 
 #ifdef DVSLAM_WITH_OPENCV
 namespace ORB_SLAM3 {
-// Same name, constructor and operator() as the reference class, so `#include "dvslam/orb_extractor.hpp"` instead of
-// "dynamic_visual_slam/ORBextractor.hpp" is the whole integration on the frontend side.
+// Same name, constructor, operator(), getters and public mvImagePyramid member as the reference class
+// (ORBextractor.hpp:44-110), so including this instead of the reference's header is the whole integration on the frontend
+// side (include/dynamic_visual_slam/ORBextractor.hpp of this repo does exactly that under the reference's include path).
 class ORBextractor {
  public:
   enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
       : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) {}
+  ~ORBextractor() {}
   int operator()(cv::InputArray _image, cv::InputArray /*_mask: ignored, ORBextractor.hpp:57*/, std::vector<cv::KeyPoint>& _keypoints,
                  cv::OutputArray _descriptors, std::vector<int>& /*vLappingArea = {0,0}: stereo branch never fires*/) {
     if (_image.empty()) return -1;
@@ -96,13 +99,21 @@ class ORBextractor {
     std::vector<dvs_keypoint> kps;
     std::vector<uint8_t> desc;
     const int n = impl_(image.data, image.rows, image.cols, image.step, kps, desc);
+    if (keep_pyramid_) {  // the reference leaves the pyramid of the last frame in this public member (ORBextractor.cpp:1169-1194)
+      mvImagePyramid.resize(impl_.GetLevels());
+      for (int l = 0; l < impl_.GetLevels(); l++) {
+        int lr = 0, lc = 0;
+        const std::vector<uint8_t> px = impl_.PyramidLevel(image.rows, image.cols, l, &lr, &lc);
+        mvImagePyramid[l].create(lr, lc, CV_8UC1);
+        std::memcpy(mvImagePyramid[l].data, px.data(), px.size());
+      }
+    }
     if (n <= 0) { _descriptors.release(); _keypoints.clear(); return n; }
     _descriptors.create(n, 32, CV_8U);
     std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
     _keypoints.resize(n);
     for (int i = 0; i < n; i++)
       _keypoints[i] = cv::KeyPoint(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, kps[i].class_id);
-    rows_ = image.rows; cols_ = image.cols;
     return n;
   }
   int GetLevels() { return impl_.GetLevels(); }
@@ -112,9 +123,15 @@ class ORBextractor {
   std::vector<float> GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
   std::vector<float> GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
 
+  // level images of the last frame (continuous 8UC1; the reference's are views into a bordered buffer, same pixels).  The
+  // reference's frontend never reads it, and filling it costs one device-to-host copy of the pyramid (2.85 MB at 720p) per
+  // frame: callers that do not need it switch the copy off.
+  std::vector<cv::Mat> mvImagePyramid;
+  void keepImagePyramid(bool on) { keep_pyramid_ = on; if (!on) mvImagePyramid.clear(); }
+
  private:
   dvslam::OrbExtractor impl_;
-  int rows_ = 0, cols_ = 0;
+  bool keep_pyramid_ = true;
 };
 }  // namespace ORB_SLAM3
 #endif

@@ -44,6 +44,7 @@ int32_t dvs_device_count(void);
  * can be made right after the handles: HIP maps streams to hardware queues in creation order, and the path's concurrent
  * streams should be neighbours in that order ("Streams and hardware queues"). */
 dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_stream);
+dvs_status dvs_stream_synchronize(void* stream);
 dvs_status dvs_stream_destroy(void* stream);
 /* "gfx950" etc. for the given device, "" on error */
 dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap);
@@ -162,6 +163,33 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
 dvs_status dvs_match_hamming_thresh(dvs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt,
                                     int32_t max_dist, int32_t* pairs, int32_t cap, int32_t* n_pairs);
 
+/* ======================= E: the multi-GPU exchange step ========================== */
+/* One process per GPU; frames (or, for small batches, pyramid levels) are sharded over the ranks and extraction needs no
+ * communication.  The match job (t, t-1) at a shard boundary needs the previous rank's last-frame descriptors: ONE
+ * ncclAllGather of fixed-size blocks per step, over RCCL/xGMI, on the caller's stream.  The reference has no counterpart
+ * (single process per node; frontend.cpp:1096 keeps prev_descriptors_ in host memory).  RCCL is dlopen'ed at first use.
+ *
+ * Bring-up: rank 0 calls dvs_comm_get_unique_id and hands the 128 bytes to the other ranks out of band (MPI_Bcast, a TCP
+ * store, a file); every rank then calls dvs_comm_create (collective, blocks until all ranks arrived). */
+typedef struct dvs_comm dvs_comm;
+#define DVS_COMM_ID_BYTES 128
+dvs_status dvs_comm_get_unique_id(uint8_t* id /* [DVS_COMM_ID_BYTES] */);
+dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t* id, dvs_comm** out);
+void dvs_comm_destroy(dvs_comm* c);
+int32_t dvs_comm_rank(const dvs_comm* c);
+int32_t dvs_comm_world(const dvs_comm* c);
+int32_t dvs_comm_rccl_version(void);  /* ncclGetVersion code, 0 if RCCL is unavailable */
+/* bytes of one rank's boundary block {descriptors[cap x 32], int32 n, padding to 64 B} */
+size_t dvs_boundary_block_bytes(int32_t cap);
+/* The exchange step.  Packs {d_desc_last (cap rows of 32 B, 16-byte aligned), *d_n_last} into this rank's slot of a gather
+ * buffer owned by the communicator (two buffers used alternately, allocated once per capacity), all-gathers in place on
+ * `stream`, and returns device pointers to the PREDECESSOR rank's descriptors / count (rank 0's predecessor is the last
+ * rank: the previous global batch's last frame), valid until the call after next.  Asynchronous. */
+dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_desc_last, const int32_t* d_n_last, int32_t cap,
+                                 const uint8_t** d_prev_desc, const int32_t** d_prev_n);
+/* plain all-gather of bytes_per_rank bytes per rank (level-sharded extraction gathers its per-level blocks with it) */
+dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, void* d_recv, size_t bytes_per_rank);
+
 /* ======================= glue either side of the path =============== */
 /* A dvs_matcher handle is the context (stream + scratch).  Host pointers unless the name says _device. */
 
@@ -186,7 +214,9 @@ dvs_status dvs_filter_depth_batch_device(dvs_matcher* ctx, const dvs_keypoint* d
 dvs_status dvs_filter_matches(dvs_matcher* ctx, const int32_t* train_idx, const int32_t* dist, int32_t n, float max_distance,
                               int32_t* out_triplets, int32_t* n_out);
 /* publishKeyframe (frontend.cpp:732-776): float back-projection with the depth image, keep 0.3 < Z < 3.0, world = R * p + t
- * (R row-major 3x3, double).  world_xyz[3 * n_out], out_index = keypoint indices (= the message's landmark_id). */
+ * (R row-major 3x3, double).  world_xyz[3 * n_out], out_index = keypoint indices (= the message's landmark_id).
+ * A keypoint whose rounded position lies outside the depth image is dropped — here, in dvs_publish_keyframe* and in
+ * dvs_filter_depth* alike (the reference reads the depth image unchecked at frontend.cpp:737). */
 dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n, const uint16_t* depth, int32_t rows, int32_t cols,
                            size_t step_bytes, float fx, float fy, float cx, float cy, const double* R, const double* t, double* world_xyz,
                            int32_t* out_index, int32_t* n_out);
@@ -283,6 +313,11 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double function_toler
  * <= 64 cameras, 1..16 of them free, a landmark observed at most once per camera; DVS_ERR_UNSUPPORTED otherwise. */
 dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double function_tolerance, double gradient_tolerance,
                                double parameter_tolerance, dvs_ba_summary* summary);
+/* Trust-region log of the last dvs_ba_solve / dvs_ba_solve_device (what ceres::Solver::Summary::iterations holds): one row of
+ * 6 doubles per iteration = {radius the step was computed with, kind, cost change, model cost change, relative decrease,
+ * candidate cost}; kind 0 = invalid step, 1 = accepted, 2 = rejected, 3 / 4 = parameter / function tolerance reached.
+ * *n_rows = rows available; at most cap_rows are written (rows may be NULL). */
+dvs_status dvs_ba_get_trace(const dvs_ba* h, double* rows, int32_t cap_rows, int32_t* n_rows);
 dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X);
 /* CameraPose::fromRt / toRt (bundle_adjustment.hpp:138-165, 192-212): caller-convention (R row-major 3x3, t) <->
  * optimiser (q_wxyz, translation).  Host arithmetic used by the SlidingWindowBA adapter. */

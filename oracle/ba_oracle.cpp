@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -152,6 +153,9 @@ struct Problem {
   std::vector<int> cam, lm;
   std::vector<uint8_t> pose_fixed, lm_fixed;
   double fx, fy, cx, cy, sigma, huber_a;
+  // per trust-region iteration of the last solve: radius used, kind (0 invalid step, 1 accepted, 2 rejected, 3 parameter
+  // tolerance reached, 4 function tolerance reached), cost change, model cost change, relative decrease, candidate cost
+  std::vector<double> trace;
 };
 
 // one residual block as ceres::ResidualBlock::Evaluate delivers it to the program evaluator:
@@ -278,6 +282,11 @@ Summary solveLM(Problem& P, int max_iterations, double ftol, double gtol, double
   const int K = P.K, L = P.L, R = P.R;
   const int NT = 6 * K + 3 * L;
   Summary S{}; S.termination = 1;
+  P.trace.clear();
+  auto log = [&](double radius_, int kind, double dc, double dm, double rel, double cand) {
+    const double row[6] = {radius_, (double)kind, dc, dm, rel, cand};
+    P.trace.insert(P.trace.end(), row, row + 6);
+  };
   std::vector<double> q = P.q, t = P.t, X = P.X;
   // variable (non-constant, referenced) tangent columns
   std::vector<uint8_t> lmUsed(L, 0), camUsed(K, 0);
@@ -405,6 +414,7 @@ Summary solveLM(Problem& P, int max_iterations, double ftol, double gtol, double
       if (model_cost_change <= 0.0) step_valid = false;
     }
     if (!step_valid) {
+      log(radius, 0, 0, model_cost_change, 0, 0);
       if (++invalid >= 5) { S.termination = 2; break; }
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;  // StepIsInvalid
       continue;
@@ -423,11 +433,12 @@ Summary solveLM(Problem& P, int max_iterations, double ftol, double gtol, double
     double sn = 0;
     for (int c = 0; c < K; c++) if (active[6 * c]) { for (int i = 0; i < 4; i++) sn += (q[4 * c + i] - cq[4 * c + i]) * (q[4 * c + i] - cq[4 * c + i]); for (int i = 0; i < 3; i++) sn += (t[3 * c + i] - ct[3 * c + i]) * (t[3 * c + i] - ct[3 * c + i]); }
     for (int l = 0; l < L; l++) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) sn += (X[3 * l + i] - cX[3 * l + i]) * (X[3 * l + i] - cX[3 * l + i]);
-    if (std::sqrt(sn) <= ptol * (xnorm() + ptol)) { S.termination = 0; break; }
+    if (std::sqrt(sn) <= ptol * (xnorm() + ptol)) { log(radius, 3, x_cost - cand_cost, model_cost_change, 0, cand_cost); S.termination = 0; break; }
     // function tolerance
     const double cost_change = x_cost - cand_cost;
-    if (std::fabs(cost_change) <= ftol * x_cost) { S.termination = 0; break; }
+    if (std::fabs(cost_change) <= ftol * x_cost) { log(radius, 4, cost_change, model_cost_change, 0, cand_cost); S.termination = 0; break; }
     const double rel_decrease = cost_change / model_cost_change;
+    log(radius, rel_decrease > min_rel_decrease ? 1 : 2, cost_change, model_cost_change, rel_decrease, cand_cost);
     if (rel_decrease > min_rel_decrease) {
       q = cq; t = ct; X = cX;
       buildNormal(P, q, t, X, Nn);
@@ -491,6 +502,53 @@ void orc_ba_evaluate(void* h, double* cost, double* res, double* Jp, double* Jl,
   if (Jl) memcpy(Jl, jl.data(), jl.size() * 8);
   if (grad) memcpy(grad, Nn.g.data(), Nn.g.size() * 8);
 }
+// `reps` evaluations (residuals, local Jacobians, loss correction, cost and the H_pp / H_ll / g sums) with the residual blocks
+// split over `nthreads` threads — how Ceres evaluates with options.num_threads = 4 (bundle_adjustment.hpp:842): every thread
+// owns a contiguous slice of the residual blocks and its own accumulators, summed at the end.  Timed CPU baseline only.
+void orc_ba_evaluate_mt(void* h, int nthreads, int reps, double* cost) {
+  Problem& P = *(Problem*)h;
+  nthreads = std::max(1, nthreads);
+  std::vector<double> res((size_t)P.R * 2), JP((size_t)P.R * 12), JL((size_t)P.R * 6), W((size_t)P.R * 18);
+  double total = 0;
+  for (int rep = 0; rep < reps; rep++) {
+    std::vector<Normal> part(nthreads);
+    std::vector<std::thread> th;
+    for (int w = 0; w < nthreads; w++)
+      th.emplace_back([&, w]() {
+        Normal& Nn = part[w];
+        Nn.Hpp.assign((size_t)P.K * 36, 0); Nn.Hll.assign((size_t)P.L * 9, 0); Nn.g.assign((size_t)6 * P.K + 3 * P.L, 0); Nn.cost = 0;
+        const int i0 = (int)((long)P.R * w / nthreads), i1 = (int)((long)P.R * (w + 1) / nthreads);
+        for (int i = i0; i < i1; i++) {
+          const int c = P.cam[i], l = P.lm[i];
+          double* r = &res[2 * i]; double* Jp = &JP[12 * i]; double* Jl = &JL[6 * i];
+          Nn.cost += evalBlock(P, &P.q[4 * c], &P.t[3 * c], &P.X[3 * l], &P.uv[2 * i], r, Jp, Jl);
+          const bool pf = P.pose_fixed[c], lf = P.lm_fixed[l];
+          if (!pf)
+            for (int a = 0; a < 6; a++) {
+              Nn.g[6 * c + a] += Jp[a] * r[0] + Jp[6 + a] * r[1];
+              for (int b = 0; b < 6; b++) Nn.Hpp[36 * c + 6 * a + b] += Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b];
+            }
+          if (!lf)
+            for (int a = 0; a < 3; a++) {
+              Nn.g[6 * P.K + 3 * l + a] += Jl[a] * r[0] + Jl[3 + a] * r[1];
+              for (int b = 0; b < 3; b++) Nn.Hll[9 * l + 3 * a + b] += Jl[a] * Jl[b] + Jl[3 + a] * Jl[3 + b];
+            }
+          if (!pf && !lf)
+            for (int a = 0; a < 6; a++)
+              for (int b = 0; b < 3; b++) W[18 * i + 3 * a + b] = Jp[a] * Jl[b] + Jp[6 + a] * Jl[3 + b];
+        }
+      });
+    for (auto& t : th) t.join();
+    total = 0;
+    for (int w = 1; w < nthreads; w++) {
+      for (size_t k = 0; k < part[0].Hpp.size(); k++) part[0].Hpp[k] += part[w].Hpp[k];
+      for (size_t k = 0; k < part[0].Hll.size(); k++) part[0].Hll[k] += part[w].Hll[k];
+      for (size_t k = 0; k < part[0].g.size(); k++) part[0].g[k] += part[w].g[k];
+    }
+    for (int w = 0; w < nthreads; w++) total += part[w].cost;
+  }
+  if (cost) *cost = total;
+}
 void orc_ba_normal_equations(void* h, double* Hpp, double* Hll, double* W, double* g, double* cost) {
   Problem& P = *(Problem*)h;
   Normal Nn;
@@ -504,6 +562,12 @@ void orc_ba_normal_equations(void* h, double* Hpp, double* Hll, double* W, doubl
 void orc_ba_solve(void* h, int max_iterations, double ftol, double gtol, double ptol, void* summary) {
   Summary s = solveLM(*(Problem*)h, max_iterations, ftol, gtol, ptol);
   memcpy(summary, &s, sizeof(s));
+}
+int orc_ba_get_trace(void* h, double* rows, int cap_rows) {
+  Problem& P = *(Problem*)h;
+  const int n = (int)(P.trace.size() / 6);
+  if (rows) memcpy(rows, P.trace.data(), (size_t)std::min(n, cap_rows) * 6 * 8);
+  return n;
 }
 void orc_ba_get_parameters(void* h, double* q, double* t, double* X) {
   Problem& P = *(Problem*)h;

@@ -1,0 +1,82 @@
+// Compiles EVERY `DVSLAM_WITH_OPENCV` branch and both drop-in headers (include/dynamic_visual_slam/*.hpp) against the test-only
+// stand-ins in tests/cpp/stubs/, written the way the reference's call sites use the types (frontend.cpp:205-220, 1094-1095,
+// 1123; backend.cpp:180, 222, 908-973, 1072, 1356-1392).  On a GPU box it also runs them.  Exit 0 = ok, 3 = no GPU.
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include "dynamic_visual_slam/ORBextractor.hpp"
+#include "dynamic_visual_slam/bundle_adjustment.hpp"
+#include "dvslam/bf_matcher.hpp"
+
+int main() {
+  if (dvs_device_count() < 1) { std::printf("no device: OpenCV-typed adapters compiled, nothing run\n"); return 3; }
+  const int rows = 480, cols = 640;
+  cv::Mat gray(rows, cols, CV_8UC1);
+  uint32_t s = 12345;
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      s = s * 1664525u + 1013904223u;
+      gray.at<uint8_t>(y, x) = (uint8_t)(((((x / 37) + (y / 29)) & 1) ? 190 : 60) + (int)((s >> 24) % 17) - 8);
+    }
+  // frontend.cpp:205-211, 220
+  auto orb_extractor_ = std::make_unique<ORB_SLAM3::ORBextractor>(500, 1.2f, 8, 20, 7);
+  dvslam::HammingBFMatcher matcher_(cv::NORM_HAMMING);
+  std::vector<int> vLappingArea = {0, 0};
+  std::vector<cv::KeyPoint> kps;
+  cv::Mat descriptors;
+  const int n = (*orb_extractor_)(gray, cv::noArray(), kps, descriptors, vLappingArea);   // frontend.cpp:1094-1095
+  if (n <= 0 || descriptors.rows != n || descriptors.cols != 32 || (int)kps.size() != n) { std::printf("extract: %d\n", n); return 1; }
+  if ((int)orb_extractor_->mvImagePyramid.size() != orb_extractor_->GetLevels()) { std::printf("mvImagePyramid missing\n"); return 1; }
+  const std::vector<float> sf = orb_extractor_->GetScaleFactors();
+  for (int l = 0; l < orb_extractor_->GetLevels(); l++) {
+    const cv::Mat& L = orb_extractor_->mvImagePyramid[l];
+    const float inv = 1.0f / sf[l];
+    if (L.cols != (int)std::lrintf((float)cols * inv) || L.rows != (int)std::lrintf((float)rows * inv)) { std::printf("level %d size %dx%d\n", l, L.cols, L.rows); return 1; }
+  }
+  if (std::memcmp(orb_extractor_->mvImagePyramid[0].data, gray.data, (size_t)rows * cols) != 0) { std::printf("level 0 != input\n"); return 1; }
+  cv::Mat empty;
+  if ((*orb_extractor_)(empty, cv::noArray(), kps, descriptors, vLappingArea) != -1) { std::printf("empty image must return -1\n"); return 1; }
+  (*orb_extractor_)(gray, cv::noArray(), kps, descriptors, vLappingArea);
+  std::vector<cv::DMatch> all_matches;
+  matcher_.match(descriptors, descriptors, all_matches);                                     // frontend.cpp:1123
+  for (int i = 0; i < n; i++)
+    if (all_matches[i].distance != 0.f || all_matches[i].queryIdx != i) { std::printf("self-match %d\n", i); return 1; }
+  dvslam::HammingBFMatcher descriptor_matcher_(cv::NORM_HAMMING, false);                     // backend.cpp:222
+  // backend.cpp:908-960: window assembly + optimize, then :967-977 / :1356-1392 result handling
+  std::unique_ptr<SlidingWindowBA> bundle_adjuster_ = std::make_unique<SlidingWindowBA>(900.0, 900.0, 640.0, 360.0);
+  std::vector<KeyframeData> window_keyframes;
+  for (int k = 0; k < 2; k++) {
+    cv::Mat R(3, 3, CV_64F), t(3, 1, CV_64F);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R.at<double>(i, j) = i == j ? 1.0 : 0.0; t.at<double>(i) = 0.0; }
+    t.at<double>(0) = 0.3 * k;
+    window_keyframes.emplace_back(7 + 2 * k, R, t, rclcpp::Time(1000 * k));
+  }
+  std::vector<Landmark> landmarks; std::vector<Observation> observations;
+  for (int i = 0; i < 30; i++) {
+    const double X = -1.0 + 0.07 * i, Y = 0.5 * std::sin(0.7 * i), Z = 3.0 + 0.05 * i;
+    landmarks.emplace_back(100 + i, "unlabeled", X, Y, Z);
+    observations.emplace_back(900 * X / Z + 640, 900 * Y / Z + 360, 100 + i, "unlabeled", 7);
+    observations.emplace_back(900 * (X - 0.3) / Z + 640, 900 * Y / Z + 360, 100 + i, "unlabeled", 9);
+  }
+  OptimizationResult result = bundle_adjuster_->optimize(window_keyframes, landmarks, observations, 20);
+  result = bundle_adjuster_->optimize(window_keyframes, landmarks, observations, 20);     // the handle is reused across calls
+  if (!result.success || result.final_cost > 1e-12 || result.optimized_poses.size() != 2 || result.optimized_landmarks.size() != 30) {
+    std::printf("BA: %s cost %g\n", result.message.c_str(), result.final_cost); return 1;
+  }
+  for (const auto& [frame_id, pose_pair] : result.optimized_poses) {                       // backend.cpp:1358-1370
+    const auto& [R_opt, t_opt] = pose_pair;
+    cv::Mat Rc = R_opt.clone(), tc = t_opt.clone();
+    if (Rc.rows != 3 || Rc.cols != 3 || tc.rows != 3 || tc.cols != 1 || frame_id < 7) return 1;
+  }
+  for (const auto& [landmark_key, optimized_pos] : result.optimized_landmarks) {           // backend.cpp:1373-1387
+    const auto& [landmark_id, landmark_category] = landmark_key;
+    if (landmark_id < 100 || landmark_category != "unlabeled" || !(optimized_pos.z > 0)) return 1;
+  }
+  CameraPose cp;                                                                            // bundle_adjustment.hpp:92-213 round trip
+  cp.fromRt(window_keyframes[1].R, window_keyframes[1].t);
+  cv::Mat R2, t2;
+  cp.toRt(R2, t2);
+  if (std::fabs(t2.at<double>(0) - 0.3) > 1e-12 || std::fabs(R2.at<double>(1, 1) - 1.0) > 1e-12) return 1;
+  std::printf("opencv-typed adapters ok: %d keypoints, BA cost %.3e in %d steps\n", n, result.final_cost, result.iterations_completed);
+  return 0;
+}

@@ -13,8 +13,38 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 assert KP_DTYPE.itemsize == 28
 
 
+FLAGS = "-O2 -ffp-contract=off (portable x86-64)"
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def use_native():
+    """bench.py's cpu_baseline: rebuild the oracle with -O2 -march=native ON THIS MACHINE and load that copy.
+    Must be called before the first lib().  The native build is deleted first so that a copy made on another CPU never runs
+    here.  Falls back to the portable build (and says so in FLAGS) if the compiler is missing."""
+    global _SO, FLAGS
+    assert "_lib" not in globals(), "use_native() must precede the first oracle call"
+    nat = os.path.join(_ROOT, "oracle", "_build", "native")
+    try:
+        subprocess.check_call(["rm", "-rf", nat])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "native"])
+        _SO = os.path.join(nat, "liboracle.so")
+        FLAGS = open(os.path.join(nat, "flags.txt")).read().strip().split(" -std")[0] + " -ffp-contract=off"
+    except Exception as e:  # noqa: BLE001
+        FLAGS += f" [native build failed: {e}]"
+    return FLAGS
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def lib():
@@ -156,6 +186,8 @@ class OracleBA:
         L.orc_ba_evaluate.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_ba_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_ba_solve.argtypes = [vp, i32, dbl, dbl, dbl, vp]
+        L.orc_ba_evaluate_mt.argtypes = [vp, i32, i32, vp]
+        L.orc_ba_get_trace.argtypes = [vp, vp, i32]; L.orc_ba_get_trace.restype = i32
         L.orc_ba_get_parameters.argtypes = [vp, vp, vp, vp]
         self.L = L
         self.K, self.Ln, self.R = prob["K"], prob["L"], len(prob["cam_idx"])
@@ -193,6 +225,18 @@ class OracleBA:
         s = BaSummary()
         self.L.orc_ba_solve(self.h, max_iterations, ftol, gtol, ptol, C.byref(s))
         return s
+
+    def trace(self):
+        n = self.L.orc_ba_get_trace(self.h, None, 0)
+        rows = np.zeros((n, 6))
+        self.L.orc_ba_get_trace(self.h, _p(rows), n)
+        return rows
+
+    def evaluate_mt(self, nthreads, reps=1):
+        """`reps` full evaluations with the residual blocks split over `nthreads` threads (timed CPU baseline)"""
+        cost = C.c_double()
+        self.L.orc_ba_evaluate_mt(self.h, nthreads, reps, C.byref(cost))
+        return cost.value
 
     def parameters(self):
         q = np.zeros((self.K, 4)); t = np.zeros((self.K, 3)); X = np.zeros((self.Ln, 3))

@@ -19,6 +19,33 @@ def _build_adapter_smoke(tmpdir, hiplib):
     return exe
 
 
+def _build_opencv_typed(tmpdir, hiplib):
+    """every DVSLAM_WITH_OPENCV branch + the two drop-in headers include/dynamic_visual_slam/*.hpp, against the TEST-ONLY cv:: /
+    rclcpp:: stand-ins of tests/cpp/stubs (compile check + data movement; they pin nothing about OpenCV)"""
+    exe = os.path.join(str(tmpdir), "adapter_opencv")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"),
+           os.path.join(ROOT, "tests", "cpp", "adapter_opencv_compile.cpp"), "-o", exe, "-L" + LIBDIR, "-ldvslam_hip", "-Wl,-rpath," + LIBDIR,
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_opencv_typed_adapters_compile(tmp_path, hiplib):
+    from dvslam_amd import device_count
+    exe = _build_opencv_typed(tmp_path, hiplib)
+    assert subprocess.call([exe]) == (0 if device_count() > 0 else 3)
+
+
+@pytest.mark.gpu
+def test_opencv_typed_adapters_run_on_gpu(tmp_path, gpu, hiplib):
+    """ORB_SLAM3::ORBextractor (cv::InputArray signature, mvImagePyramid), dvslam::HammingBFMatcher and the global-namespace
+    SlidingWindowBA / KeyframeData / OptimizationResult written like the reference's call sites"""
+    exe = _build_opencv_typed(tmp_path, hiplib)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "opencv-typed adapters ok" in out.stdout
+
+
 def test_adapters_compile_and_refuse_without_gpu(tmp_path, hiplib):
     from dvslam_amd import device_count
     exe = _build_adapter_smoke(tmp_path, hiplib)
@@ -75,3 +102,80 @@ def test_single_rank_exchange_is_identity():
     desc = torch.arange(64 * 32, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(64, 32)
     d, n = dvdist.exchange_boundary(desc, torch.tensor(17, dtype=torch.int32), 64)
     assert int(n) == 17 and torch.equal(d, desc)
+
+
+def test_level_shards_cover_every_level_once():
+    """SURVEY.md §8e, small batches: levels -> ranks balanced by pixel count; every level owned by exactly one rank"""
+    from dvslam_amd import dist as dvdist
+    px = [1280 * 720, 1067 * 600, 889 * 500, 741 * 417, 617 * 347, 514 * 289, 429 * 241, 357 * 201]
+    for world in (1, 2, 3, 4, 8):
+        masks = dvdist.level_shards(px, world)
+        assert len(masks) == world
+        union = 0
+        for m in masks:
+            assert union & m == 0
+            union |= m
+        assert union == 0xFF
+        load = [sum(px[l] for l in range(8) if m >> l & 1) for m in masks]
+        assert max(load) <= max(px[0], 1.34 * sum(px) / world)      # level 0 alone is 32 % of the work: the floor for >= 4 ranks
+    assert dvdist.level_shards(px, 8) == [1 << l for l in range(8)]
+
+
+def test_bench_self_launch_spawns_the_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts its own two ranks as a child process (before torch / the GPU is
+    touched); --dry-launch makes the ranks report themselves instead of running GPU work"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    ranks = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in ranks) == [0, 1] and all(r["world"] == 2 and r["dry_launch"] for r in ranks)
+    assert len({r["pid"] for r in ranks}) == 2
+    # under a launcher (the driver's form) the same file must NOT spawn again: it reads RANK / WORLD_SIZE from the environment
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-launch"], capture_output=True, text=True,
+                         env=env2, timeout=120)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_comm_c_abi_refuses_without_gpu(hiplib):
+    """the RCCL exchange behind the C-ABI: symbols exist, the block layout equals dist.py's, and without a device
+    dvs_comm_create says DVS_ERR_NO_DEVICE instead of falling back to anything"""
+    import ctypes as C
+    from dvslam_amd import device_count
+    from dvslam_amd import dist as dvdist
+    for cap in (1, 500, 2024, 3024):
+        assert hiplib.dvs_boundary_block_bytes(cap) == dvdist._block_bytes(cap)
+    if device_count() == 0:
+        h = C.c_void_p()
+        ident = (C.c_uint8 * 128)()
+        assert hiplib.dvs_comm_create(0, 0, 1, ident, C.byref(h)) == -5
+
+
+@pytest.mark.gpu
+def test_comm_exchange_single_rank_on_gpu(gpu, hiplib):
+    """world = 1 RCCL communicator through the C-ABI: the exchange packs {descriptors, n}, all-gathers in place and hands back
+    the predecessor's (= own) block; two calls alternate between the two gather buffers"""
+    import ctypes as C
+    from dvslam_amd import _lib
+    from dvslam_amd import dist as dvdist
+    comm = dvdist.Comm(0, 0, 1, lambda ident: ident)
+    assert comm.rccl_version > 0
+    cap = 2024
+    rng = np.random.default_rng(5)
+    st = _lib.stream_create(0)
+    seen = []
+    for rnd in range(3):
+        desc = rng.integers(0, 256, size=(cap, 32), dtype=np.uint8)
+        n = np.array([1900 + rnd], np.int32)
+        d_desc = _lib.DeviceBuffer(desc.nbytes).upload(desc); d_n = _lib.DeviceBuffer(4).upload(n)
+        pd, pn = comm.exchange_boundary(st, d_desc.ptr, d_n.ptr, cap)
+        got = np.empty((cap, 32), np.uint8); gn = np.empty(1, np.int32)
+        _lib.stream_synchronize(st)   # the exchange is asynchronous on `st`, a non-blocking stream
+        _lib.check(hiplib.dvs_memcpy_d2h(0, got.ctypes.data, pd, got.nbytes)); _lib.check(hiplib.dvs_memcpy_d2h(0, gn.ctypes.data, pn, 4))
+        assert (got == desc).all() and gn[0] == 1900 + rnd
+        seen.append(pd)
+    assert seen[0] != seen[1] and seen[0] == seen[2], "two gather buffers used alternately"
+    comm.close()
+    _lib.stream_destroy(st)

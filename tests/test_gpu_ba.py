@@ -138,3 +138,44 @@ def test_sliding_window_adapter_round_trip(gpu, oracle):
     oracle.lib().orc_ba_from_rt.argtypes = [oracle.C.c_void_p] * 4
     oracle.lib().orc_ba_from_rt(np.ascontiguousarray(kfs[2][1]).ctypes.data, np.ascontiguousarray(kfs[2][2]).ctypes.data, q.ctypes.data, tr.ctypes.data)
     assert np.allclose(q, P["q"][2] if P["q"][2][0] * q[0] > 0 else -P["q"][2], atol=1e-12) and np.allclose(tr, P["t"][2], atol=1e-12)
+
+
+# ---- the LM loop bracketed from outside its own transcription (tests/ba_bracket.py) ------
+@pytest.mark.parametrize("solver", ["host_schur", "device"])
+@pytest.mark.parametrize("name", ["3x60", "5x200", "10x2000"])
+def test_lm_reaches_the_scipy_optimum(gpu, name, solver):
+    """run to convergence (100 iterations, tolerances far below Ceres' defaults) and land on the optimum an independent
+    scipy.optimize.least_squares(loss="huber") solve found: relative cost <= 1e-6, poses equal up to the free scale gauge"""
+    import ba_bracket as bb
+    from dvslam_amd import BAProblem
+    kw, G = bb.scipy_golden(name)
+    g = BAProblem(synth.make_ba_problem(**kw))
+    s = (g.solve if solver == "host_schur" else g.solve_device)(100, 1e-14, 1e-14, 1e-14)
+    assert abs(s.initial_cost - float(G["initial_cost"])) <= 1e-9 * s.initial_cost
+    assert abs(s.final_cost - float(G["optimum_cost"])) <= 1e-6 * float(G["optimum_cost"]), (s.final_cost, float(G["optimum_cost"]))
+    q, t, X = g.parameters()
+    ang, dc, dX, scale = bb.gauge_aligned_errors(q, t, X, G["q"], G["t"], G["X"])
+    assert ang < 2e-4 and dc < 2e-3, (ang, dc, dX, scale)
+    bb.check_schedule(g.trace())
+
+
+@pytest.mark.parametrize("solver", ["host_schur", "device"])
+@pytest.mark.parametrize("kw", __import__("ba_bracket").HARD, ids=["5x200 seed 4", "5x200 seed 3", "10x2000 seed 42"])
+def test_lm_continues_correctly_after_rejected_steps(gpu, oracle, kw, solver):
+    """windows whose run contains rejected / invalid steps FOLLOWED by further iterations (a candidate's cost-only
+    evaluation used to overwrite the accepted point's H_pp / g_p on the device path): Ceres' documented radius schedule holds
+    on the solver's own log, and decisions, radii and costs equal the oracle's iteration by iteration"""
+    import ba_bracket as bb
+    from dvslam_amd import BAProblem
+    P = synth.make_ba_problem(**kw)
+    g = BAProblem(P); o = oracle.OracleBA(P)
+    s = (g.solve if solver == "host_schur" else g.solve_device)(40); s2 = o.solve(40)
+    tr, tr2 = g.trace(), o.trace()
+    nacc, nfail = bb.check_schedule(tr)
+    assert nfail >= 2 and nacc == s.num_successful_steps
+    rej = [i for i in range(len(tr)) if int(tr[i, 1]) in (0, 2)]
+    assert rej and rej[0] < len(tr) - 1, "a failed step must be followed by more iterations"
+    assert (s.termination, s.num_successful_steps, s.num_iterations) == (s2.termination, s2.num_successful_steps, s2.num_iterations)
+    assert (tr[:, 1] == tr2[:, 1]).all(), "same accept / reject / invalid decision at every iteration"
+    assert np.allclose(tr[:, 0], tr2[:, 0], rtol=1e-6, atol=0) and np.allclose(tr[:, 5], tr2[:, 5], rtol=1e-8, atol=0)
+    assert abs(s.final_cost - s2.final_cost) <= 1e-6 * s2.final_cost

@@ -115,3 +115,30 @@ def test_lm_converges_on_the_synthetic_window(oracle):
     assert np.median(np.linalg.norm(r, axis=1)) < 1.6
     s2 = oracle.OracleBA(P).solve(2)                            # iteration limit -> NO_CONVERGENCE (success=false in the reference)
     assert s2.termination == 1 and s2.num_iterations == 2
+
+
+# ---- the LM loop bracketed from outside its own transcription (tests/ba_bracket.py) --------------------------------------
+@pytest.mark.parametrize("name", ["3x60", "5x200", "10x2000"])
+def test_oracle_lm_reaches_the_scipy_optimum(oracle, name):
+    """oracle/ba_oracle.cpp's restatement of ceres::Solve, run to convergence, lands on the optimum an independent
+    scipy.optimize.least_squares(huber) solve found (tools/gen_ba_scipy_golden.py): relative cost <= 1e-6"""
+    import ba_bracket as bb
+    kw, G = bb.scipy_golden(name)
+    o = oracle.OracleBA(synth.make_ba_problem(**kw))
+    s = o.solve(100, 1e-14, 1e-14, 1e-14)
+    assert abs(s.initial_cost - float(G["initial_cost"])) <= 1e-9 * s.initial_cost, "same problem, same Huber cost at the start"
+    assert abs(s.final_cost - float(G["optimum_cost"])) <= 1e-6 * float(G["optimum_cost"])
+    q, t, X = o.parameters()
+    ang, dc, dX, scale = bb.gauge_aligned_errors(q, t, X, G["q"], G["t"], G["X"])
+    assert ang < 2e-4 and dc < 2e-3, (ang, dc, dX, scale)      # poses agree up to the free scale
+
+
+@pytest.mark.parametrize("kw", __import__("ba_bracket").HARD[:2], ids=["5x200 seed 4", "5x200 seed 3"])
+def test_oracle_follows_the_documented_trust_region_schedule(oracle, kw):
+    import ba_bracket as bb
+    o = oracle.OracleBA(synth.make_ba_problem(**kw))
+    s = o.solve(40)
+    tr = o.trace()
+    nacc, nfail = bb.check_schedule(tr)
+    assert nacc == s.num_successful_steps and nfail >= 2, "these windows must exercise rejected / invalid steps"
+    assert len(tr) == s.num_iterations
