@@ -10,6 +10,7 @@
 // scan disjoint, ordered slices of the train set and merge through LDS in slice order (keeps the lowest-index
 // tie-break exact).  <8, 2> is the batch shape, <16, 1> the single-job (latency) shape.
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -121,6 +122,130 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   }
 }
 
+// =============================================================================================================================
+// Matrix-core variant for batches of large jobs.  Hamming distance as an exact integer contraction:
+// with every descriptor bit b encoded as the byte e(b) = +8 / -8,   sum_k e(q_k) e(t_k) = 64 (256 - 2 dist(q, t)),
+// so a 2000 x 256 . 256 x 2000 int8 product on the MFMA pipe (v_mfma_i32_32x32x32_i8, exact int32 accumulation) replaces
+// 16 M (v_xor, v_bcnt) pairs per job on the VALU pipe — which every other kernel of the path saturates while the matrix
+// cores sit idle.  The arg-min with cv::BFMatcher's lowest-index tie-break also comes out of the product: one extra
+// k-step carries, for the train row r, the constant 63 - code(r), code = the position of r among the 64 rows a lane's
+// accumulators hold, times a 1 on the query side; so   acc = 64 (256 - 2 dist) + 63 - code   and ONE signed max over a lane's
+// accumulator registers picks the smallest distance and, among equals, the lowest row.  Rows past the set's count carry
+// -32512 from four more slots of that k-step and can never win.  north_star says "no MFMA: none of this is a dense
+// contraction" — the match is one once the bits are bytes; measured effect in DESIGN.md §4.
+//
+// Expanded set layout (k_expand_desc, per set of strideRows descriptors): tiles of 32 rows x 10 KB =
+//   [8 data k-steps | query-role extra step | train-role extra step] x [half h = 0, 1] x [row & 31] x 16 bytes,
+// i.e. every 1-KB piece is exactly one operand fragment of the 32x32x32 MFMA in lane order (lane = 32 h + (row & 31) holds 16
+// consecutive k) — the layout both operands share, so a piece moves HBM -> LDS by one LDS-DMA wave-instruction and LDS -> VGPR
+// by one ds_read_b128 per lane, with no shuffle on either side.
+// =============================================================================================================================
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int kMtBytes = 10 * 1024;            // one 32-row tile of an expanded set
+constexpr int kChunkTiles = 4;                 // 128 train rows per chunk = the 64 accumulator registers of one lane
+constexpr int kPieces = kChunkTiles * 9;       // 1-KB pieces staged per chunk (8 data steps + the train-role extra step per tile)
+constexpr int kChunkLds = kPieces * 1024;      // 36 KB; two buffers -> 72 KB per workgroup, two workgroups per CU
+
+// position of row r (within its 128-row chunk) in the register order of the lane that holds it: C/D layout of the 32x32 MFMA,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) within a tile; tiles in order
+__host__ __device__ __forceinline__ int mfma_row_code(int r128) {
+  const int r = r128 & 31;
+  return (r128 >> 5) * 16 + (r >> 3) * 4 + (r & 3);
+}
+
+__global__ __launch_bounds__(256) void k_expand_desc(const uint8_t* __restrict__ desc, const int* __restrict__ nArr, int strideRows,
+                                                     const uint8_t* __restrict__ desc0, const int* __restrict__ n0, int8_t* __restrict__ E,
+                                                     size_t setBytes, int mtPad) {
+  const int set = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int piece = t >> 5, r32 = t & 31;
+  const int mt = piece / 20, sh = piece - mt * 20;
+  if (mt >= mtPad) return;
+  const int s = sh >> 1, h = sh & 1;
+  const bool first = set == 0 && desc0 != nullptr;   // set 0 may live elsewhere (a frame sequence's predecessor)
+  const uint8_t* d = first ? desc0 : desc + (ptrdiff_t)set * strideRows * 32;
+  const int n = min(max(first ? *n0 : nArr[set], 0), strideRows);
+  const int row = mt * 32 + r32;
+  const bool valid = row < n;
+  uint4 o = make_uint4(0u, 0u, 0u, 0u);
+  if (s < 8) {
+    if (valid) {
+      const unsigned bits = *reinterpret_cast<const unsigned short*>(d + (size_t)row * 32 + s * 4 + h * 2);
+      auto ex = [](unsigned x4) -> unsigned {  // 4 bits -> 4 bytes of +8 / -8 (0x08 / 0xF8): spread by multiply, no carries
+        return ((((x4 & 15u) * 0x00204081u) & 0x01010101u) * 0xF0u) | 0x08080808u;
+      };
+      o = make_uint4(ex(bits), ex(bits >> 4), ex(bits >> 8), ex(bits >> 12));
+    }
+  } else if (h == 0) {
+    if (s == 8) o = make_uint4(0x40404001u, 0x00000040u, 0u, 0u);                       // query role: 1, then 64 x 4
+    else o = make_uint4((unsigned)(63 - mfma_row_code(row & 127)) | (valid ? 0u : 0x81818100u), valid ? 0u : 0x00000081u, 0u, 0u);
+  }
+  *reinterpret_cast<uint4*>(E + (size_t)set * setBytes + (size_t)mt * kMtBytes + (size_t)sh * 512 + r32 * 16) = o;
+}
+
+// workgroup = 128 queries (one 32-query tile per wavefront, its 9 B fragments resident in registers) x all train rows, streamed
+// in chunks of 128 rows through two LDS buffers by LDS-DMA; job = blockIdx.y.  Query set of job p = set p + qSetOff of Eq,
+// train set = set p of Et (a frame sequence expands [predecessor, frame 0, ...] once and uses it in both roles).
+__global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict__ Eq, size_t qSetBytes, int qSetOff, const int8_t* __restrict__ Et,
+                                                       size_t tSetBytes, const int* __restrict__ nqArr, int qStrideRows,
+                                                       const int* __restrict__ ntArr, int tStrideRows, const int* __restrict__ nt0,
+                                                       int* __restrict__ outIdx, int* __restrict__ outDist) {
+  extern __shared__ __attribute__((aligned(16))) int8_t mlds[];
+  const int pair = blockIdx.y, qt = blockIdx.x;
+  const int nq = min(max(nqArr[pair], 0), qStrideRows);
+  const int nt = min(max(pair == 0 && nt0 ? *nt0 : ntArr[pair], 0), tStrideRows);
+  if (qt * 128 >= nq) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int8_t* eq = Eq + (size_t)(pair + qSetOff) * qSetBytes + (size_t)(qt * 4 + w) * kMtBytes + lane * 16;
+  v4i bq[9];
+#pragma unroll
+  for (int s = 0; s < 9; s++) bq[s] = *reinterpret_cast<const v4i*>(eq + s * 1024);
+  const int8_t* et = Et + (size_t)pair * tSetBytes + lane * 16;
+  const int nchunks = (nt + 127) >> 7;
+  auto stage = [&](int c, int buf) {
+    for (int p = w; p < kPieces; p += 4) {
+      const int mt = p / 9, s = p - mt * 9;
+      const int8_t* src = et + (size_t)(c * kChunkTiles + mt) * kMtBytes + (s < 8 ? s : 9) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(mlds + buf * kChunkLds + p * 1024), 16, 0, 0);
+    }
+  };
+  int bestc = INT_MIN, besti = -1;
+  if (nchunks > 0) stage(0, 0);
+  for (int c = 0; c < nchunks; c++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c have landed ...
+    __syncthreads();                                   // ... and everyone's; everyone has also finished reading the other buffer
+    if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+    const int8_t* buf = mlds + (c & 1) * kChunkLds + lane * 16;
+    int key = INT_MIN;
+#pragma unroll
+    for (int m = 0; m < kChunkTiles; m++) {
+      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 9; s++) {
+        const v4i a = *reinterpret_cast<const v4i*>(buf + (m * 9 + s) * 1024);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) key = max(key, acc[i]);
+    }
+    // key = 64 (256 - 2 dist) + 63 - code: the lane's best row of this chunk (lowest row among equal distances)
+    const int cval = key >> 6, code = 63 - (key & 63);
+    const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + (lane >> 5) * 4 + (code & 3);
+    if (cval > bestc) { bestc = cval; besti = row; }   // later chunks hold higher rows: strict '>' keeps the lowest on ties
+  }
+  // the two lane halves hold interleaved rows of the same query column
+  const int oc = __shfl_xor(bestc, 32), oi = __shfl_xor(besti, 32);
+  if (oc > bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
+  const int qi = qt * 128 + w * 32 + (lane & 31);
+  if (lane < 32 && qi < nq) {
+    outIdx[(size_t)pair * qStrideRows + qi] = nt > 0 ? besti : -1;
+    outDist[(size_t)pair * qStrideRows + qi] = nt > 0 ? (256 - bestc) >> 1 : INT_MAX;
+  }
+}
+
 // threshold variant, pass 1: number of train rows with distance < maxDist per query
 __global__ __launch_bounds__(256) void k_thresh_count(const u64* __restrict__ q, int nq, const u64* __restrict__ t, int nt,
                                                       int maxDist, int* __restrict__ counts) {
@@ -186,6 +311,9 @@ struct dvs_matcher {
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only buffers of the glue entry points (frontend.hip)
   size_t cscratch[4] = {0, 0, 0, 0};
   void* d_zero = nullptr;  // 64 zero bytes: the empty predecessor of dvs_match_hamming_sequence_device
+  void* d_expand[2] = {nullptr, nullptr};  // +8 / -8 byte images of the descriptor sets for the matrix-core kernel (grow-only)
+  size_t cexpand[2] = {0, 0};
+  int use_mfma = 1;        // DVS_MATCH_MFMA=0 keeps every job on the popcount kernel
 };
 
 namespace {
@@ -195,6 +323,32 @@ dvs_status grow(void** p, size_t* cap, size_t need) {
   *p = nullptr; *cap = 0;
   DVS_HIP(hipMalloc(p, need ? need : 1));
   *cap = need;
+  return DVS_OK;
+}
+}  // namespace
+
+namespace {
+// expanded image of `nsets` descriptor sets (set s at desc + s * strideRows * 32 with count nArr[s]; set 0 from desc0 / n0 if given)
+dvs_status expand_sets(dvs_matcher* m, int slot, const uint8_t* desc, const int* nArr, int strideRows, const uint8_t* desc0, const int* n0,
+                       int nsets, size_t* setBytes) {
+  const int mtPad = (strideRows + 127) / 128 * kChunkTiles;
+  *setBytes = (size_t)mtPad * kMtBytes;
+  DVS_TRY(grow(&m->d_expand[slot], &m->cexpand[slot], *setBytes * (size_t)nsets));
+  hipLaunchKernelGGL(k_expand_desc, dim3((mtPad * 640 + 255) / 256, nsets), dim3(256), 0, m->stream, desc, nArr, strideRows, desc0, n0,
+                     (int8_t*)m->d_expand[slot], *setBytes, mtPad);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+dvs_status launch_match_mfma(dvs_matcher* m, const int8_t* Eq, size_t qSetBytes, int qSetOff, const int8_t* Et, size_t tSetBytes, const int* nq,
+                             int qStrideRows, const int* nt, int tStrideRows, const int* nt0, int npairs, int* d_idx, int* d_dist) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_match_mfma, dim3((qStrideRows + 127) / 128, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et, tSetBytes,
+                     nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
+  DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
 }  // namespace
@@ -251,6 +405,7 @@ dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out) {
   hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete m; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   m->stream = m->own_stream;
+  if (const char* e2 = getenv("DVS_MATCH_MFMA")) m->use_mfma = e2[0] != '0';
   *out = m;
   return DVS_OK;
 }
@@ -259,7 +414,7 @@ void dvs_matcher_destroy(dvs_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero};
+  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero, m->d_expand[0], m->d_expand[1]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
@@ -300,6 +455,13 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }
+  if (m->use_mfma && t_stride_rows > 0) {  // many large jobs: the contraction runs on the matrix cores (k_match_mfma)
+    size_t qb = 0, tb = 0;
+    DVS_TRY(expand_sets(m, 0, d_q, d_nq, q_stride_rows, nullptr, nullptr, npairs, &qb));
+    DVS_TRY(expand_sets(m, 1, d_t, d_nt, t_stride_rows, nullptr, nullptr, npairs, &tb));
+    return launch_match_mfma(m, (const int8_t*)m->d_expand[0], qb, 0, (const int8_t*)m->d_expand[1], tb, d_nq, q_stride_rows, d_nt, t_stride_rows,
+                             nullptr, npairs, d_idx, d_dist);
+  }
   constexpr int kSplit = 8, kQPL = 2;
   dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
   hipLaunchKernelGGL((k_match<kSplit, kQPL>), grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0,
@@ -323,6 +485,13 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
       DVS_HIP(hipMemsetAsync(m->d_zero, 0, 64, m->stream));
     }
     d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
+  }
+  if (m->use_mfma && (long long)nframes * stride_rows > 16384) {
+    // sets [predecessor, frame 0 .. nframes - 1] are expanded ONCE and used in both roles: job p = set p + 1 against set p
+    size_t sb = 0;
+    DVS_TRY(expand_sets(m, 0, d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, nframes + 1, &sb));
+    return launch_match_mfma(m, (const int8_t*)m->d_expand[0], sb, 1, (const int8_t*)m->d_expand[0], sb, d_n, stride_rows, d_n - 1, stride_rows, d_prev_n,
+                             nframes, d_idx, d_dist);
   }
   constexpr int kSplit = 8, kQPL = 2;
   dim3 grid((stride_rows + 64 * kQPL - 1) / (64 * kQPL), nframes);

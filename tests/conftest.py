@@ -1,6 +1,12 @@
 import os
 import sys
 import pytest
+# PyTorch wheels bundle a complete ROCm stack (libamdhip64, libhsa-runtime64, librccl ...) under torch/lib with the same SONAMEs as
+# /opt/rocm's.  Whichever copy a process loads first serves everyone, EXCEPT that RCCL dlopens its HSA runtime by path: with
+# libdvslam_hip.so (linked against /opt/rocm) loaded before torch, a second HSA runtime comes up and ncclCommInitRank fails with
+# "no ROCm-capable device".  Tests that use both therefore import torch first, as bench.py does; a C++ host without torch only ever
+# sees /opt/rocm's copy.
+import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dynamic-visual-slam_amd"))

@@ -244,10 +244,9 @@ def test_out_of_image_keypoints_are_dropped_not_faulted(gpu, oracle):
     kps["x"][:4] = [-5.0, 100000.0, 10.0, 639.6]; kps["y"][:4] = [10.0, 10.0, -0.6, 479.6]
     g = FrontendGlue()
     R = np.eye(3); t = np.zeros(3)
-    from dvslam_amd import DvsError
-    with pytest.raises(DvsError):                       # the host entry point checks its keypoints up front
-        g.backproject(kps, depth, 600.0, 600.0, 320.0, 240.0, R, t)
-    w, oi = g.backproject(kps[4:], depth, 600.0, 600.0, 320.0, 240.0, R, t)
-    assert len(oi) == 60
+    w, oi = g.backproject(kps, depth, 600.0, 600.0, 320.0, 240.0, R, t)   # ONE policy on every entry point: dropped
+    assert len(oi) == 60 and list(oi[:2]) == [4, 5]
+    w2, oi2 = g.backproject(kps[4:], depth, 600.0, 600.0, 320.0, 240.0, R, t)
+    assert len(oi2) == 60 and (w == w2).all()
     payload, m = g.publish_keyframe(kps, desc, depth, 600.0, 600.0, 320.0, 240.0, R, t)
     assert m == 60 and list(unpack_keyframe(payload)["landmark_ids"][:2]) == [4, 5]

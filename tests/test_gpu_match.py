@@ -104,3 +104,63 @@ def test_sequence_device(gpu, oracle):
             t = (prev[:nprev[0]] if with_prev else prev[:0]) if p == 0 else D[p - 1, :n[p - 1]]
             i2, d2 = oracle.match(D[p, :n[p]], t)
             assert (idx[p, :n[p]] == i2).all() and (d[p, :n[p]] == d2).all(), (with_prev, p)
+
+
+def _tie_heavy(n, seed, distinct=37):
+    """descriptors drawn from a small pool (+ a few flipped bits): many exact ties between train rows, so the lowest-index rule
+    decides most matches"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pool = rng.integers(0, 256, size=(distinct, 32), dtype=np.uint8)
+    d = pool[rng.integers(0, distinct, size=n)].copy()
+    flip = rng.integers(0, 4, size=n)
+    for i in np.nonzero(flip == 0)[0]:
+        d[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    return d
+
+
+def test_batch_device_matrix_core(gpu, oracle):
+    """large batches run the int8 MFMA kernel (k_match_mfma): ragged counts incl. 0 / 1 / a partial last chunk / the full
+    stride, tie-heavy sets (lowest train index must win), every job against the oracle bit for bit"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    P, S = 10, 2024
+    nq = np.array([2024, 2000, 1, 0, 1999, 129, 128, 127, 2005, 33], np.int32)
+    nt = np.array([2024, 1, 2000, 500, 0, 2005, 128, 129, 257, 1900], np.int32)
+    Q = np.stack([_tie_heavy(S, 300 + p) if p % 2 else synth.make_descriptors(S, 300 + p) for p in range(P)])
+    T = np.stack([_tie_heavy(S, 300 + p + (0 if p % 4 == 1 else 50)) if p % 2 else synth.make_descriptors(S, 400 + p) for p in range(P)])
+    T[0, 1500] = Q[0, 7]; T[0, 1700] = Q[0, 7]; T[2, 1999] = Q[2, 0]
+    dq = DeviceBuffer(Q.nbytes).upload(Q); dt = DeviceBuffer(T.nbytes).upload(T)
+    dnq = DeviceBuffer(P * 4).upload(nq); dnt = DeviceBuffer(P * 4).upload(nt)
+    di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
+    for rep in range(2):   # second call: the expanded images are rebuilt in the same buffers
+        m.match_batch_device(dq.ptr, dnq.ptr, S, dt.ptr, dnt.ptr, S, P, di.ptr, dd.ptr)
+        m.synchronize()
+        idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
+        for p in range(P):
+            i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
+            assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (rep, p)
+
+
+def test_sequence_device_matrix_core(gpu, oracle):
+    """the bench's shape on the MFMA kernel: frames of up to 2024 descriptors, frame p against p - 1 (expanded once, used in
+    both roles), frame 0 against a predecessor elsewhere or against nothing"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    F, S = 9, 2024
+    n = np.array([2005, 2024, 0, 64, 1999, 2000, 1, 1500, 2011], np.int32)
+    D = np.stack([_tie_heavy(S, 700 + p, 101) if p in (4, 5) else synth.make_descriptors(S, 700 + p) for p in range(F)])
+    D[1, 3] = D[0, 9]; D[1, 4] = D[0, 9]; D[0, 2004] = D[0, 9]
+    prev = synth.make_descriptors(S, 799); nprev = np.array([1777], np.int32)
+    dd = DeviceBuffer(D.nbytes).upload(D); dn = DeviceBuffer(F * 4).upload(n)
+    dp = DeviceBuffer(prev.nbytes).upload(prev); dnp = DeviceBuffer(4).upload(nprev)
+    di = DeviceBuffer(F * S * 4); dx = DeviceBuffer(F * S * 4)
+    for with_prev in (True, False):
+        m.match_sequence_device(dd.ptr, dn.ptr, S, F, dp.ptr if with_prev else 0, dnp.ptr if with_prev else 0, di.ptr, dx.ptr)
+        m.synchronize()
+        idx = di.download(np.int32, F * S).reshape(F, S); d = dx.download(np.int32, F * S).reshape(F, S)
+        for p in range(F):
+            t = (prev[:nprev[0]] if with_prev else prev[:0]) if p == 0 else D[p - 1, :n[p - 1]]
+            i2, d2 = oracle.match(D[p, :n[p]], t)
+            assert (idx[p, :n[p]] == i2).all() and (d[p, :n[p]] == d2).all(), (with_prev, p)
