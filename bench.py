@@ -209,7 +209,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--nfeatures", type=int, default=2000)
-    ap.add_argument("--pipelines", type=int, default=1, help="double-buffered batches in flight per GPU")
+    ap.add_argument("--serial-match", dest="match_stream", action="store_false",
+                    help="enqueue the match behind its own batch's extraction on the same stream (default: the match, which runs on the "
+                         "matrix cores, has its own stream and overlaps the next batch's extraction on the vector ALUs)")
     ap.add_argument("--resident-batches", type=int, default=6,
                     help="distinct resident input batches the steps rotate over (6 x 64 x 0.92 MB of level 0 + 6 x 180 MB of pyramids and "
                          "blurred levels per pass: far beyond the 256 MB Infinity Cache)")
@@ -246,34 +248,34 @@ def main():
     # synthetic input, resident in HBM before the timed region: this rank's shard of NB global batches
     d_img, frames_distinct = make_batches(synth, torch, dev, B, NB, rank, rows, cols, not args.single_resident_batch)
 
-    # Two pipelines (extractor + matcher handle, HBM buffers, torch stream each) take alternate steps, so consecutive
-    # batches overlap on the GPU exactly like a double-buffered camera stream would; every step still processes one
-    # full batch of B frames through the whole path, and a step's first match job waits (stream event) for the
-    # descriptors of the previous step's last frame, which the other pipeline produced.
-    NP = max(1, args.pipelines)
-    pipes = []
-    for p in range(NP):
-        # The pipeline overlaps kernels on four streams (main, blur, next-batch pyramid, boundary exchange).  All four are
-        # created by the library, back to back, BEFORE RCCL comes up and none comes from torch's stream pool: HIP maps streams
-        # to hardware queues in creation order, and with the exchange on a torch pool stream or RCCL initialised first the
-        # same job ran anywhere between 48 k and 72 k frames/s depending on GPU_MAX_HW_QUEUES (kernels alone on the GPU took
-        # 1.3-2.5x longer); like this it is 71 k for 4, 6, 8 and 12 queues.
-        orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
-        xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # boundary exchange
-        ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
-        mat = dvslam_amd.BFMatcher(device=local)
-        mat.set_stream(ts.cuda_stream)
-        cap = orb.capacity
-        with torch.cuda.stream(ts):
-            # two output sets used alternately: step i writes set i % 2 and its first match job reads the LAST frame of set
-            # (i - 1) % 2 in place (dvs_match_hamming_sequence_device) — no boundary copy on one GPU
-            bufs = dict(kps=[torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(2)],
-                        desc=[torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)],
-                        n=[torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)],
-                        idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
-                        dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
-        pipes.append(dict(orb=orb, mat=mat, stream=ts, done=torch.cuda.Event(), xstream=xs,
-                          xdone=torch.cuda.Event(), count=0, prev=None, **bufs))
+    # One pipeline per GPU: extractor + matcher handles and their streams.  The match runs on the matrix cores (k_match_mfma)
+    # and extraction on the vector ALUs, so the match of step i gets its OWN stream and runs beside the extraction of step
+    # i + 1 instead of after its own: three output sets rotate (step i writes set i % 3, its match reads sets i % 3 and
+    # (i - 1) % 3, and set i % 3 is not overwritten before step i + 3, by which time match i + 1 — its last reader — is
+    # two steps old; the wait on it is stated anyway).  Every step still runs the whole path on one full batch.
+    # The pipeline overlaps kernels on five streams (main, blur, next-batch pyramid, match, boundary exchange).  All are
+    # created by the library, back to back, BEFORE RCCL comes up and none comes from torch's stream pool: HIP maps streams
+    # to hardware queues in creation order, and with the exchange on a torch pool stream or RCCL initialised first the
+    # same job ran anywhere between 48 k and 72 k frames/s depending on GPU_MAX_HW_QUEUES (kernels alone on the GPU took
+    # 1.3-2.5x longer); like this it is 71 k for 4, 6, 8 and 12 queues.
+    NP = 1
+    NSETS = 3
+    orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
+    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # match
+    xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # boundary exchange
+    ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
+    mat = dvslam_amd.BFMatcher(device=local)
+    mat.set_stream(ms.cuda_stream if args.match_stream else ts.cuda_stream)
+    cap = orb.capacity
+    with torch.cuda.stream(ts):
+        bufs = dict(kps=[torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(NSETS)],
+                    desc=[torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NSETS)],
+                    n=[torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NSETS)],
+                    idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
+                    dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
+    P = dict(orb=orb, mat=mat, stream=ts, mstream=ms if args.match_stream else ts, xstream=xs, xdone=torch.cuda.Event(),
+             ext_done=[torch.cuda.Event() for _ in range(NSETS)], match_done=[torch.cuda.Event() for _ in range(NSETS)], prev=None, **bufs)
+    pipes = [P]
     torch.cuda.synchronize()
     # RCCL comes up AFTER the pipeline's handles and streams exist (see the stream comment above)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torchrun (also with one rank): exercise RCCL
@@ -303,17 +305,16 @@ def main():
 
     def step():
         i = state["i"]; state["i"] += 1
-        P = pipes[i % NP]; Q = pipes[(i - 1) % NP]
-        s = P["count"] % 2; P["count"] += 1
+        s = i % NSETS
         img = d_img[i % NB]; nxt = d_img[(i + 1) % NB]
+        T, M, X = P["stream"], P["mstream"], P["xstream"]
         prev_desc = prev_n = 0
         if i > 0:
-            qd, qn = Q["last"]           # last frame of the previous step (this rank's)
+            qd, qn = P["last"]           # last frame of the previous step (this rank's)
             if collective:
                 # the one exchange step: every rank's last-frame block, this rank needs its predecessor's.  It depends only on
-                # the previous step, so it runs on a side stream beside this step's extraction and is joined before the match
-                X = P["xstream"]
-                X.wait_event(Q["done"])
+                # the previous step's extraction, so it runs on a side stream beside this step's and is joined before the match
+                X.wait_event(P["ext_done"][(i - 1) % NSETS])
                 if comm is not None:
                     prev_desc, prev_n = comm.exchange_boundary(X.cuda_stream, qd.data_ptr(), qn.data_ptr(), cap)
                     P["xdone"].record(X)
@@ -324,29 +325,31 @@ def main():
                     P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
                     prev_desc, prev_n = bd.data_ptr(), bn.data_ptr()
             else:
-                if NP > 1:
-                    P["stream"].wait_event(Q["done"])
                 prev_desc, prev_n = qd.data_ptr(), qn.data_ptr()
-        with torch.cuda.stream(P["stream"]):
-            if args.prefetch and NP == 1:
+        if i >= NSETS and M is not T:
+            T.wait_event(P["match_done"][(i - NSETS + 1) % NSETS])   # the last reader of the set this step overwrites
+        with torch.cuda.stream(T):
+            if args.prefetch:
                 # streaming: the next batch is already resident, so its pyramid is built beside this batch's FAST
                 # (every step still builds exactly one pyramid; the one of step 0 is built in-step)
                 P["orb"].hint_next_batch_device(nxt.data_ptr())
             P["orb"].extract_batch_device(img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
                                           P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
-            if i > 0 and collective:
-                P["stream"].wait_event(P["xdone"])
-            P["mat"].match_sequence_device(P["desc"][s].data_ptr(), P["n"][s].data_ptr(), cap, B, prev_desc, prev_n,
-                                           P["idx"].data_ptr(), P["dist"].data_ptr())
-            if collective or NP > 1:
-                P["done"].record(P["stream"])   # only the exchange stream / another pipeline ever waits for it
+            P["ext_done"][s].record(T)
+        if M is not T:
+            M.wait_event(P["ext_done"][s])
+        if i > 0 and collective:
+            M.wait_event(P["xdone"])
+        P["mat"].match_sequence_device(P["desc"][s].data_ptr(), P["n"][s].data_ptr(), cap, B, prev_desc, prev_n,
+                                       P["idx"].data_ptr(), P["dist"].data_ptr())
+        P["match_done"][s].record(M)
         P["last"] = (P["desc"][s][B - 1], P["n"][s][B - 1:B])
         P["cur"] = s
 
     def sync_all():
-        for P in pipes:
-            P["xstream"].synchronize()
-            P["stream"].synchronize()
+        P["xstream"].synchronize()
+        P["stream"].synchronize()
+        P["mstream"].synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -367,14 +370,12 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel durations: K more steps on ONE pipeline with hipEvents around every stage launch (the events cost ~10 us
     # of stream time per stage, so they stay out of the whole-job timing above)
-    orb = pipes[0]["orb"]
-    P = pipes[0]
     # (a) the same schedule as the timed region (overlap + pyramid prefetch), events on the streams the kernels run on: what a
     #     kernel takes WHILE its neighbours share the machine (rocprofv3's kernel statistics of this command show these)
     orb.enable_stage_timing(True)
     with torch.cuda.stream(P["stream"]):
         for k in range(args.steps):
-            if args.prefetch and NP == 1:
+            if args.prefetch:
                 orb.hint_next_batch_device(d_img[(k + 1) % NB].data_ptr())
             orb.extract_batch_device(d_img[k % NB].data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
                                      P["desc"][P["cur"]].data_ptr(), cap, P["n"][P["cur"]].data_ptr())
@@ -428,7 +429,8 @@ def main():
             "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame "
                                    "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "frames_distinct": frames_distinct,
                        "resident_batches": NB, "keypoints_frame1": int(n_host[min(1, B - 1)]),
-                       "matches_lt50_frame1": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, {NP} batches in flight"},
+                       "matches_lt50_frame1": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, match of batch i on its own stream beside the extraction "
+                                      f"of batch i + 1" if args.match_stream else f"frame-sharded x{world}, boundary-descriptor all_gather, serial match"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},

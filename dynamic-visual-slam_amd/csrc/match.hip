@@ -184,9 +184,11 @@ __global__ __launch_bounds__(256) void k_expand_desc(const uint8_t* __restrict__
   *reinterpret_cast<uint4*>(E + (size_t)set * setBytes + (size_t)mt * kMtBytes + (size_t)sh * 512 + r32 * 16) = o;
 }
 
-// workgroup = 128 queries (one 32-query tile per wavefront, its 9 B fragments resident in registers) x all train rows, streamed
-// in chunks of 128 rows through two LDS buffers by LDS-DMA; job = blockIdx.y.  Query set of job p = set p + qSetOff of Eq,
-// train set = set p of Et (a frame sequence expands [predecessor, frame 0, ...] once and uses it in both roles).
+// workgroup = 128 NQ queries (NQ 32-query tiles per wavefront, their 9 B fragments each resident in registers) x all train rows,
+// streamed in chunks of 128 rows through two LDS buffers by LDS-DMA; job = blockIdx.y.  Query set of job p = set p + qSetOff of
+// Eq, train set = set p of Et (a frame sequence expands [predecessor, frame 0, ...] once and uses it in both roles).
+// NQ = 2: every A fragment read from LDS feeds two MFMAs and a chunk carries twice the matrix work per workgroup barrier.
+template <int NQ>
 __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict__ Eq, size_t qSetBytes, int qSetOff, const int8_t* __restrict__ Et,
                                                        size_t tSetBytes, const int* __restrict__ nqArr, int qStrideRows,
                                                        const int* __restrict__ ntArr, int tStrideRows, const int* __restrict__ nt0,
@@ -195,13 +197,16 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict_
   const int pair = blockIdx.y, qt = blockIdx.x;
   const int nq = min(max(nqArr[pair], 0), qStrideRows);
   const int nt = min(max(pair == 0 && nt0 ? *nt0 : ntArr[pair], 0), tStrideRows);
-  if (qt * 128 >= nq) return;
+  if (qt * 128 * NQ >= nq) return;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int8_t* eq = Eq + (size_t)(pair + qSetOff) * qSetBytes + (size_t)(qt * 4 + w) * kMtBytes + lane * 16;
-  v4i bq[9];
+  // this wave's query tiles: (qt * 4 + w) * NQ + u — consecutive, so the expanded image needs NQ * 4 tiles per workgroup
+  const int8_t* eq = Eq + (size_t)(pair + qSetOff) * qSetBytes + (size_t)((qt * 4 + w) * NQ) * kMtBytes + lane * 16;
+  v4i bq[NQ][9];
 #pragma unroll
-  for (int s = 0; s < 9; s++) bq[s] = *reinterpret_cast<const v4i*>(eq + s * 1024);
+  for (int u = 0; u < NQ; u++)
+#pragma unroll
+    for (int s = 0; s < 9; s++) bq[u][s] = *reinterpret_cast<const v4i*>(eq + (size_t)u * kMtBytes + s * 1024);
   const int8_t* et = Et + (size_t)pair * tSetBytes + lane * 16;
   const int nchunks = (nt + 127) >> 7;
   auto stage = [&](int c, int buf) {
@@ -212,37 +217,53 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict_
                                        (__attribute__((address_space(3))) void*)(mlds + buf * kChunkLds + p * 1024), 16, 0, 0);
     }
   };
-  int bestc = INT_MIN, besti = -1;
+  int bestc[NQ], besti[NQ];
+#pragma unroll
+  for (int u = 0; u < NQ; u++) { bestc[u] = INT_MIN; besti[u] = -1; }
   if (nchunks > 0) stage(0, 0);
   for (int c = 0; c < nchunks; c++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c have landed ...
     __syncthreads();                                   // ... and everyone's; everyone has also finished reading the other buffer
     if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
     const int8_t* buf = mlds + (c & 1) * kChunkLds + lane * 16;
-    int key = INT_MIN;
+    int key[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; u++) key[u] = INT_MIN;
 #pragma unroll
     for (int m = 0; m < kChunkTiles; m++) {
-      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      v16i acc[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < 9; s++) {
         const v4i a = *reinterpret_cast<const v4i*>(buf + (m * 9 + s) * 1024);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], acc[u], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 16; i++) key = max(key, acc[i]);
+      for (int u = 0; u < NQ; u++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) key[u] = max(key[u], acc[u][i]);
     }
-    // key = 64 (256 - 2 dist) + 63 - code: the lane's best row of this chunk (lowest row among equal distances)
-    const int cval = key >> 6, code = 63 - (key & 63);
-    const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + (lane >> 5) * 4 + (code & 3);
-    if (cval > bestc) { bestc = cval; besti = row; }   // later chunks hold higher rows: strict '>' keeps the lowest on ties
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+      // key = 64 (256 - 2 dist) + 63 - code: the lane's best row of this chunk (lowest row among equal distances)
+      const int cval = key[u] >> 6, code = 63 - (key[u] & 63);
+      const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + (lane >> 5) * 4 + (code & 3);
+      if (cval > bestc[u]) { bestc[u] = cval; besti[u] = row; }   // later chunks hold higher rows: strict '>' keeps the lowest on ties
+    }
   }
-  // the two lane halves hold interleaved rows of the same query column
-  const int oc = __shfl_xor(bestc, 32), oi = __shfl_xor(besti, 32);
-  if (oc > bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
-  const int qi = qt * 128 + w * 32 + (lane & 31);
-  if (lane < 32 && qi < nq) {
-    outIdx[(size_t)pair * qStrideRows + qi] = nt > 0 ? besti : -1;
-    outDist[(size_t)pair * qStrideRows + qi] = nt > 0 ? (256 - bestc) >> 1 : INT_MAX;
+#pragma unroll
+  for (int u = 0; u < NQ; u++) {
+    // the two lane halves hold interleaved rows of the same query column
+    const int oc = __shfl_xor(bestc[u], 32), oi = __shfl_xor(besti[u], 32);
+    int bc = bestc[u], bi = besti[u];
+    if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    const int qi = ((qt * 4 + w) * NQ + u) * 32 + (lane & 31);
+    if (lane < 32 && qi < nq) {
+      outIdx[(size_t)pair * qStrideRows + qi] = nt > 0 ? bi : -1;
+      outDist[(size_t)pair * qStrideRows + qi] = nt > 0 ? (256 - bc) >> 1 : INT_MAX;
+    }
   }
 }
 
@@ -343,11 +364,19 @@ dvs_status launch_match_mfma(dvs_matcher* m, const int8_t* Eq, size_t qSetBytes,
                              int qStrideRows, const int* nt, int tStrideRows, const int* nt0, int npairs, int* d_idx, int* d_dist) {
   static bool attr_set = false;
   if (!attr_set) {
-    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
+    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
+    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_match_mfma, dim3((qStrideRows + 127) / 128, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et, tSetBytes,
-                     nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
+  // the expanded query image is padded to a multiple of 4 tiles (128 rows): a 256-query workgroup whose second half lies past
+  // it must not read there -> NQ = 2 only when the padded tile count is a multiple of 8
+  const int mtPadQ = (qStrideRows + 127) / 128 * kChunkTiles;
+  if (qStrideRows > 128 && mtPadQ % 8 == 0)
+    hipLaunchKernelGGL(k_match_mfma<2>, dim3((qStrideRows + 255) / 256, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et,
+                       tSetBytes, nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
+  else
+    hipLaunchKernelGGL(k_match_mfma<1>, dim3((qStrideRows + 127) / 128, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et,
+                       tSetBytes, nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }

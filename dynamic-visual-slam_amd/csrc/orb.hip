@@ -56,6 +56,11 @@ struct dvs_orb {
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
   int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
   int env_fast_tail = 0;
+  int env_fast_v = 2;              // DVS_FAST_V=1: the round-1 FAST kernel
+  int env_desc_split = 0;          // DVS_DESC_SPLIT=1: orientation kernel before the blur joins, descriptor kernel after (round 1's schedule)
+  int env_oct_threads = 0;         // DVS_OCT_T=512: quad-tree workgroup size for every batch size
+  int env_pf_after_fast = 0;       // DVS_PF_AFTER_FAST=1: the next batch's level chain starts when this batch's FAST has finished
+  hipEvent_t ev_fast = nullptr;
   bool pf_valid = false;
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -341,7 +346,8 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
     G.fastRows = maxh;
     const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
-    G.fastWaveLds = (int)align_up(2 * (size_t)G.fastRows * G.fastP + listBytes, 16);
+    G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
+    G.fastWaveLds = (int)align_up((size_t)G.fastTile + (size_t)G.fastRows * G.fastP + listBytes, 16);
   }
   return DVS_OK;
 }
@@ -409,6 +415,9 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   h->rows = rows; h->cols = cols;
   return DVS_OK;
 }
@@ -484,18 +493,22 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // the next batch's pyramid (if announced) runs on the auxiliary stream beside THIS batch's FAST: the chain is latency-bound
   // and FAST is VALU-bound and insensitive to its cache traffic (beside the fetch-bound descriptor stage it doubled that
   // stage's time), and with this batch's own pyramid prefetched the same way FAST needs no per-level gating at all
-  if (next_img0 && h->overlap && G.nlevels >= 2) {
+  auto launch_prefetch = [&](bool after_fast) -> dvs_status {
+    if (!(next_img0 && h->overlap && G.nlevels >= 2)) return DVS_OK;
     if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes));
     ImgSrc nsrc = src;
     nsrc.img0 = next_img0;
-    DVS_HIP(hipEventRecord(h->ev_desc, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
-    DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_desc, 0));
+    hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
+    DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
+    DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
     h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
     DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
     h->timer.end(h->pf_stream);
     DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
     h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
-  }
+    return DVS_OK;
+  };
+  if (!h->env_pf_after_fast) DVS_TRY(launch_prefetch(false));
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
   {
     const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
@@ -504,7 +517,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
       if (wavek) {
         const dim3 grid((c1 - c0 + 3) / 4, nimg);
         const size_t lds = 4 * (size_t)G.fastWaveLds;
-        if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+        if (h->env_fast_v == 1) {  // round-1 kernel, for A/B measurements
+          if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave_r1<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+          else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave_r1<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+          else hipLaunchKernelGGL(k_fast_wave_r1<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+        } else if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
         else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
         else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
       } else {
@@ -530,6 +547,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
       h->timer.end(st);
     }
   }
+  if (h->env_pf_after_fast) DVS_TRY(launch_prefetch(true));
   // blur only depends on the pyramid.  It is forked onto the auxiliary stream AFTER FAST so that the throughput-bound
   // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
   // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
@@ -542,7 +560,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   h->timer.begin(DVS_STAGE_OCTREE, st);
   // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
   // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(G.nlevels * nimg <= 256 ? kOctTMax : kOctT), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(h->env_oct_threads ? h->env_oct_threads : kOctTMax), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
@@ -561,7 +579,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 5. orientation + descriptors + output records.  With the blur on its own stream the orientation half (pyramid + keypoints
   //    only, fetch-bound) runs while the blur (VALU-bound) is still in flight; the descriptor half joins both.
   const dim3 dgrid((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg);
-  if (bst != st) {
+  if (bst != st && h->env_desc_split) {
     h->timer.begin(DVS_STAGE_DESCRIBE, st);
     hipLaunchKernelGGL(k_describe<1>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
@@ -572,6 +590,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
                        capacity, h->d_orient);
     h->timer.end(st);
   } else {
+    if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
     h->timer.begin(DVS_STAGE_DESCRIBE, st);
     hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
@@ -616,6 +635,10 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e2 = getenv("DVS_NO_OVERLAP")) h->overlap = !(e2[0] == '1');
   if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1' ? 1 : 0;
   if (const char* e4 = getenv("DVS_FAST_TAIL")) h->env_fast_tail = atoi(e4);
+  if (const char* e5 = getenv("DVS_FAST_V")) h->env_fast_v = atoi(e5);
+  if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
+  if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
+  if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
   int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
@@ -624,6 +647,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_prefetch, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
     dvs_orb_destroy(h);
     set_error("aux stream / event creation failed");
@@ -653,6 +677,7 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_fast) (void)hipEventDestroy(h->ev_fast);
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
   if (h->ev_prefetch) (void)hipEventDestroy(h->ev_prefetch);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);

@@ -45,6 +45,7 @@ struct Geom {
   int32_t fastP;        // LDS tile pitch of the wave-per-cell FAST kernel (48 / 64 / 80)
   int32_t fastRows;     // max cell height (rows of the LDS tile)
   int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
+  int32_t fastTile;     // bytes of the staged tile, a multiple of 256 (whole LDS-DMA wave-instructions)
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
   int32_t debug;        // diagnostics only (DVS_DEBUG env): bit 0 = skip the quad-tree sort (results invalid)

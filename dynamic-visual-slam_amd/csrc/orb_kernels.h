@@ -60,6 +60,11 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c) {
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {  // (a[23:0] * b[23:0]) >> 32
+  uint32_t d;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ int mul_i24(int a, int b) {
   int d;
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -110,9 +115,19 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
 // the wave slots it then occupies cost the blur more than the quad-tree gains (81 k -> 79 k frames/s; 1024: 75 k)
 constexpr int kOctT = 256;
 constexpr int kOctTMax = 512;  // few frames: nothing competes for the wave slots, the tree alone decides the latency
-// exclusive scan over blockDim.x (multiple of 64, <= kOctTMax) threads; wsum = kOctTMax / 64 + 1 ints
+// Threads a quad-tree workgroup actually uses.  The kernel's duration is its slowest workgroup — level 0 with ~6000 candidates —
+// while the small levels finish early: in batch mode (more workgroups than CUs) the launch has 512 threads and the levels keep
+// 512 / 256 / 128 of them (the other wavefronts exit at once and free their slots for the blur running beside), which
+// shortens the long workgroups without taking more wave slots in total than 256 threads everywhere did.
+__device__ __forceinline__ int oct_threads() {
+  const int bd = (int)blockDim.x;
+  if (gridDim.x * gridDim.y <= 256 || bd < 512) return bd;
+  const int l = (int)blockIdx.x;
+  return l < 2 ? 512 : (l < 5 ? 256 : 128);
+}
+// exclusive scan over oct_threads() (multiple of 64, <= kOctTMax) threads; wsum = kOctTMax / 64 + 1 ints
 __device__ __forceinline__ int block_excl_scan_rt(int v, int* wsum, int& total) {
-  const int nw = (int)blockDim.x >> 6;
+  const int nw = oct_threads() >> 6;
   int incl = wave_incl_scan(v);
   int w = threadIdx.x >> 6;
   __syncthreads();  // wsum may still be read from a previous call
@@ -221,7 +236,10 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
 #pragma unroll
   for (int r = 0; r < kResizeRows; r++) {
     if (y0 + r >= dh) break;
-    const int b0 = (int)(short)(bb[r] & 0xffff), b1 = bb[r] >> 16;
+    // the row's two Q11 weights (0 .. 2048 for INTER_LINEAR), pre-shifted on the scalar unit: with B = b << 12 (< 2^24) and
+    // H = h & ~15 (h >> 4 << 4, < 2^20), v_mul_hi_u32_u24(B, H) = (b * (h >> 4) * 2^16) >> 32 = (b * (h >> 4)) >> 16 — OpenCV's
+    // vertical term in two instructions (and, mul_hi) instead of three (shift, mul, shift)
+    const uint32_t b0 = (uint32_t)(bb[r] & 0xffff) << 12, b1 = (uint32_t)(bb[r] >> 16) << 12;
     // 8-byte window starting at the group's first tap
     const uint32_t lo0 = __builtin_amdgcn_alignbit(w0[r][1], w0[r][0], t.shift), hi0 = __builtin_amdgcn_alignbit(w0[r][2], w0[r][1], t.shift);
     const uint32_t lo1 = __builtin_amdgcn_alignbit(w1[r][1], w1[r][0], t.shift), hi1 = __builtin_amdgcn_alignbit(w1[r][2], w1[r][1], t.shift);
@@ -230,11 +248,10 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     for (int i = 0; i < 4; i++) {
       // (left tap, right tap) as two u16 halves, then a0 * left + a1 * right in one v_dot2_u32_u16
       const us2 al = __builtin_bit_cast(us2, t.alpha[i]);
-      const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), al, 0u, false);
-      const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), al, 0u, false);
-      // |b| <= 2048, h >> 4 <= 32 640: 24-bit multiplier
-      const int v = (((mul_i24(b0, h0 >> 4)) >> 16) + ((mul_i24(b1, h1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 0xff) << (8 * i);
+      const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), al, 0u, false);
+      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), al, 0u, false);
+      const uint32_t v = (mulhi_u24(b0, h0 & ~15u) + mulhi_u24(b1, h1 & ~15u) + 2u) >> 2;   // <= 255: a convex combination of bytes
+      out |= v << (8 * i);
     }
     // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
     *reinterpret_cast<uint32_t*>(d + (uint32_t)((y0 + r) * dp + x4)) = out;
@@ -571,9 +588,11 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// round-1 form of the kernel (register staging, one survivor per lane in the score stage); kept selectable (DVS_FAST_V=1) as the
+// A/B reference of the round-2 instruction diet below
 template <int P>
-__global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
-                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
+__global__ __launch_bounds__(256) void k_fast_wave_r1(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
+                                                      uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int lane = lane_id();
   const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
@@ -728,6 +747,248 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   if (lane == 0) *countOut = min(nout, cap);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round-2 form (the instruction diet).  Same phases and results as k_fast_wave_r1; what changed, with the
+// wave-level VALU instructions per cell of the two (hipcc -S listings):
+//   * staging by LDS-DMA: the tile's LDS image is dword-linear in lane order, so each global_load_lds_dword wave-instruction
+//     lands 64 consecutive dwords with no VGPR round trip (no ds_write, no per-row 64-bit address arithmetic); the score tile
+//     is cleared with 16-byte stores
+//   * score stage on TWO survivors per lane: the two pixels' ring samples are packed into the halves of one register and the
+//     3+3+3 window network runs on v_pk_minimum3_f16 / v_pk_maximum3_f16 (gfx950) — byte values 0..255 are f16 denormals whose
+//     order is their integer order, min / max never round — so one instruction serves two pixels
+//   * compaction: one packed 4-bit mask per lane and a DPP prefix sum instead of four ballots and eight v_mbcnt
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// exact cornerScore<16> of two pixels at once (pixel a in the low halves, b in the high halves).  ta / tb point 3 rows and 3
+// columns BEFORE the pixel, so that every ring offset is a non-negative ds_read immediate (no per-sample address arithmetic).
+template <int P>
+__device__ __forceinline__ i16x2 fast_corner_score2(const u8* ta, const u8* tb) {
+  constexpr int C = 3 * P + 3;
+  const int o[16] = {C + 3 * P,  C + 3 * P + 1,  C + 2 * P + 2,  C + P + 3,  C + 3,  C - P + 3,  C - 2 * P + 2,  C - 3 * P + 1,
+                     C - 3 * P,  C - 3 * P - 1,  C - 2 * P - 2,  C - P - 3,  C - 3,  C + P - 3,  C + 2 * P - 2,  C + 3 * P - 1};
+  f16x2 r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    u16x2 t;
+    t.x = ta[o[k]]; t.y = tb[o[k]];
+    r[k] = __builtin_bit_cast(f16x2, t);
+  }
+  u16x2 vv;
+  vv.x = ta[C]; vv.y = tb[C];
+  auto mn3 = [](f16x2 a, f16x2 b, f16x2 c) -> f16x2 { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); };
+  auto mx3 = [](f16x2 a, f16x2 b, f16x2 c) -> f16x2 { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); };
+  f16x2 lo3[16], hi3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo3[k] = mn3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+    hi3[k] = mx3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+  }
+  f16x2 lo9[16], hi9[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo9[k] = mn3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    hi9[k] = mx3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+  }
+  f16x2 mn[6], mx[6];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    mn[k] = mn3(hi9[3 * k], hi9[3 * k + 1], hi9[3 * k + 2]);
+    mx[k] = mx3(lo9[3 * k], lo9[3 * k + 1], lo9[3 * k + 2]);
+  }
+  mn[5] = hi9[15]; mx[5] = lo9[15];
+  const f16x2 minHi = mn3(mn3(mn[0], mn[1], mn[2]), mn3(mn[3], mn[4], mn[5]), mn[5]);
+  const f16x2 maxLo = mx3(mx3(mx[0], mx[1], mx[2]), mx3(mx[3], mx[4], mx[5]), mx[5]);
+  const i16x2 v = __builtin_bit_cast(i16x2, vv);
+  const i16x2 a = v - __builtin_bit_cast(i16x2, minHi), b = __builtin_bit_cast(i16x2, maxLo) - v;
+  const i16x2 one = {1, 1};
+  return __builtin_elementwise_max(a, b) - one;
+}
+
+// inclusive prefix sum over the wavefront by DPP row shifts / broadcasts (six v_add_u32_dpp)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int lane = lane_id();
+  const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
+  const int ci = cell0 + blockIdx.x * 4 + wvi;                        // every size derived from them stay on the scalar unit
+  if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
+  const int f = blockIdx.y;
+  unsigned char* base = fsm + wvi * g->fastWaveLds;
+  u8* tile = base;
+  u8* score = base + g->fastTile;
+  uint16_t* work = reinterpret_cast<uint16_t*>(base + g->fastTile + g->fastRows * P);
+  const Cell cell = cells[ci];
+  const LevelGeom& L = g->lv[cell.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, cell.level, pitch);
+  const int cw = cell.cw, ch = cell.ch;
+  const int iw = cw - 6, ih = ch - 6;
+  int* countOut = cellCount + (uint64_t)f * g->totalCells + ci;
+  if (iw <= 0 || ih <= 0) { if (lane == 0) *countOut = 0; return; }
+  const int xa = cell.x0 & ~3, ox = cell.x0 - xa;
+  // 1. stage by LDS-DMA.  One wave-instruction lands RP whole tile rows (RP * W consecutive LDS dwords, W = P / 4 dwords per
+  //    row; lanes >= RP * W idle): lane -> (row-in-piece, dword column) is fixed, so a lane's global offset is computed once
+  //    and each further piece only advances the SCALAR base by RP rows — no vector arithmetic in the loop beyond the
+  //    row-bound compare of the last piece.  Columns past the cell's last dword re-read that dword (never outside the image).
+  {
+    constexpr int W = P / 4, RP = 64 / W;
+    const int wpr = (ox + cw + 3) >> 2;  // dwords per row the cell needs (<= W)
+    const int lr = lane / W, lc = lane - lr * W;
+    const uint32_t off = (uint32_t)mad_i24(lr, pitch, min(lc, wpr - 1) * 4);
+    const bool lane_on = lane < RP * W;
+    const u8* rb = img + (uint64_t)cell.y0 * pitch + xa;
+    for (int r0 = 0; r0 < ch; r0 += RP) {
+      if (lane_on && r0 + lr < ch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (uint64_t)r0 * pitch + off),
+                                         (__attribute__((address_space(3))) void*)(tile + r0 * P), 4, 0, 0);
+    }
+    uint4* s128 = reinterpret_cast<uint4*>(score);
+    for (int i = lane; i < (ch * P) >> 4; i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  wave_lds_fence();
+  const int tmin = g->minTh, tini = g->iniTh;
+  const unsigned long long ltmask = (1ull << lane) - 1ull;
+  // 2. rejection test, 4 pixels per lane
+  const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
+  const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
+  const int total = ng * ih;
+  const float invng = 1.0f / (float)ng;
+  // column masks of the first / last dword column of the interior: bit j = pixel j of the group is an interior column
+  const uint32_t cmFirst = (0xFu << (cx0 & 3)) & 0xFu, cmLast = 0xFu >> (3 - ((cx1 - 1) & 3));
+  int nwork = 0;
+  const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
+  for (int i0 = 0; i0 < total; i0 += 64) {
+    const int idx = i0 + lane;
+    const bool valid = idx < total;
+    const int row = valid ? (int)(((float)idx + 0.5f) * invng) : 0;
+    const int gi = valid ? mad_i24(row, -ng, idx) : 0;  // idx - row * ng; 24-bit forms: v_mul_lo_u32 / v_mad_u64_u32 run at 1/4 rate
+    const int y = row + 3;
+    const int wcol = g0 + gi;  // word column
+    const uint32_t* rp = t32 + mad_i24(y, P / 4, wcol);
+    const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
+    const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
+    const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
+    const uint32_t Lp2 = rp[2 * (P / 4) - 1], Op2 = rp[2 * (P / 4)], Rp2 = rp[2 * (P / 4) + 1];
+    const uint32_t s4 = __builtin_amdgcn_alignbyte(R0, O0, 3);    // ring 4  ( 3, 0)
+    const uint32_t s12 = __builtin_amdgcn_alignbyte(O0, L0, 1);   // ring 12 (-3, 0)
+    const uint32_t s2 = __builtin_amdgcn_alignbyte(Rp2, Op2, 2);  // ring 2  ( 2, 2)
+    const uint32_t s14 = __builtin_amdgcn_alignbyte(Op2, Lp2, 2); // ring 14 (-2, 2)
+    const uint32_t s6 = __builtin_amdgcn_alignbyte(Rm2, Om2, 2);  // ring 6  ( 2,-2)
+    const uint32_t s10 = __builtin_amdgcn_alignbyte(Om2, Lm2, 2); // ring 10 (-2,-2)
+    // packed 16-bit evaluation, two pixels per instruction: with r_k the raw ring samples,
+    //   all four opposite pairs hold a darker sample   <=>  max_pairs(min(r_k, r_k+8)) < v - t
+    //   all four opposite pairs hold a brighter sample <=>  min_pairs(max(r_k, r_k+8)) > v + t
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    auto lo2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); };
+    auto hi2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); };
+    const s16x2 T2 = {(short)tmin, (short)tmin};
+    uint32_t sgn[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      auto un = [&](uint32_t w) -> s16x2 { return hh ? hi2(w) : lo2(w); };
+      const s16x2 v2 = un(O0);
+      const s16x2 r0 = un(Op3), r8 = un(Om3), r4 = un(s4), r12 = un(s12), r2 = un(s2), r10 = un(s10), r6 = un(s6), r14 = un(s14);
+      const s16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
+                                                 __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
+      const s16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
+                                                 __builtin_elementwise_min(__builtin_elementwise_max(r2, r10), __builtin_elementwise_max(r6, r14)));
+      const s16x2 e1 = (mn + T2) - v2;   // < 0  <=>  mn < v - t
+      const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
+      sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
+    }
+    // sign bits 15 / 31 of the two halves -> one 4-bit mask (bit j = pixel j passes), gated by the interior-column mask
+    uint32_t m4 = ((sgn[0] >> 15) & 0x00010001u) | ((sgn[1] >> 13) & 0x00040004u);  // bits 0, 16 | 2, 18
+    m4 = (m4 | (m4 >> 15)) & 0xFu;
+    uint32_t cm = valid ? 0xFu : 0u;
+    cm &= gi == 0 ? cmFirst : 0xFu;
+    cm &= gi == ng - 1 ? cmLast : 0xFu;
+    m4 &= cm;
+    const int cnt = __popc(m4);
+    const int incl = wave_incl_scan_dpp(cnt);
+    int pos = nwork + incl - cnt;
+    // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left of them: the score stage then addresses every
+    // ring sample with a non-negative immediate
+    const int cbase = mad_i24(row, P, wcol * 4 - 3);   // (y - 3) * P + x - 3
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (m4 & (1u << j)) work[pos++] = (uint16_t)(cbase + j);
+    nwork += __builtin_amdgcn_readlane(incl, 63);
+  }
+  wave_lds_fence();
+  // 3. exact score for the survivors, two per lane (2 lane, 2 lane + 1); corners (score >= minTh) are re-compacted in place, row-major
+  int ncorner = 0;
+  const uint32_t* work32 = reinterpret_cast<const uint32_t*>(work);
+  for (int e0 = 0; e0 < nwork; e0 += 128) {
+    const int ea = e0 + 2 * lane;
+    const bool va = ea < nwork, vb = ea + 1 < nwork;
+    const uint32_t cc = va ? work32[(e0 >> 1) + lane] : 0u;
+    const int ca = va ? (int)(cc & 0xFFFFu) : 0, cb = vb ? (int)(cc >> 16) : 0;   // idle halves read a harmless in-tile pixel
+    const i16x2 sc2 = fast_corner_score2<P>(tile + ca, tile + cb);
+    const int sa = sc2.x, sb = sc2.y;
+    const bool isa = va && sa >= tmin, isb = vb && sb >= tmin;
+    u8* scoreC = score + (3 * P + 3);
+    if (isa) scoreC[ca] = (u8)sa;
+    if (isb) scoreC[cb] = (u8)sb;
+    const unsigned long long ba = __ballot(isa), bb = __ballot(isb);
+    wave_lds_fence();
+    const int rank = ncorner + __popcll(ba & ltmask) + __popcll(bb & ltmask);
+    if (isa) work[rank] = (uint16_t)(ca + (3 * P + 3));   // from here on the list holds the pixels' own offsets
+    if (isb) work[rank + (isa ? 1 : 0)] = (uint16_t)(cb + (3 * P + 3));
+    ncorner += __popcll(ba) + __popcll(bb);
+  }
+  wave_lds_fence();
+  // 4. NMS on the corner list: bit 14 = strict 3x3 maximum, bit 15 = ... and score >= iniTh
+  bool any20 = false;
+  for (int e0 = 0; e0 < ncorner; e0 += 64) {
+    const int e = e0 + lane;
+    bool hi = false;
+    if (e < ncorner) {
+      const int c = work[e];
+      const int sc = score[c];
+      const bool ismax = sc > score[c - 1] && sc > score[c + 1] && sc > score[c - P - 1] && sc > score[c - P] && sc > score[c - P + 1] &&
+                         sc > score[c + P - 1] && sc > score[c + P] && sc > score[c + P + 1];
+      hi = ismax && sc >= tini;
+      work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0) | (hi ? 0x8000 : 0));
+    }
+    any20 = any20 || (__ballot(hi) != 0ull);
+  }
+  wave_lds_fence();
+  // 5. ordered emission
+  uint32_t* out = cand + (uint64_t)f * g->candPerFrame + L.candOff + (uint64_t)cell.slot * L.cellCap;
+  const int cap = L.cellCap;
+  const int selbit = any20 ? 0x8000 : 0x4000;
+  int nout = 0;
+  for (int e0 = 0; e0 < ncorner; e0 += 64) {
+    const int e = e0 + lane;
+    const int w = e < ncorner ? work[e] : 0;
+    const bool sel = (w & selbit) != 0;
+    const unsigned long long b = __ballot(sel);
+    if (sel) {
+      const int c = w & 0x3fff;
+      const int yy = c / P, xx = c - yy * P - ox;  // sub-image coordinates
+      const int rank = nout + __popcll(b & ltmask);
+      if (rank < cap) out[rank] = pack_pt(xx + cell.j * L.wCell, yy + cell.i * L.hCell, score[c]);
+    }
+    nout += __popcll(b);
+  }
+  if (lane == 0) *countOut = min(nout, cap);
+}
+
 // =============================================================================================
 // quad-tree distribution (DistributeOctTree).  One workgroup per (level, frame).  The reference's
 // std::list is kept as an ARRAY IN LIST ORDER that is rebuilt by prefix sums after every sweep:
@@ -738,7 +999,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
 // Points never move: each keeps the list position of its node (nodeOf); a node's winner is the max
 // response with the lowest candidate index (:757-776), resolved with one atomicMax per point.
 // =============================================================================================
-#define OCT_T ((int)blockDim.x)  /* threads of a quad-tree workgroup: 256 beside the blur, 512 for few frames (see kOctT) */
+#define OCT_T (oct_threads())  /* threads of a quad-tree workgroup that take part (see oct_threads) */
 struct QNode { int16_t ulx, uly, brx, bry; int32_t cnt; int32_t pt; };
 
 __device__ __forceinline__ int qt_quadrant(const QNode& nd, int x, int y) {
@@ -978,6 +1239,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   __shared__ SortShared s_sort;
   const int tid = threadIdx.x;
   const int level = blockIdx.x, f = blockIdx.y;
+  if (tid >= OCT_T) return;  // wavefronts this level does not use leave before the first barrier
   const LevelGeom& L = g->lv[level];
 
   QtShared sh;
