@@ -209,9 +209,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--nfeatures", type=int, default=2000)
-    ap.add_argument("--serial-match", dest="match_stream", action="store_false",
-                    help="enqueue the match behind its own batch's extraction on the same stream (default: the match, which runs on the "
-                         "matrix cores, has its own stream and overlaps the next batch's extraction on the vector ALUs)")
+    ap.add_argument("--match-stream", dest="match_stream", action="store_true",
+                    help="give the match its own stream so that it can overlap the next batch's extraction (default: enqueued behind its "
+                         "own batch's extraction on the same stream; measured faster, DESIGN.md section 5)")
     ap.add_argument("--resident-batches", type=int, default=6,
                     help="distinct resident input batches the steps rotate over (6 x 64 x 0.92 MB of level 0 + 6 x 180 MB of pyramids and "
                          "blurred levels per pass: far beyond the 256 MB Infinity Cache)")
@@ -261,11 +261,13 @@ def main():
     NP = 1
     NSETS = 3
     orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
-    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # match
-    xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)   # boundary exchange
+    # streams are created only when used: every HIP stream is a hardware queue, and one idle queue too many cost 0.2 ms per step
+    # (measured: an unused fourth stream in the extractor handle, 0.74 -> 0.93 ms)
+    need_x = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ) or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
     ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
-    mat = dvslam_amd.BFMatcher(device=local)
-    mat.set_stream(ms.cuda_stream if args.match_stream else ts.cuda_stream)
+    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if args.match_stream else ts   # match
+    xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if need_x else ts              # boundary exchange
+    mat = dvslam_amd.BFMatcher(device=local, stream=ms.cuda_stream)
     cap = orb.capacity
     with torch.cuda.stream(ts):
         bufs = dict(kps=[torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(NSETS)],
@@ -273,7 +275,7 @@ def main():
                     n=[torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NSETS)],
                     idx=torch.empty((B, cap), dtype=torch.int32, device=dev),
                     dist=torch.empty((B, cap), dtype=torch.int32, device=dev))
-    P = dict(orb=orb, mat=mat, stream=ts, mstream=ms if args.match_stream else ts, xstream=xs, xdone=torch.cuda.Event(),
+    P = dict(orb=orb, mat=mat, stream=ts, mstream=ms, xstream=xs, xdone=torch.cuda.Event(),
              ext_done=[torch.cuda.Event() for _ in range(NSETS)], match_done=[torch.cuda.Event() for _ in range(NSETS)], prev=None, **bufs)
     pipes = [P]
     torch.cuda.synchronize()

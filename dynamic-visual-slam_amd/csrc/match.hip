@@ -439,6 +439,19 @@ dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out) {
   return DVS_OK;
 }
 
+dvs_status dvs_matcher_create_on_stream(int32_t device, void* hip_stream, dvs_matcher** out) {
+  DVS_ARG(out);
+  *out = nullptr;
+  DVS_TRY(check_device(device));
+  dvs_matcher* m = new (std::nothrow) dvs_matcher();
+  if (!m) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  m->device = device;
+  m->stream = (hipStream_t)hip_stream;  // no stream of its own: every HIP stream is a hardware queue
+  if (const char* e2 = getenv("DVS_MATCH_MFMA")) m->use_mfma = e2[0] != '0';
+  *out = m;
+  return DVS_OK;
+}
+
 void dvs_matcher_destroy(dvs_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
@@ -460,6 +473,7 @@ dvs_status dvs_matcher_use_own_stream(dvs_matcher* m) {
   DVS_ARG(m);
   DVS_HIP(hipSetDevice(m->device));
   DVS_HIP(hipStreamSynchronize(m->stream));
+  if (!m->own_stream) DVS_HIP(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   m->stream = m->own_stream;
   return DVS_OK;
 }

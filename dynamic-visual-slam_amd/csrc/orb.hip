@@ -61,6 +61,17 @@ struct dvs_orb {
   int env_oct_threads = 0;         // DVS_OCT_T=512: quad-tree workgroup size for every batch size
   int env_pf_after_fast = 0;       // DVS_PF_AFTER_FAST=1: the next batch's level chain starts when this batch's FAST has finished
   hipEvent_t ev_fast = nullptr;
+  // FAST look-ahead (DVS_LOOKAHEAD, default on): with the next batch announced, not only its pyramid but also its FAST runs
+  // ahead — on fa_stream, into the OTHER candidate buffer set — beside THIS batch's quad-tree / blur / descriptor kernels and
+  // the caller's match (latency-, fetch- and MFMA-bound, while FAST is VALU-bound).  One FAST at a time: the streams order it.
+  hipStream_t fa_stream = nullptr;
+  hipEvent_t ev_front = nullptr, ev_back[2] = {nullptr, nullptr};
+  int env_lookahead = 0;           // measured slower (0.767 vs 0.733 ms per step): off unless DVS_LOOKAHEAD=1
+  int cset = 0;                    // candidate buffer set of the batch being extracted
+  bool la_valid = false;           // FAST of the announced batch is (being) computed into set 1 - cset
+  uint32_t* d_cand2[2] = {nullptr, nullptr};
+  int* d_cellcount2[2] = {nullptr, nullptr};
+  unsigned back_calls = 0;
   bool pf_valid = false;
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -82,6 +93,9 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
+  if (h->d_cand2[1]) (void)hipFree(h->d_cand2[1]);
+  if (h->d_cellcount2[1]) (void)hipFree(h->d_cellcount2[1]);
+  h->d_cand2[0] = h->d_cand2[1] = nullptr; h->d_cellcount2[0] = h->d_cellcount2[1] = nullptr; h->la_valid = false;
   void* ptrs[] = {h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
                   h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
@@ -364,6 +378,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
+  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
   free_workspace(h);
   Geom G;
   std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
@@ -385,9 +400,11 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
   DVS_HIP(hipMalloc((void**)&h->d_blur, B * G.frameBytes));
   DVS_HIP(hipMalloc((void**)&h->d_cand, B * G.candPerFrame * 4));
+  h->d_cand2[0] = h->d_cand; h->d_cand2[1] = nullptr; h->cset = 0; h->la_valid = false;
   DVS_HIP(hipMalloc((void**)&h->d_pts, B * G.ptsPerFrame * 4));
   DVS_HIP(hipMalloc((void**)&h->d_nodeof, B * G.ptsPerFrame * 4));
   DVS_HIP(hipMalloc((void**)&h->d_cellcount, B * G.totalCells * 4));
+  h->d_cellcount2[0] = h->d_cellcount; h->d_cellcount2[1] = nullptr;
   DVS_HIP(hipMalloc((void**)&h->d_celloff, B * G.totalCells * 4));
   DVS_HIP(hipMalloc((void**)&h->d_candtotal, B * G.nlevels * 4));
   DVS_HIP(hipMalloc((void**)&h->d_lvlcount, B * G.nlevels * 4));
@@ -454,10 +471,17 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   const bool prefetched = h->pf_valid && h->overlap && h->pf_img == src.img0 && h->pf_step == src.step0 &&
                           h->pf_fstride == src.fstride0 && h->pf_nimg == nimg;
   h->pf_valid = false;
+  const bool la_hit = prefetched && h->la_valid;   // ... and so is its FAST, in the other candidate set
+  h->la_valid = false;
   if (prefetched) {
     std::swap(h->d_pyr, h->d_pyr_alt);
     DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
   }
+  if (la_hit) {
+    h->cset ^= 1;
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_front, 0));
+  }
+  h->d_cand = h->d_cand2[h->cset]; h->d_cellcount = h->d_cellcount2[h->cset];
   src.pyr = h->d_pyr;
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
   //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
@@ -493,6 +517,29 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // the next batch's pyramid (if announced) runs on the auxiliary stream beside THIS batch's FAST: the chain is latency-bound
   // and FAST is VALU-bound and insensitive to its cache traffic (beside the fetch-bound descriptor stage it doubled that
   // stage's time), and with this batch's own pyramid prefetched the same way FAST needs no per-level gating at all
+  // FAST launcher: cells [c0, c1) of `isrc` on stream `fs` into candidate set `cs`
+  const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
+  auto launch_fast = [&](const ImgSrc& isrc, hipStream_t fs, int cs, int c0, int c1) {
+    if (c1 <= c0) return;
+    uint32_t* cand = h->d_cand2[cs];
+    int* ccnt = h->d_cellcount2[cs];
+    if (wavek) {
+      const dim3 grid((c1 - c0 + 3) / 4, nimg);
+      const size_t lds = 4 * (size_t)G.fastWaveLds;
+      if (h->env_fast_v == 1) {  // round-1 kernel, for A/B measurements
+        if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave_r1<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+        else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave_r1<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+        else hipLaunchKernelGGL(k_fast_wave_r1<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+      } else if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+      else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+      else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
+    } else {
+      hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0);
+    }
+  };
+  // the next batch's front half (if announced): its level chain on pf_stream and — with look-ahead — its FAST on fa_stream into
+  // the other candidate set.  Both overwrite what the PREVIOUS batch's back half read (the other pyramid buffer, the other
+  // candidate set): gated on that call's last kernel (ev_back of the previous call; it precedes this point of `st` anyway).
   auto launch_prefetch = [&](bool after_fast) -> dvs_status {
     if (!(next_img0 && h->overlap && G.nlevels >= 2)) return DVS_OK;
     if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes));
@@ -501,33 +548,37 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
     DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
+    const bool la = h->env_lookahead && h->fa_stream && !after_fast;
+    const int ns = h->cset ^ 1;
+    if (la) {
+      if (!h->d_cand2[1]) {
+        DVS_HIP(hipMalloc((void**)&h->d_cand2[1], (size_t)h->max_batch * G.candPerFrame * 4));
+        DVS_HIP(hipMalloc((void**)&h->d_cellcount2[1], (size_t)h->max_batch * G.totalCells * 4));
+      }
+      nsrc.pyr = h->d_pyr_alt;
+      DVS_HIP(hipStreamWaitEvent(h->fa_stream, gate, 0));
+      h->timer.begin(DVS_STAGE_FAST, h->fa_stream);
+      launch_fast(nsrc, h->fa_stream, ns, 0, G.lv[0].nCells);   // level 0 needs no pyramid
+      h->timer.end(h->fa_stream);
+    }
     h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
     DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
     h->timer.end(h->pf_stream);
     DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
+    if (la) {
+      DVS_HIP(hipStreamWaitEvent(h->fa_stream, h->ev_prefetch, 0));
+      h->timer.begin(DVS_STAGE_FAST, h->fa_stream, false);
+      launch_fast(nsrc, h->fa_stream, ns, G.lv[0].nCells, G.totalCells);
+      h->timer.end(h->fa_stream);
+      DVS_HIP(hipEventRecord(h->ev_front, h->fa_stream));
+      h->la_valid = true;
+    }
     h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
     return DVS_OK;
   };
   if (!h->env_pf_after_fast) DVS_TRY(launch_prefetch(false));
-  // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap)
-  {
-    const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
-    auto launch_fast = [&](int c0, int c1) {
-      if (c1 <= c0) return;
-      if (wavek) {
-        const dim3 grid((c1 - c0 + 3) / 4, nimg);
-        const size_t lds = 4 * (size_t)G.fastWaveLds;
-        if (h->env_fast_v == 1) {  // round-1 kernel, for A/B measurements
-          if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave_r1<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-          else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave_r1<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-          else hipLaunchKernelGGL(k_fast_wave_r1<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-        } else if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-        else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-        else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-      } else {
-        hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, st, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0);
-      }
-    };
+  // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap); nothing to do when it ran ahead
+  if (!la_hit) {
     if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
       int tail = G.nlevels;  // first level of the merged tail: levels whose cells are < 1/16 of all cells each
       while (tail > 2 && G.lv[tail - 1].nCells * 16 < G.totalCells) tail--;
@@ -538,12 +589,12 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
         const int lastl = merged ? G.nlevels - 1 : l;
         if (lastl > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[lastl], 0));
         h->timer.begin(DVS_STAGE_FAST, st, l == 0);
-        launch_fast(G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
+        launch_fast(src, st, h->cset, G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
         h->timer.end(st);
       }
     } else {
       h->timer.begin(DVS_STAGE_FAST, st);
-      launch_fast(0, G.totalCells);
+      launch_fast(src, st, h->cset, 0, G.totalCells);
       h->timer.end(st);
     }
   }
@@ -639,10 +690,15 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
   if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
   if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
+  if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
   int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      (h->env_lookahead && hipStreamCreateWithPriority(&h->fa_stream, hipStreamNonBlocking, getenv("DVS_FA_PRIO") ? (atoi(getenv("DVS_FA_PRIO")) > 0 ? prio_hi : (atoi(getenv("DVS_FA_PRIO")) < 0 ? prio_lo : 0)) : prio_lo) != hipSuccess) ||
+      hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
@@ -670,10 +726,14 @@ void dvs_orb_destroy(dvs_orb* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
   if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
+  if (h->fa_stream) (void)hipStreamSynchronize(h->fa_stream);
   h->timer.resolve();
   free_workspace(h);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
+  if (h->fa_stream) (void)hipStreamDestroy(h->fa_stream);
+  if (h->ev_front) (void)hipEventDestroy(h->ev_front);
+  for (hipEvent_t e : h->ev_back) if (e) (void)hipEventDestroy(e);
   if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -700,6 +760,8 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   DVS_HIP(hipStreamSynchronize(h->aux_stream));
   DVS_HIP(hipStreamSynchronize(h->pf_stream));
+  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
+  h->la_valid = false; h->pf_valid = false;
   h->overlap = on != 0;
   return DVS_OK;
 }
@@ -717,6 +779,7 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
+  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));  // ... and so may its FAST
   return DVS_OK;
 }
 

@@ -84,6 +84,7 @@ def lib():
     L.dvs_orb_enable_stage_timing.argtypes = [vp, i32]
     L.dvs_orb_get_stage_times.argtypes = [vp, vp, vp, i32]
     L.dvs_matcher_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_matcher_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
     L.dvs_match_hamming_sequence_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.dvs_matcher_destroy.argtypes = [vp]; L.dvs_matcher_destroy.restype = None
     L.dvs_matcher_set_stream.argtypes = [vp, vp]

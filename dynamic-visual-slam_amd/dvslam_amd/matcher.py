@@ -8,10 +8,14 @@ class BFMatcher:
     (frontend.cpp:220,614,1123; backend.cpp:222,1072).  match(query, train) returns one
     (queryIdx=i, trainIdx, distance) per query row as two int32 arrays (trainIdx, distance)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: raw hipStream_t (int) the matcher enqueues on from the start; None = a stream of its own"""
         self._L = lib()
         h = C.c_void_p()
-        check(self._L.dvs_matcher_create(device, C.byref(h)))
+        if stream is None:
+            check(self._L.dvs_matcher_create(device, C.byref(h)))
+        else:
+            check(self._L.dvs_matcher_create_on_stream(device, stream, C.byref(h)))
         self._h = h
 
     def close(self):

@@ -137,6 +137,9 @@ dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32
 
 typedef struct dvs_matcher dvs_matcher;
 dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out);
+/* the same on a caller-owned hipStream_t from the start (NULL = the legacy default stream): the handle then never creates a
+ * stream of its own.  Every HIP stream is a hardware queue; idle ones are not free ("Streams and hardware queues") */
+dvs_status dvs_matcher_create_on_stream(int32_t device, void* hip_stream, dvs_matcher** out);
 void dvs_matcher_destroy(dvs_matcher* m);
 dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* hip_stream);
 dvs_status dvs_matcher_use_own_stream(dvs_matcher* m);

@@ -26,7 +26,19 @@ __global__ void k(unsigned* out, int iters) {
     else if (OP == 12) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(r) : "v"(b));                  \
     else if (OP == 13) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r) : "v"(b));               \
     else if (OP == 14) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(r) : "v"(b));                   \
-    else if (OP == 15) asm volatile("v_max_i16_e32 %0, %0, %1" : "+v"(r) : "v"(b));
+    else if (OP == 15) asm volatile("v_max_i16_e32 %0, %0, %1" : "+v"(r) : "v"(b));                 \
+    else if (OP == 16) asm volatile("v_min_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_1" : "+v"(r) : "v"(b)); \
+    else if (OP == 17) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(r) : "v"(b));                 \
+    else if (OP == 18) asm volatile("v_min_u16_e32 %0, %0, %1" : "+v"(r) : "v"(b));                 \
+    else if (OP == 19) asm volatile("v_sub_u16_e32 %0, %0, %1" : "+v"(r) : "v"(b));                 \
+    else if (OP == 20) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(r) : "v"(b));                  \
+    else if (OP == 21) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %1" : "+v"(r) : "v"(b));         \
+    else if (OP == 22) asm volatile("v_lshrrev_b32_e32 %0, 1, %0" : "+v"(r));                       \
+    else if (OP == 23) asm volatile("v_min_u16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_1" : "+v"(r) : "v"(b)); \
+    else if (OP == 24) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r) : "v"(b) : );    \
+    else if (OP == 25) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r)); \
+    else if (OP == 26) asm volatile("v_sub_u32_e32 %0, %0, %1" : "+v"(r) : "v"(b));                 \
+    else if (OP == 27) asm volatile("v_or_b32_e32 %0, %0, %1" : "+v"(r) : "v"(b));
     STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
     STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
   }
@@ -61,5 +73,8 @@ int main() {
   run<5>("v_min3_u32", d); run<6>("v_mad_u32_u24", d); run<7>("v_mul_lo_u32", d); run<8>("v_alignbyte_b32", d);
   run<9>("v_xor_b32_e32", d); run<10>("v_max_i32_e32", d); run<11>("v_lshlrev_b32_e32", d); run<12>("v_xor_b32_e64", d);
   run<13>("v_lshl_or_b32", d); run<14>("v_pk_add_u16", d); run<15>("v_max_i16_e32", d);
+  run<16>("v_min_u16_sdwa(b,w1)", d); run<17>("v_and_b32_e32", d); run<18>("v_min_u16_e32", d); run<19>("v_sub_u16_e32", d);
+  run<20>("v_pk_min_i16", d); run<21>("v_pk_minimum3_f16", d); run<22>("v_lshrrev_b32", d); run<23>("v_min_u16_sdwa(pad)", d);
+  run<24>("v_cndmask_b32", d); run<25>("v_add_u32_dpp", d); run<26>("v_sub_u32", d); run<27>("v_or_b32", d);
   return 0;
 }
