@@ -252,13 +252,35 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
     if (l >= L) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
     if (!P.lm_fixed[l]) {
-      for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
-        const int p = lmObs[e];
-        const double* j = Jl + 6 * (size_t)p;
-        const double r0 = res[2 * p], r1 = res[2 * p + 1];
+      auto acc = [&](const double* j, double r0, double r1) {
         h[0] += j[0] * j[0] + j[3] * j[3]; h[1] += j[0] * j[1] + j[3] * j[4]; h[2] += j[0] * j[2] + j[3] * j[5];
         h[3] += j[1] * j[1] + j[4] * j[4]; h[4] += j[1] * j[2] + j[4] * j[5]; h[5] += j[2] * j[2] + j[5] * j[5];
         gl[0] += j[0] * r0 + j[3] * r1; gl[1] += j[1] * r0 + j[4] * r1; gl[2] += j[2] * r0 + j[5] * r1;
+      };
+      // a landmark's observations sit in K different cameras' blocks: every record is its own L2 round trip.  Four records
+      // (index, then 8 doubles each) are requested together instead of one after the other; the sums keep their order.
+      int e = lmStart[l];
+      const int e1 = lmStart[l + 1];
+      for (; e + 4 <= e1; e += 4) {
+        int pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pp[u] = lmObs[e + u];
+        double jj[4][6], rr[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) jj[u][i] = Jl[6 * (size_t)pp[u] + i];
+          rr[u][0] = res[2 * (size_t)pp[u]]; rr[u][1] = res[2 * (size_t)pp[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc(jj[u], rr[u][0], rr[u][1]);
+      }
+      for (; e < e1; e++) {
+        const int p = lmObs[e];
+        double j6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) j6[i] = Jl[6 * (size_t)p + i];
+        acc(j6, res[2 * (size_t)p], res[2 * (size_t)p + 1]);
       }
     }
     double* H = Hll + 9 * (size_t)l;

@@ -1,0 +1,693 @@
+// ransac.hip — the frontend's two robust-estimation stages as BATCHED HYPOTHESIS kernels:
+//   dvs_find_fundamental_ransac   cv::findFundamentalMat(p1, p2, mask, FM_RANSAC, 2.0, 0.99)     frontend.cpp:635, 1146-1147
+//   dvs_solve_pnp_ransac          cv::solvePnPRansac(obj, img, K, dist, rvec, tvec, false, 100, 4.0, 0.99, inliers)
+//                                                                                                frontend.cpp:911-921
+// OpenCV runs these as sequential sample -> fit -> count loops on one CPU thread.  Here ALL hypotheses of a call are fitted
+// at once (one thread each), scored at once (one workgroup per hypothesis over all correspondences), and a single thread then
+// replays the sequential loop over the counts — RANSACUpdateNumIters's adaptive stopping rule included — so the result is what
+// the sequential loop with the same samples would return.
+//
+// What can NOT be reproduced is OpenCV's sample sequence (cv::RNG state threaded through the whole process) and with it the
+// bit pattern of the result; the reference only consumes the inlier SET (frontend.cpp:640-644, 1149-1153) and the refined pose.
+// So the sampler is our own, stated here and in DESIGN.md: sample j of hypothesis h draws r = splitmix64(seed + 0x9E3779B97F4A7C15
+// * (h * 16 + j + 1)) mod (n - j) and takes the r-th index not drawn before (ascending), i.e. a uniform draw without
+// replacement; parity is a tolerance on the inlier set and the pose (tests/test_gpu_ransac.py), not bit equality.
+// Minimal solvers: normalised 8-point (null vector by complete-pivoting elimination, rank 2 enforced through the smallest
+// right singular vector) where OpenCV's kernel is the 7-point one; P3P (Grunert's quartic, all <= 4 poses scored) where
+// OpenCV's kernel is 5-point EPnP.  The final pose is refined on the inliers by Levenberg-Marquardt on the reprojection error,
+// which is what SOLVEPNP_ITERATIVE does, so it does not depend on the minimal solver.
+// All arithmetic is FP64 (a few hundred hypotheses of a few dozen flops: latency-bound, not a throughput kernel).
+#include <float.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+namespace dvs {
+
+dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out);
+hipStream_t matcher_stream(dvs_matcher* m);
+int matcher_device(dvs_matcher* m);
+
+__host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// k distinct indices out of n (k <= 8), uniform without replacement, in draw order
+template <int KS>
+__device__ __forceinline__ void sample_distinct(unsigned long long seed, int h, int n, int* idx) {
+  int sorted[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) {
+    int r = (int)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(h * 16 + j + 1)) % (unsigned long long)(n - j));
+    for (int i = 0; i < j; i++) if (r >= sorted[i]) r++;   // skip the indices drawn before (ascending)
+    idx[j] = r;
+    int p = j;
+    while (p > 0 && sorted[p - 1] > r) { sorted[p] = sorted[p - 1]; p--; }
+    sorted[p] = r;
+  }
+}
+
+// eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi)
+__device__ __forceinline__ void smallest_eigvec3(const double* S, double* v) {
+  double a[3][3] = {{S[0], S[1], S[2]}, {S[1], S[4], S[5]}, {S[2], S[5], S[8]}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 12; sweep++) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; k++) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+        for (int k = 0; k < 3; k++) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+        for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+      }
+  }
+  int m = 0;
+  if (a[1][1] < a[m][m]) m = 1;
+  if (a[2][2] < a[m][m]) m = 2;
+  for (int k = 0; k < 3; k++) v[k] = V[k][m];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fundamental matrix: one thread = one hypothesis from 8 correspondences (x2^T F x1 = 0)
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_f_hypotheses(const float* __restrict__ p1, const float* __restrict__ p2, int n, int H,
+                                                     unsigned long long seed, double* __restrict__ Fout, int* __restrict__ valid) {
+  const int h = blockIdx.x * 64 + threadIdx.x;
+  if (h >= H) return;
+  int idx[8];
+  sample_distinct<8>(seed, h, n, idx);
+  double x1[8], y1[8], x2[8], y2[8];
+  double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+  for (int i = 0; i < 8; i++) {
+    x1[i] = p1[2 * idx[i]]; y1[i] = p1[2 * idx[i] + 1]; x2[i] = p2[2 * idx[i]]; y2[i] = p2[2 * idx[i] + 1];
+    c1x += x1[i]; c1y += y1[i]; c2x += x2[i]; c2y += y2[i];
+  }
+  c1x /= 8; c1y /= 8; c2x /= 8; c2y /= 8;
+  double d1 = 0, d2 = 0;
+  for (int i = 0; i < 8; i++) {
+    d1 += sqrt((x1[i] - c1x) * (x1[i] - c1x) + (y1[i] - c1y) * (y1[i] - c1y));
+    d2 += sqrt((x2[i] - c2x) * (x2[i] - c2x) + (y2[i] - c2y) * (y2[i] - c2y));
+  }
+  bool ok = d1 > 1e-9 && d2 > 1e-9;
+  const double s1 = ok ? sqrt(2.0) * 8 / d1 : 1.0, s2 = ok ? sqrt(2.0) * 8 / d2 : 1.0;   // Hartley: mean distance sqrt(2)
+  double A[8][9];
+  for (int i = 0; i < 8; i++) {
+    const double u1 = (x1[i] - c1x) * s1, v1 = (y1[i] - c1y) * s1, u2 = (x2[i] - c2x) * s2, v2 = (y2[i] - c2y) * s2;
+    A[i][0] = u2 * u1; A[i][1] = u2 * v1; A[i][2] = u2; A[i][3] = v2 * u1; A[i][4] = v2 * v1; A[i][5] = v2; A[i][6] = u1; A[i][7] = v1; A[i][8] = 1.0;
+  }
+  // null vector of the 8 x 9 system by Gauss-Jordan elimination with complete pivoting; the column never chosen is the free one
+  int colOf[8];
+  bool used[9] = {false, false, false, false, false, false, false, false, false};
+  for (int k = 0; k < 8 && ok; k++) {
+    int pr = k, pc = -1;
+    double best = 0;
+    for (int i = k; i < 8; i++)
+      for (int j = 0; j < 9; j++)
+        if (!used[j] && fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
+    if (pc < 0 || best < 1e-12) { ok = false; break; }
+    for (int j = 0; j < 9; j++) { const double tmp = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = tmp; }
+    used[pc] = true; colOf[k] = pc;
+    const double inv = 1.0 / A[k][pc];
+    for (int j = 0; j < 9; j++) A[k][j] *= inv;
+    for (int i = 0; i < 8; i++)
+      if (i != k) {
+        const double f = A[i][pc];
+        if (f != 0.0) for (int j = 0; j < 9; j++) A[i][j] -= f * A[k][j];
+      }
+  }
+  double f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) {
+    int fc = 0;
+    for (int j = 0; j < 9; j++) if (!used[j]) fc = j;
+    f[fc] = 1.0;
+    for (int k = 0; k < 8; k++) f[colOf[k]] = -A[k][fc];
+    // rank 2: F <- F - (F v) v^T with v the right singular vector of the smallest singular value
+    double S[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[3 * a + b] = f[a] * f[b] + f[3 + a] * f[3 + b] + f[6 + a] * f[6 + b];
+    double v[3];
+    smallest_eigvec3(S, v);
+    for (int r = 0; r < 3; r++) {
+      const double fv = f[3 * r] * v[0] + f[3 * r + 1] * v[1] + f[3 * r + 2] * v[2];
+      for (int cidx = 0; cidx < 3; cidx++) f[3 * r + cidx] -= fv * v[cidx];
+    }
+    // denormalise: F = T2^T Fn T1, T = [s 0 -s cx; 0 s -s cy; 0 0 1]
+    double G[9];
+    // Fn T1
+    for (int r = 0; r < 3; r++) {
+      G[3 * r] = f[3 * r] * s1; G[3 * r + 1] = f[3 * r + 1] * s1;
+      G[3 * r + 2] = f[3 * r + 2] - s1 * (f[3 * r] * c1x + f[3 * r + 1] * c1y);
+    }
+    // T2^T (.)
+    for (int cidx = 0; cidx < 3; cidx++) {
+      f[cidx] = s2 * G[cidx]; f[3 + cidx] = s2 * G[3 + cidx];
+      f[6 + cidx] = G[6 + cidx] - s2 * (c2x * G[cidx] + c2y * G[3 + cidx]);
+    }
+    double nrm = 0;
+    for (int k = 0; k < 9; k++) nrm += f[k] * f[k];
+    ok = nrm > 0 && isfinite(nrm);
+    if (ok) { nrm = 1.0 / sqrt(nrm); for (int k = 0; k < 9; k++) f[k] *= nrm; }
+  }
+  for (int k = 0; k < 9; k++) Fout[9 * (size_t)h + k] = ok ? f[k] : 0.0;
+  valid[h] = ok ? 1 : 0;
+}
+
+// OpenCV's FMEstimatorCallback::computeError: max of the two squared point-to-epipolar-line distances
+__device__ __forceinline__ double epi_err(const double* F, double x1, double y1, double x2, double y2) {
+  const double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  const double d2 = x2 * a + y2 * b + c, s2 = 1.0 / (a * a + b * b);
+  const double a1 = F[0] * x2 + F[3] * y2 + F[6], b1 = F[1] * x2 + F[4] * y2 + F[7], c1 = F[2] * x2 + F[5] * y2 + F[8];
+  const double d1 = x1 * a1 + y1 * b1 + c1, s1 = 1.0 / (a1 * a1 + b1 * b1);
+  return fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+
+__device__ __forceinline__ int block_count256(bool pred) {  // number of threads of the 256-thread block with pred
+  __shared__ int wcnt[4];
+  const unsigned long long b = __ballot(pred);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  return wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// one workgroup per hypothesis: inlier count over all correspondences
+__global__ __launch_bounds__(256) void k_f_score(const float* __restrict__ p1, const float* __restrict__ p2, int n, const double* __restrict__ Fall,
+                                                 const int* __restrict__ valid, double thr2, int* __restrict__ counts) {
+  const int h = blockIdx.x;
+  if (!valid[h]) { if (threadIdx.x == 0) counts[h] = 0; return; }
+  double F[9];
+  for (int k = 0; k < 9; k++) F[k] = Fall[9 * (size_t)h + k];
+  int total = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool in = false;
+    if (i < n) in = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr2;
+    total += block_count256(in);
+  }
+  if (threadIdx.x == 0) counts[h] = total;
+}
+
+// cv::RANSACUpdateNumIters
+__device__ __forceinline__ int ransac_update_iters(double p, double ep, int modelPoints, int maxIters) {
+  p = fmax(p, 0.0); p = fmin(p, 1.0);
+  ep = fmax(ep, 0.0); ep = fmin(ep, 1.0);
+  double num = fmax(1.0 - p, DBL_MIN);
+  double denom = 1.0 - pow(1.0 - ep, (double)modelPoints);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+// the sequential RANSAC loop replayed over the hypothesis counts (RANSACPointSetRegistrator::run): hypothesis h is iteration h,
+// a strictly better count replaces the best and shortens the loop.  sel[0] = best hypothesis (-1: none), sel[1] = iterations used.
+__global__ void k_ransac_select(const int* __restrict__ counts, int H, int n, int modelPoints, double confidence, int group,
+                                int* __restrict__ sel) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int niters = H / group, best = -1, bestCount = 0, it = 0;
+  const int maxIters = niters;
+  for (; it < niters; it++) {
+    for (int s = 0; s < group; s++) {   // `group` candidate models per iteration (P3P: up to 4 poses per sample), in order
+      const int h = it * group + s;
+      const int good = counts[h];
+      if (good > max(bestCount, modelPoints - 1)) {
+        bestCount = good; best = h;
+        niters = ransac_update_iters(confidence, (double)(n - good) / n, modelPoints, maxIters);
+      }
+    }
+  }
+  sel[0] = best; sel[1] = it; sel[2] = bestCount;
+}
+
+__global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, const float* __restrict__ p2, int n, const double* __restrict__ Fall,
+                                                const int* __restrict__ sel, double thr2, unsigned char* __restrict__ mask, double* __restrict__ Fbest) {
+  const int best = sel[0];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (best < 0) { if (i < n) mask[i] = 0; if (i < 9) Fbest[i] = 0.0; return; }
+  double F[9];
+  for (int k = 0; k < 9; k++) F[k] = Fall[9 * (size_t)best + k];
+  if (i < 9) Fbest[i] = F[i];
+  if (i < n) mask[i] = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr2 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// PnP: P3P hypotheses (Grunert 1841 as in Haralick et al., "Review and analysis of solutions of the three point perspective
+// pose estimation problem", IJCV 1994): quartic in v = s3 / s1, then u = s2 / s1, the three depths, and the rigid motion that
+// takes the object triangle onto the camera-frame triangle.
+// ---------------------------------------------------------------------------------------------------------------------------
+// real roots of a4 x^4 + a3 x^3 + a2 x^2 + a1 x + a0 (Ferrari through the resolvent cubic), each polished by Newton steps
+__host__ __device__ __forceinline__ int quartic_real_roots(double a4, double a3, double a2, double a1, double a0, double* roots) {
+  if (!(fabs(a4) > 1e-14 * (fabs(a3) + fabs(a2) + fabs(a1) + fabs(a0)))) return 0;
+  const double b = a3 / a4, c = a2 / a4, d = a1 / a4, e = a0 / a4;
+  // depressed quartic y^4 + p y^2 + q y + r, x = y - b / 4
+  const double p = c - 3.0 * b * b / 8.0, q = d - b * c / 2.0 + b * b * b / 8.0, r = e - b * d / 4.0 + b * b * c / 16.0 - 3.0 * b * b * b * b / 256.0;
+  int nr = 0;
+  double ys[4];
+  if (fabs(q) < 1e-14 * (1.0 + fabs(p) + fabs(r))) {  // biquadratic
+    const double disc = p * p - 4.0 * r;
+    if (disc >= -1e-9 * (p * p + fabs(4.0 * r))) {
+      const double sd = sqrt(fmax(disc, 0.0));
+      const double z[2] = {(-p + sd) / 2.0, (-p - sd) / 2.0};
+      for (int k = 0; k < 2; k++) if (z[k] >= 0) { ys[nr++] = sqrt(z[k]); ys[nr++] = -sqrt(z[k]); }
+    }
+  } else {
+    // resolvent cubic 8 m^3 + 8 p m^2 + (2 p^2 - 8 r) m - q^2 = 0: its largest real root is positive when q != 0
+    const double B = p, C = (p * p - 4.0 * r) / 4.0, D = -q * q / 8.0;   // m^3 + B m^2 + C m + D
+    const double Q3 = (3.0 * C - B * B) / 9.0, R3 = (9.0 * B * C - 27.0 * D - 2.0 * B * B * B) / 54.0;
+    const double disc = Q3 * Q3 * Q3 + R3 * R3;
+    double m;
+    if (disc >= 0) {
+      const double sd = sqrt(disc);
+      m = cbrt(R3 + sd) + cbrt(R3 - sd) - B / 3.0;
+    } else {
+      const double th = acos(fmax(-1.0, fmin(1.0, R3 / sqrt(-Q3 * Q3 * Q3))));
+      m = 2.0 * sqrt(-Q3) * cos(th / 3.0) - B / 3.0;
+    }
+    for (int k = 0; k < 3; k++) {  // polish the resolvent root
+      const double fm = ((m + B) * m + C) * m + D, dfm = (3.0 * m + 2.0 * B) * m + C;
+      if (dfm != 0.0) m -= fm / dfm;
+    }
+    if (m > 0) {
+      const double s2m = sqrt(2.0 * m);
+      // (y^2 + p/2 + m)^2 = 2 m (y - q / (4 m))^2  ->  y^2 + s y + (p/2 + m - q / (2 s)) = 0  and  y^2 - s y + (p/2 + m + q / (2 s)) = 0
+      const double t2 = p / 2.0 + m - q / (2.0 * s2m), t1 = p / 2.0 + m + q / (2.0 * s2m);   // t2 pairs with the (-s) roots, t1 with (+s)
+      // a double root shows up as a discriminant of either sign at rounding level: keep it (Newton below settles it), or a
+      // fronto-parallel triangle — the planar scenes of an RGB-D camera facing a wall — loses its true pose
+      const double dA = 2.0 * m - 4.0 * t2, dB = 2.0 * m - 4.0 * t1, tol = 1e-9 * (fabs(2.0 * m) + fabs(4.0 * t1) + fabs(4.0 * t2));
+      if (dA >= -tol) { const double sd = sqrt(fmax(dA, 0.0)); ys[nr++] = (-s2m + sd) / 2.0; ys[nr++] = (-s2m - sd) / 2.0; }
+      if (dB >= -tol) { const double sd = sqrt(fmax(dB, 0.0)); ys[nr++] = (s2m + sd) / 2.0; ys[nr++] = (s2m - sd) / 2.0; }
+    }
+  }
+  for (int k = 0; k < nr; k++) {
+    double x = ys[k] - b / 4.0;
+    for (int itn = 0; itn < 3; itn++) {
+      const double fx = (((a4 * x + a3) * x + a2) * x + a1) * x + a0, dfx = ((4.0 * a4 * x + 3.0 * a3) * x + 2.0 * a2) * x + a1;
+      if (dfx == 0.0) break;
+      x -= fx / dfx;
+    }
+    roots[k] = x;
+  }
+  return nr;
+}
+
+__host__ __device__ __forceinline__ void triad(const double* A0, const double* A1, const double* A2, double E[3][3], bool& ok) {
+  double d1[3], d2[3], e3[3];
+  for (int k = 0; k < 3; k++) { d1[k] = A1[k] - A0[k]; d2[k] = A2[k] - A0[k]; }
+  const double n1 = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
+  e3[0] = d1[1] * d2[2] - d1[2] * d2[1]; e3[1] = d1[2] * d2[0] - d1[0] * d2[2]; e3[2] = d1[0] * d2[1] - d1[1] * d2[0];
+  const double n3 = sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+  ok = ok && n1 > 1e-12 && n3 > 1e-12;
+  for (int k = 0; k < 3; k++) { E[k][0] = d1[k] / n1; E[k][2] = e3[k] / n3; }
+  E[0][1] = E[1][2] * E[2][0] - E[2][2] * E[1][0];
+  E[1][1] = E[2][2] * E[0][0] - E[0][2] * E[2][0];
+  E[2][1] = E[0][2] * E[1][0] - E[1][2] * E[0][0];
+}
+
+// Grunert's P3P for one triangle: object points P (rows), unit bearings j (rows) -> up to 4 poses (R row-major 9, t 3 each) with
+// x_cam = R X + t, in ascending order of the quartic's root
+__host__ __device__ __forceinline__ int p3p_solve(const double P[3][3], const double j[3][3], double* poses /* 4 x 12 */) {
+  auto dist2 = [&](int a, int b) { double s = 0; for (int k = 0; k < 3; k++) s += (P[a][k] - P[b][k]) * (P[a][k] - P[b][k]); return s; };
+  auto dot = [&](int a, int b) { return j[a][0] * j[b][0] + j[a][1] * j[b][1] + j[a][2] * j[b][2]; };
+  const double a2 = dist2(1, 2), b2 = dist2(0, 2), c2 = dist2(0, 1);
+  const double ca = dot(1, 2), cb = dot(0, 2), cg = dot(0, 1);
+  int nsol = 0;
+  if (!(a2 > 1e-18 && b2 > 1e-18 && c2 > 1e-18)) return 0;
+  const double q = (a2 - c2) / b2, w = (a2 + c2) / b2;
+  const double A4 = (q - 1) * (q - 1) - 4 * c2 / b2 * ca * ca;
+  const double A3 = 4 * (q * (1 - q) * cb - (1 - w) * ca * cg + 2 * c2 / b2 * ca * ca * cb);
+  const double A2 = 2 * (q * q - 1 + 2 * q * q * cb * cb + 2 * (b2 - c2) / b2 * ca * ca - 4 * w * ca * cb * cg + 2 * (b2 - a2) / b2 * cg * cg);
+  const double A1 = 4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg * cg * cb - (1 - w) * ca * cg);
+  const double A0 = (1 + q) * (1 + q) - 4 * a2 / b2 * cg * cg;
+  double roots[4];
+  const int nr = quartic_real_roots(A4, A3, A2, A1, A0, roots);
+  for (int a = 1; a < nr; a++) {   // canonical solution order (ascending v): ties between equally good poses resolve the same way
+    const double key = roots[a];
+    int b = a - 1;
+    while (b >= 0 && roots[b] > key) { roots[b + 1] = roots[b]; b--; }
+    roots[b + 1] = key;
+  }
+  for (int rI = 0; rI < nr && nsol < 4; rI++) {
+    const double v = roots[rI];
+    if (!(v > 0) || !isfinite(v)) continue;
+    if (rI > 0 && fabs(v - roots[rI - 1]) <= 1e-9 * fabs(v)) continue;   // a double root gives one pose
+    const double den = 2 * (cg - v * ca);
+    if (fabs(den) < 1e-12) continue;
+    const double u = ((-1 + q) * v * v - 2 * q * cb * v + 1 + q) / den;
+    if (!(u > 0) || !isfinite(u)) continue;
+    const double dd = 1 + u * u - 2 * u * cg;
+    if (!(dd > 1e-18)) continue;
+    const double s1 = sqrt(c2 / dd), s2 = u * s1, s3 = v * s1;
+    double Q[3][3];
+    for (int k = 0; k < 3; k++) { Q[0][k] = s1 * j[0][k]; Q[1][k] = s2 * j[1][k]; Q[2][k] = s3 * j[2][k]; }
+    double EQ[3][3], EP[3][3];
+    bool ok = true;
+    triad(Q[0], Q[1], Q[2], EQ, ok);
+    triad(P[0], P[1], P[2], EP, ok);
+    if (!ok) continue;
+    double* o = poses + 12 * nsol;
+    double R[9];
+    for (int a = 0; a < 3; a++) for (int bq = 0; bq < 3; bq++) R[3 * a + bq] = EQ[a][0] * EP[bq][0] + EQ[a][1] * EP[bq][1] + EQ[a][2] * EP[bq][2];
+    bool fin = true;
+    for (int k = 0; k < 9; k++) { o[k] = R[k]; fin = fin && isfinite(R[k]); }
+    for (int a = 0; a < 3; a++) { o[9 + a] = Q[0][a] - (R[3 * a] * P[0][0] + R[3 * a + 1] * P[0][1] + R[3 * a + 2] * P[0][2]); fin = fin && isfinite(o[9 + a]); }
+    if (!fin) continue;
+    nsol++;
+  }
+  return nsol;
+}
+
+// one thread = one sample of 3 correspondences -> up to 4 poses; unused slots are marked invalid
+__global__ __launch_bounds__(64) void k_p3p_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, int n, int H,
+                                                       double fx, double fy, double cx, double cy, unsigned long long seed,
+                                                       double* __restrict__ poses, int* __restrict__ valid) {
+  const int h = blockIdx.x * 64 + threadIdx.x;
+  if (h >= H) return;
+  int idx[3];
+  sample_distinct<3>(seed, h, n, idx);
+  double P[3][3], j[3][3];
+  for (int i = 0; i < 3; i++) {
+    for (int k = 0; k < 3; k++) P[i][k] = obj[3 * idx[i] + k];
+    const double bx = (img[2 * idx[i]] - cx) / fx, by = (img[2 * idx[i] + 1] - cy) / fy;
+    const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
+    j[i][0] = bx * nn; j[i][1] = by * nn; j[i][2] = nn;
+  }
+  double sol[48];
+  const int nsol = p3p_solve(P, j, sol);
+  for (int s = 0; s < 4; s++) {
+    valid[4 * h + s] = s < nsol ? 1 : 0;
+    if (s < nsol) for (int k = 0; k < 12; k++) poses[12 * ((size_t)4 * h + s) + k] = sol[12 * s + k];
+  }
+}
+
+__device__ __forceinline__ double reproj_err2(const double* R, const double* t, double fx, double fy, double cx, double cy, const float* X, const float* uv) {
+  const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+  const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+  if (!(z > 1e-9)) return 1e300;
+  const double du = fx * x / z + cx - uv[0], dv = fy * y / z + cy - uv[1];
+  return du * du + dv * dv;
+}
+
+__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ poses,
+                                                   const int* __restrict__ valid, double fx, double fy, double cx, double cy, double thr2,
+                                                   int* __restrict__ counts) {
+  const int h = blockIdx.x;
+  if (!valid[h]) { if (threadIdx.x == 0) counts[h] = 0; return; }
+  double Rt[12];
+  for (int k = 0; k < 12; k++) Rt[k] = poses[12 * (size_t)h + k];
+  int total = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool in = false;
+    if (i < n) in = reproj_err2(Rt, Rt + 9, fx, fy, cx, cy, obj + 3 * i, img + 2 * i) <= thr2;
+    total += block_count256(in);
+  }
+  if (threadIdx.x == 0) counts[h] = total;
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* sm) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sm[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] += sm[tid + s]; __syncthreads(); }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ void exp_so3(const double* w, double* E) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+  const double A = th < 1e-8 ? 1.0 - th2 / 6.0 : sin(th) / th, B = th < 1e-8 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
+  const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double kk = 0;
+      for (int c = 0; c < 3; c++) kk += K[3 * a + c] * K[3 * c + b];
+      E[3 * a + b] = (a == b ? 1.0 : 0.0) + A * K[3 * a + b] + B * kk;
+    }
+}
+
+// inlier mask of the selected pose, then Levenberg-Marquardt on the reprojection error over the inliers (what
+// SOLVEPNP_ITERATIVE does), one workgroup.  out: rvec (Rodrigues) + tvec; inliers as ascending indices.
+__global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ poses,
+                                                    const int* __restrict__ sel, double fx, double fy, double cx, double cy, double thr2,
+                                                    int* __restrict__ inliers, int* __restrict__ nin, double* __restrict__ rt, int* __restrict__ success) {
+  __shared__ double sm[256];
+  __shared__ double sR[9], st[3], sRn[9], stn[3], sH[36], sg[6], sd[6];
+  __shared__ int s_cnt, s_wsum[5];
+  __shared__ double s_lambda, s_cost;
+  __shared__ int s_stop;
+  const int tid = threadIdx.x;
+  const int best = sel[0];
+  if (best < 0) { if (tid == 0) { *nin = 0; *success = 0; for (int k = 0; k < 6; k++) rt[k] = 0; } return; }
+  if (tid < 9) sR[tid] = poses[12 * (size_t)best + tid];
+  if (tid < 3) st[tid] = poses[12 * (size_t)best + 9 + tid];
+  if (tid == 0) { s_cnt = 0; s_lambda = 1e-3; s_stop = 0; }
+  __syncthreads();
+  // ordered inlier list (ascending index): block scans over chunks of 256
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    const bool in = i < n && reproj_err2(sR, st, fx, fy, cx, cy, obj + 3 * i, img + 2 * i) <= thr2;
+    int incl = in ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if ((tid & 63) >= o) incl += tt; }
+    __syncthreads();
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = s_cnt;
+    for (int w = 0; w < (tid >> 6); w++) base += s_wsum[w];
+    if (in) inliers[base + incl - 1] = i;
+    __syncthreads();
+    if (tid == 0) s_cnt += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+  }
+  const int m = s_cnt;
+  if (tid == 0) *nin = m;
+  auto cost_of = [&](const double* R, const double* t) -> double {
+    double c = 0;
+    for (int e = tid; e < m; e += 256) { const int i = inliers[e]; c += fmin(reproj_err2(R, t, fx, fy, cx, cy, obj + 3 * i, img + 2 * i), 1e12); }
+    return block_sum256(c, sm);
+  };
+  __threadfence_block();
+  __syncthreads();
+  double cost = cost_of(sR, st);
+  for (int iter = 0; iter < 20 && m >= 3; iter++) {
+    // normal equations of the current pose: left perturbation R <- exp(w) R, t <- t + dt
+    double H[21], g[6];
+    for (int k = 0; k < 21; k++) H[k] = 0;
+    for (int k = 0; k < 6; k++) g[k] = 0;
+    for (int e = tid; e < m; e += 256) {
+      const int i = inliers[e];
+      const float* X = obj + 3 * i;
+      const double rx = sR[0] * X[0] + sR[1] * X[1] + sR[2] * X[2], ry = sR[3] * X[0] + sR[4] * X[1] + sR[5] * X[2], rz = sR[6] * X[0] + sR[7] * X[1] + sR[8] * X[2];
+      const double x = rx + st[0], y = ry + st[1], z = rz + st[2];
+      if (!(z > 1e-9)) continue;
+      const double iz = 1.0 / z, du = fx * x * iz + cx - img[2 * i], dv = fy * y * iz + cy - img[2 * i + 1];
+      // d(u,v)/d p_c
+      const double a00 = fx * iz, a02 = -fx * x * iz * iz, a11 = fy * iz, a12 = -fy * y * iz * iz;
+      // d p_c / d w = -[R X]_x ; d p_c / d t = I
+      double Ju[6], Jv[6];
+      // -[r]_x = [[0, rz, -ry], [-rz, 0, rx], [ry, -rx, 0]]
+      Ju[0] = a02 * ry;            Ju[1] = a00 * rz - a02 * rx;   Ju[2] = -a00 * ry;
+      Jv[0] = -a11 * rz + a12 * ry; Jv[1] = -a12 * rx;             Jv[2] = a11 * rx;
+      Ju[3] = a00; Ju[4] = 0; Ju[5] = a02;
+      Jv[3] = 0; Jv[4] = a11; Jv[5] = a12;
+      int k = 0;
+      for (int a = 0; a < 6; a++) {
+        for (int b = a; b < 6; b++) H[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        g[a] += Ju[a] * du + Jv[a] * dv;
+      }
+    }
+    {
+      int k = 0;
+      for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) {
+          const double v = block_sum256(H[k++], sm);
+          if (tid == 0) { sH[6 * a + b] = v; sH[6 * b + a] = v; }
+        }
+      for (int a = 0; a < 6; a++) { const double v = block_sum256(g[a], sm); if (tid == 0) sg[a] = v; }
+    }
+    __syncthreads();
+    bool accepted = false;
+    for (int tries = 0; tries < 8 && !accepted; tries++) {
+      if (tid == 0) {  // (H + lambda diag(H)) d = -g by Cholesky
+        double A[36], b6[6];
+        for (int k = 0; k < 36; k++) A[k] = sH[k];
+        for (int a = 0; a < 6; a++) { A[7 * a] += s_lambda * fmax(sH[7 * a], 1e-12); b6[a] = -sg[a]; }
+        bool ok = true;
+        for (int jx = 0; jx < 6 && ok; jx++) {
+          double d = A[7 * jx];
+          for (int k = 0; k < jx; k++) d -= A[6 * jx + k] * A[6 * jx + k];
+          if (!(d > 0)) { ok = false; break; }
+          d = sqrt(d);
+          A[7 * jx] = d;
+          for (int i = jx + 1; i < 6; i++) {
+            double sacc = A[6 * i + jx];
+            for (int k = 0; k < jx; k++) sacc -= A[6 * i + k] * A[6 * jx + k];
+            A[6 * i + jx] = sacc / d;
+          }
+        }
+        if (ok) {
+          for (int i = 0; i < 6; i++) { double sacc = b6[i]; for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * b6[k]; b6[i] = sacc / A[7 * i]; }
+          for (int i = 5; i >= 0; i--) { double sacc = b6[i]; for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * b6[k]; b6[i] = sacc / A[7 * i]; }
+          double E[9];
+          exp_so3(b6, E);
+          for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sRn[3 * a + b] = E[3 * a] * sR[b] + E[3 * a + 1] * sR[3 + b] + E[3 * a + 2] * sR[6 + b];
+          for (int a = 0; a < 3; a++) stn[a] = st[a] + b6[3 + a];
+          for (int a = 0; a < 6; a++) sd[a] = b6[a];
+        } else {
+          for (int k = 0; k < 9; k++) sRn[k] = sR[k];
+          for (int k = 0; k < 3; k++) stn[k] = st[k];
+          for (int a = 0; a < 6; a++) sd[a] = 0;
+        }
+      }
+      __syncthreads();
+      const double ncost = cost_of(sRn, stn);
+      if (ncost < cost) {
+        accepted = true;
+        const double stepn = fabs(sd[0]) + fabs(sd[1]) + fabs(sd[2]) + fabs(sd[3]) + fabs(sd[4]) + fabs(sd[5]);
+        __syncthreads();
+        if (tid == 0) {
+          for (int k = 0; k < 9; k++) sR[k] = sRn[k];
+          for (int k = 0; k < 3; k++) st[k] = stn[k];
+          s_lambda = fmax(s_lambda * 0.1, 1e-12);
+          if (stepn < 1e-12 || cost - ncost <= 1e-14 * cost) s_stop = 1;
+        }
+        cost = ncost;
+      } else {
+        __syncthreads();
+        if (tid == 0) s_lambda *= 10.0;
+      }
+      __syncthreads();
+    }
+    if (!accepted || s_stop) break;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // rotation matrix -> Rodrigues vector
+    const double tr = sR[0] + sR[4] + sR[8];
+    const double cth = fmax(-1.0, fmin(1.0, (tr - 1.0) / 2.0)), th = acos(cth);
+    double w[3] = {sR[7] - sR[5], sR[2] - sR[6], sR[3] - sR[1]};
+    const double sn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) / 2.0;   // sin(theta)
+    if (sn > 1e-12) {
+      const double f = th / (2.0 * sn);
+      for (int k = 0; k < 3; k++) w[k] *= f;
+    } else if (cth > 0) {
+      for (int k = 0; k < 3; k++) w[k] *= 0.5;
+    } else {  // theta = pi: axis from the diagonal
+      const double ax[3] = {sqrt(fmax((sR[0] + 1) / 2, 0.0)), sqrt(fmax((sR[4] + 1) / 2, 0.0)), sqrt(fmax((sR[8] + 1) / 2, 0.0))};
+      w[0] = th * ax[0]; w[1] = th * ax[1] * (sR[1] >= 0 ? 1 : -1); w[2] = th * ax[2] * (sR[2] >= 0 ? 1 : -1);
+    }
+    for (int k = 0; k < 3; k++) { rt[k] = w[k]; rt[3 + k] = st[k]; }
+    *success = m > 0 ? 1 : 0;
+  }
+}
+
+}  // namespace dvs
+
+using namespace dvs;
+
+extern "C" {
+
+// host-logic test hooks (no GPU): the product's quartic and P3P routines, compiled for the host
+int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, double a0, double* roots4) {
+  return quartic_real_roots(a4, a3, a2, a1, a0, roots4);
+}
+int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48) {
+  double P[3][3], j[3][3];
+  memcpy(P, P9, sizeof(P)); memcpy(j, j9, sizeof(j));
+  return p3p_solve(P, j, poses48);
+}
+
+dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
+                                       int32_t max_iters, uint64_t seed, double* F9, uint8_t* inlier_mask, int32_t* n_inliers) {
+  DVS_ARG(ctx && n >= 0 && max_iters >= 1 && max_iters <= 4096 && (inlier_mask || n == 0) && threshold > 0);
+  if (n_inliers) *n_inliers = 0;
+  if (F9) memset(F9, 0, 72);
+  if (n < 8) {  // cv::findFundamentalMat needs >= 7 points for FM_RANSAC (8 for our kernel): empty F, mask of zeros
+    if (inlier_mask) memset(inlier_mask, 0, (size_t)n);
+    return DVS_OK;
+  }
+  DVS_ARG(pts1 && pts2);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const int H = max_iters;
+  const size_t pb = ((size_t)n * 8 + 15) & ~(size_t)15;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, 2 * pb + (size_t)H * 72 + (size_t)H * 8 + 64 + 80 + (size_t)n + 32, (void**)&base));
+  float* d_p1 = (float*)base; float* d_p2 = (float*)(base + pb);
+  double* d_F = (double*)(base + 2 * pb);
+  int* d_valid = (int*)(d_F + 9 * (size_t)H); int* d_counts = d_valid + H;
+  int* d_sel = d_counts + H;                       // 4 ints
+  double* d_Fb = (double*)(((uintptr_t)(d_sel + 4) + 15) & ~(uintptr_t)15);
+  unsigned char* d_mask = (unsigned char*)(d_Fb + 9);
+  DVS_HIP(hipMemcpyAsync(d_p1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_p2, pts2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_f_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_p1, d_p2, n, H, (unsigned long long)seed, d_F, d_valid);
+  hipLaunchKernelGGL(k_f_score, dim3(H), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_valid, threshold * threshold, d_counts);
+  hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, H, n, 8, confidence, 1, d_sel);
+  hipLaunchKernelGGL(k_f_mask, dim3((std::max(n, 9) + 255) / 256), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_sel, threshold * threshold, d_mask, d_Fb);
+  DVS_HIP(hipGetLastError());
+  int sel[4] = {0, 0, 0, 0};
+  DVS_HIP(hipMemcpyAsync(sel, d_sel, 12, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(inlier_mask, d_mask, (size_t)n, hipMemcpyDeviceToHost, st));
+  double Fb[9];
+  DVS_HIP(hipMemcpyAsync(Fb, d_Fb, 72, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  if (F9) memcpy(F9, Fb, 72);
+  if (n_inliers) *n_inliers = sel[0] >= 0 ? sel[2] : 0;
+  return DVS_OK;
+}
+
+dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
+                                double reproj_err, double confidence, uint64_t seed, double* rvec3, double* tvec3, int32_t* inliers,
+                                int32_t* n_inliers, int32_t* success) {
+  DVS_ARG(ctx && n >= 0 && iterations >= 1 && iterations <= 1024 && K4 && rvec3 && tvec3 && success && reproj_err > 0);
+  *success = 0;
+  if (n_inliers) *n_inliers = 0;
+  memset(rvec3, 0, 24); memset(tvec3, 0, 24);
+  if (n < 4) return DVS_OK;   // cv::solvePnPRansac: "npoints >= 4"
+  DVS_ARG(pts3d && pts2d);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const int H = iterations;
+  const size_t ob = ((size_t)n * 12 + 15) & ~(size_t)15, ib = ((size_t)n * 8 + 15) & ~(size_t)15;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, ob + ib + (size_t)4 * H * 96 + (size_t)4 * H * 8 + 64 + 48 + (size_t)n * 4 + 64, (void**)&base));
+  float* d_obj = (float*)base; float* d_img = (float*)(base + ob);
+  double* d_poses = (double*)(base + ob + ib);
+  int* d_valid = (int*)(d_poses + 12 * (size_t)4 * H); int* d_counts = d_valid + 4 * H;
+  int* d_sel = d_counts + 4 * H;                  // 4 ints
+  int* d_nin = d_sel + 4; int* d_succ = d_nin + 1;
+  double* d_rt = (double*)(((uintptr_t)(d_succ + 1) + 15) & ~(uintptr_t)15);
+  int* d_inl = (int*)(d_rt + 6);
+  DVS_HIP(hipMemcpyAsync(d_obj, pts3d, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  DVS_HIP(hipMemcpyAsync(d_img, pts2d, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], thr2 = reproj_err * reproj_err;
+  hipLaunchKernelGGL(k_p3p_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_obj, d_img, n, H, fx, fy, cx, cy, (unsigned long long)seed, d_poses, d_valid);
+  hipLaunchKernelGGL(k_pnp_score, dim3(4 * H), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_valid, fx, fy, cx, cy, thr2, d_counts);
+  hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, 4 * H, n, 3, confidence, 4, d_sel);
+  hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_sel, fx, fy, cx, cy, thr2, d_inl, d_nin, d_rt, d_succ);
+  DVS_HIP(hipGetLastError());
+  int nin = 0, succ = 0;
+  double rt[6];
+  DVS_HIP(hipMemcpyAsync(&nin, d_nin, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(&succ, d_succ, 4, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipMemcpyAsync(rt, d_rt, 48, hipMemcpyDeviceToHost, st));
+  DVS_HIP(hipStreamSynchronize(st));
+  if (inliers && nin > 0) DVS_HIP(hipMemcpy(inliers, d_inl, (size_t)nin * 4, hipMemcpyDeviceToHost));
+  if (n_inliers) *n_inliers = nin;
+  *success = succ;
+  if (succ) { memcpy(rvec3, rt, 24); memcpy(tvec3, rt + 3, 24); }
+  return DVS_OK;
+}
+
+}  // extern "C"

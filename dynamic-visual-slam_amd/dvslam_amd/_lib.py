@@ -101,9 +101,13 @@ def lib():
     L.dvs_boundary_block_bytes.argtypes = [i32]; L.dvs_boundary_block_bytes.restype = sz
     L.dvs_exchange_boundary.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.dvs_comm_all_gather.argtypes = [vp, vp, vp, vp, sz]
+    L.dvs_find_fundamental_ransac.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, C.c_uint64, vp, vp, C.POINTER(i32)]
+    L.dvs_solve_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_uint64, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
     L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
     L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int
+    L.dvs_test_quartic_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
+    L.dvs_test_p3p.argtypes = [vp, vp, vp]
     L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
     L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):

@@ -22,6 +22,24 @@ class FrontendGlue:
         L.dvs_publish_keyframe.argtypes = [vp, C.POINTER(KeyframeHeader), vp, vp, i32, vp, i32, i32, sz, f32, f32, f32, f32, vp, vp, vp, sz,
                                            C.POINTER(sz), C.POINTER(i32)]
 
+    def find_fundamental_ransac(self, pts1, pts2, threshold=2.0, confidence=0.99, max_iters=1000, seed=1):
+        """cv::findFundamentalMat(pts1, pts2, mask, FM_RANSAC, threshold, confidence) -> (F 3x3, mask uint8[n], inliers of the model)"""
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); n = C.c_int32()
+        check(self._L.dvs_find_fundamental_ransac(self._h, ptr(p1), ptr(p2), len(p1), threshold, confidence, max_iters, seed, ptr(F), ptr(mask),
+                                                  C.byref(n)))
+        return F.reshape(3, 3), mask[:len(p1)], n.value
+
+    def solve_pnp_ransac(self, pts3d, pts2d, K4, iterations=100, reproj_err=4.0, confidence=0.99, seed=1):
+        """cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations, reproj_err, confidence, inliers)
+        -> (success, rvec, tvec, inlier indices)"""
+        o = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); i2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K4, np.float64)
+        rvec = np.zeros(3); tvec = np.zeros(3); inl = np.zeros(max(len(o), 1), np.int32); nin = C.c_int32(); ok = C.c_int32()
+        check(self._L.dvs_solve_pnp_ransac(self._h, ptr(o), ptr(i2), len(o), ptr(K), iterations, reproj_err, confidence, seed, ptr(rvec), ptr(tvec),
+                                           ptr(inl), C.byref(nin), C.byref(ok)))
+        return bool(ok.value), rvec, tvec, inl[:nin.value].copy()
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.dvs_matcher_destroy(self._h)

@@ -253,6 +253,27 @@ dvs_status dvs_publish_keyframe(dvs_matcher* ctx, const dvs_keyframe_header* hdr
 dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_header* hdr, char* frame_id_buf, size_t frame_id_cap,
                                    uint64_t* landmark_ids, double* landmark_xyz, uint64_t* obs_landmark_ids, double* obs_pixels,
                                    uint8_t* obs_desc, int32_t cap_n, int32_t* n_landmarks, int32_t* n_observations);
+/* ---- the frontend's robust-estimation stages, as batched-hypothesis kernels ---------------------------
+ * OpenCV's RANSAC draws its samples from a cv::RNG whose state cannot be restated, so these are NOT bit-compatible with
+ * cv::findFundamentalMat / cv::solvePnPRansac; they implement the same estimator (threshold, confidence, iteration cap, the
+ * adaptive stopping rule RANSACUpdateNumIters, error measures) over a documented deterministic sampler (`seed`; csrc/ransac.hip),
+ * and parity is stated as a tolerance on the inlier set and the pose.  Host pointers.
+ *
+ * cv::findFundamentalMat(pts1, pts2, mask, cv::FM_RANSAC, threshold = 2.0, confidence = 0.99) as frontend.cpp:635, 1146-1147
+ * call it: pts n x 2 float, x2^T F x1 = 0; inlier_mask[n] = 1 where max of the two squared epipolar distances <= threshold^2
+ * for the best model.  F9 (row-major, unit Frobenius norm) may be NULL.  n < 8: mask of zeros, *n_inliers = 0. */
+dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
+                                       int32_t max_iters /* OpenCV default 1000 */, uint64_t seed, double* F9, uint8_t* inlier_mask,
+                                       int32_t* n_inliers);
+/* cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations = 100, reproj_err = 4.0, confidence = 0.99, inliers)
+ * (frontend.cpp:911-921; zero distortion): obj n x 3 float (camera frame of the previous image), img n x 2 float,
+ * K4 = {fx, fy, cx, cy}.  P3P hypotheses, best by inlier count, Levenberg-Marquardt refinement on the inliers (the
+ * SOLVEPNP_ITERATIVE step).  rvec3 = Rodrigues vector, tvec3: x_cam = R X + t.  inliers: ascending indices (capacity n, may be
+ * NULL).  *success = 0 (and zeros) when no model found or n < 4. */
+dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
+                                double reproj_err, double confidence, uint64_t seed, double* rvec3, double* tvec3, int32_t* inliers,
+                                int32_t* n_inliers, int32_t* success);
+
 /* Harris corner measure as cv::ORB scores keypoints (ORB::HARRIS_SCORE, the mode test_dbow2_integration.cpp:19 runs with:
  * OpenCV features2d orb.cpp HarrisResponses — integer 3x3 gradients over a block_size^2 window, response = (ab - c^2 - k(a+b)^2)
  * / (4 block_size 255)^4 in float; cv::ORB uses block_size 7, k 0.04).  x, y: integer pixel positions in this image (one pyramid
@@ -335,6 +356,9 @@ void dvs_test_sort_nodes_ranked(const int32_t* count, const int32_t* ulx, int32_
 /* ... and through the kernel's workgroup sort itself (needs a GPU; n <= 1500) */
 dvs_status dvs_test_sort_nodes_device(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
 void dvs_test_sincosf(float a, float* s, float* c);
+/* the PnP stage's quartic (Ferrari + Newton) and P3P (Grunert) routines on the host: real roots (unordered) / up to 4 poses x 12 */
+int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, double a0, double* roots4);
+int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48);
 dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
                              int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);
 

@@ -330,3 +330,59 @@ def associate(obs_desc, obs_px, lm_desc, lm_xyz, R, t, fx, fy, cx, cy, max_desc=
     _glue_lib().orc_associate(_p(obs_desc), _p(obs_px), len(obs_desc), _p(lm_desc), _p(lm_xyz), len(lm_desc), _p(R), _p(t), fx, fy, cx, cy,
                               max_desc, max_reproj, _p(best))
     return best
+
+
+# ------------------------------------------------ robust estimation stages (N4) -------------------------------------------------
+def _ransac_lib():
+    L = lib()
+    vp, i32, dbl, u64 = C.c_void_p, C.c_int, C.c_double, C.c_uint64
+    L.orc_splitmix64.restype = u64; L.orc_splitmix64.argtypes = [u64]
+    L.orc_sample_distinct.argtypes = [u64, i32, i32, i32, vp]
+    L.orc_quartic_real_roots.restype = i32; L.orc_quartic_real_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
+    L.orc_p3p.restype = i32; L.orc_p3p.argtypes = [vp, vp, vp]
+    L.orc_eight_point.restype = i32; L.orc_eight_point.argtypes = [vp, vp, i32, vp]
+    L.orc_find_fundamental_ransac.argtypes = [vp, vp, i32, dbl, dbl, i32, u64, vp, vp, vp]
+    L.orc_solve_pnp_ransac.restype = i32
+    L.orc_solve_pnp_ransac.argtypes = [vp, vp, i32, vp, i32, dbl, dbl, u64, vp, vp, vp, vp, vp]
+    return L
+
+
+def sample_distinct(seed, h, n, k):
+    idx = np.zeros(k, np.int32)
+    _ransac_lib().orc_sample_distinct(seed, h, n, k, _p(idx))
+    return idx
+
+
+def quartic_real_roots(a):
+    r = np.zeros(4)
+    n = _ransac_lib().orc_quartic_real_roots(*[float(v) for v in a], _p(r))
+    return np.sort(r[:n])
+
+
+def p3p(P, j):
+    out = np.zeros((4, 12))
+    n = _ransac_lib().orc_p3p(_p(np.ascontiguousarray(P, np.float64)), _p(np.ascontiguousarray(j, np.float64)), _p(out))
+    return [(out[i, :9].reshape(3, 3).copy(), out[i, 9:].copy()) for i in range(n)]
+
+
+def eight_point(p1, p2):
+    F = np.zeros(9)
+    p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+    ok = _ransac_lib().orc_eight_point(_p(p1), _p(p2), len(p1), _p(F))
+    return F.reshape(3, 3) if ok else None
+
+
+def find_fundamental_ransac(p1, p2, threshold=2.0, confidence=0.99, max_iters=1000, seed=1):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); sel = np.zeros(3, np.int32)
+    _ransac_lib().orc_find_fundamental_ransac(_p(p1), _p(p2), len(p1), threshold, confidence, max_iters, seed, _p(F), _p(mask), _p(sel))
+    return F.reshape(3, 3), mask[:len(p1)], sel
+
+
+def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_err=4.0, confidence=0.99, seed=1):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3); img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    K4 = np.ascontiguousarray(K4, np.float64)
+    rvec = np.zeros(3); tvec = np.zeros(3); inl = np.zeros(max(len(obj), 1), np.int32); nin = C.c_int(); sel = np.zeros(3, np.int32)
+    ok = _ransac_lib().orc_solve_pnp_ransac(_p(obj), _p(img), len(obj), _p(K4), iterations, reproj_err, confidence, seed, _p(rvec), _p(tvec), _p(inl),
+                                            C.byref(nin), _p(sel))
+    return bool(ok), rvec, tvec, inl[:nin.value].copy(), sel
