@@ -55,6 +55,44 @@ def make_frame(t: int = 0, cols: int = 1280, rows: int = 720, seed: int = 1234, 
     return np.ascontiguousarray(np.clip(frame, 0, 255).astype(np.uint8))
 
 
+def traj_state(t: float):
+    """Bounded camera trajectory of the 1000-frame replay sequence (BASELINE configs[4]): roll angle [rad] and image-plane offset
+    [px] of frame t.  <= 7 px and <= 0.26 deg of motion per frame, |offset| <= 240 px, |roll| <= 12 deg, so every frame stays on
+    the canvas however long the sequence runs (make_frame's straight-line motion leaves it after ~170 frames)."""
+    th = np.deg2rad(12.0) * np.sin(2 * np.pi * t / 300.0)
+    ox = 180.0 * np.sin(2 * np.pi * t / 450.0) + 60.0 * np.sin(2 * np.pi * t / 97.0)
+    oy = 110.0 * np.sin(2 * np.pi * t / 333.0 + 0.7)
+    return th, ox, oy
+
+
+def make_traj_frame(t: int, cols: int = 640, rows: int = 480, seed: int = 1234, noise: int = 8) -> np.ndarray:
+    """frame t of the bounded-trajectory sequence: the canvas sampled at R(th) (p - c) + c + (ox, oy) (nearest neighbour, so the
+    generator is integer-exact), plus per-frame uniform sensor noise"""
+    margin = 260 + 4 * 64
+    cw, ch = cols + 2 * margin, rows + 2 * margin
+    canvas = _canvas(seed, cw, ch)
+    th, ox, oy = traj_state(t)
+    c, s = np.cos(th), np.sin(th)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    dx, dy = xx - cols / 2.0, yy - rows / 2.0
+    sx = np.rint(c * dx - s * dy + cols / 2.0 + margin + ox).astype(np.int64)
+    sy = np.rint(s * dx + c * dy + rows / 2.0 + margin + oy).astype(np.int64)
+    np.clip(sx, 0, cw - 1, out=sx); np.clip(sy, 0, ch - 1, out=sy)
+    frame = canvas[sy, sx].astype(np.int32)
+    if noise > 0:
+        rng = np.random.Generator(np.random.PCG64(seed * 7919 + 104729 + t))
+        frame += rng.integers(-noise, noise + 1, size=frame.shape, dtype=np.int32)
+    return np.ascontiguousarray(np.clip(frame, 0, 255).astype(np.uint8))
+
+
+def traj_pose(t: float, f: float, z0: float):
+    """closed-form camera-to-world pose (R, T) of frame t for a fronto-parallel plane at depth z0 and focal length f [px]: the
+    pixel p sees the canvas point R(th) (p - c) + offset, i.e. world = Rz(th) x_cam + (ox, oy, 0) z0 / f"""
+    th, ox, oy = traj_state(t)
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]), np.array([ox * z0 / f, oy * z0 / f, 0.0])
+
+
 def make_rgbd(t: int = 0, cols: int = 1280, rows: int = 720, seed: int = 1234):
     """(bgr uint8 HxWx3, depth uint16 HxW in mm) as the frontend receives them (FE:1076-1077)."""
     g = make_frame(t, cols, rows, seed)

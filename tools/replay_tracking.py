@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""File-driven stand-in for bag_playback.launch.xml WITH the tracking stages (BASELINE configs[4]):
+a synthetic RGB-D sequence runs through the two nodes' per-frame logic, once on the MI355X (every stage through the C-ABI) and
+once on the CPU oracle, and the two trajectories are compared with each other and with the generator's closed-form ground truth.
+
+Per frame (Frontend::syncCallback, frontend.cpp:1068-1324):
+  gray -> ORB extract -> filterDepth -> match vs previous frame -> distance < 50 -> findFundamentalMat(RANSAC, 2 px, 0.99) inliers
+  -> feature culling (matched first, then <= 200 unmatched with response >= 50, best first; :1171-1219)
+  -> estimateCameraPose: 3D points from the PREVIOUS depth image, solvePnPRansac(100, 4 px, 0.99), inverse motion, isMotionOutlier
+     (0.5 m / 0.2 rad), pose accumulation R_ / t_ (:843-962)
+  -> isKeyframe: match vs last keyframe + F-RANSAC, keyframe if < 150 consistent matches or > 30 frames (:601-662)
+  -> publishKeyframe as Keyframe.msg CDR bytes (:699-790)
+Backend (Backend::syncCallback / bundleAdjustmentCallback, backend.cpp:709-989): unpack, associate observations with the landmark
+database (Hamming < 50, reprojection < 5 px), new landmarks otherwise, and every `ba_every` keyframes SlidingWindowBA over the
+last 5 keyframes (the reference runs it on a 2 s wall timer; a replay has no wall clock).
+
+The scene is a fronto-parallel textured plane at Z0 (depth image constant), the camera translates in the image plane and rolls
+(dvslam_amd.synth.traj_state), so ground truth is exact.  RANSAC seeds are the frame index: both pipelines draw the same samples."""
+import argparse
+import json
+import os
+import sys
+import time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamic-visual-slam_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rodrigues_to_R(w):
+    th = np.linalg.norm(w)
+    if th < 1e-15:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def rot_angle(R):
+    return float(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1)))
+
+
+def quat_xyzw(R):
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+
+class HipStages:
+    """every stage through the C-ABI of libdvslam_hip.so (ctypes drivers in dvslam_amd)"""
+    name = "hip"
+
+    def __init__(self, nfeatures):
+        import dvslam_amd
+        self.orb = dvslam_amd.ORBextractor(nfeatures, 1.2, 8, 20, 7)
+        self.mat = dvslam_amd.BFMatcher()
+        self.g = dvslam_amd.FrontendGlue()
+        self._ba = dvslam_amd
+
+    def extract(self, gray):
+        n, k, d = self.orb(gray)
+        return k, d
+
+    def filter_depth(self, k, d, depth):
+        return self.g.filter_depth(k, d, depth)[:2]
+
+    def match(self, q, t):
+        return self.mat.match(q, t)
+
+    def fundamental_inliers(self, p1, p2, seed):
+        return self.g.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, seed)[1].astype(bool)
+
+    def pnp(self, obj, img, K4, seed):
+        ok, rvec, tvec, inl = self.g.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
+        return ok, rvec, tvec, len(inl)
+
+    def publish(self, *a, **kw):
+        return self.g.publish_keyframe(*a, **kw)[0]
+
+    def unpack(self, payload):
+        from dvslam_amd.glue import unpack_keyframe
+        return unpack_keyframe(payload)
+
+    def associate(self, *a):
+        return self.g.associate(*a)
+
+    def solve_ba(self, prob, iters):
+        b = self._ba.BAProblem(prob)
+        s = b.solve_device(iters)
+        return s, b.parameters()
+
+
+class CpuStages:
+    """the same stages on the CPU oracle (tests/oracle_bindings.py): the checker, and the CPU reference of the comparison"""
+    name = "cpu"
+
+    def __init__(self, nfeatures):
+        import oracle_bindings as ob
+        self.ob = ob
+        self.orb = ob.OracleORB(nfeatures, 1.2, 8, 20, 7)
+
+    def extract(self, gray):
+        n, k, d = self.orb.extract(gray)
+        return k, d
+
+    def filter_depth(self, k, d, depth):
+        return self.ob.filter_depth(k, d, depth)[:2]
+
+    def match(self, q, t):
+        return self.ob.match(q, t)
+
+    def fundamental_inliers(self, p1, p2, seed):
+        return self.ob.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, seed)[1].astype(bool)
+
+    def pnp(self, obj, img, K4, seed):
+        ok, rvec, tvec, inl, sel = self.ob.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
+        return ok, rvec, tvec, len(inl)
+
+    def publish(self, *a, **kw):
+        return self.ob.publish_keyframe(*a, **kw)[0]
+
+    def unpack(self, payload):
+        return self.ob.unpack_keyframe(payload)
+
+    def associate(self, *a):
+        return self.ob.associate(*a)
+
+    def solve_ba(self, prob, iters):
+        o = self.ob.OracleBA(prob)
+        s = o.solve(iters)
+        return s, o.parameters()
+
+
+def pts_of(kps, idx):
+    return np.stack([kps["x"][idx], kps["y"][idx]], 1).astype(np.float32)
+
+
+def track(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every=10, verbose=False, frames=None):
+    """runs the sequence through `stages`; returns the per-frame visual-odometry poses (camera-to-world, frame 0 = identity),
+    keyframe list, backend results"""
+    from dvslam_amd import synth
+    cx, cy = cols / 2.0, rows / 2.0
+    K4 = np.array([f, f, cx, cy])
+    depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    R_, t_ = np.eye(3), np.zeros(3)                       # Frontend::R_, t_ (frontend.cpp:162-163)
+    poses = []
+    prev_k = prev_d = None
+    last_kf_k = last_kf_d = None
+    since_kf = 0
+    kf_frames, kf_payloads, kf_poses = [], [], []
+    stats = dict(matches=[], geometric=[], pnp_inliers=[], pose_updates=0, motion_outliers=0, pnp_failures=0)
+    t_stage = 0.0
+    for t in range(n_frames):
+        gray = frames[t] if frames is not None else synth.make_traj_frame(t, cols, rows)
+        t0 = time.perf_counter()
+        k, d = stages.extract(gray)
+        fk, fd = stages.filter_depth(k, d, depth)         # filterDepth (:1100)
+        publish = None
+        if prev_k is None:                                # first frame (:1285-1300): becomes the first keyframe
+            backend_k, backend_d = fk, fd
+            publish = True
+        else:
+            idx, dist = stages.match(fd, prev_d)          # :1123
+            q = np.nonzero(dist < 50)[0]                  # :1126-1132
+            tr = idx[q]
+            stats["matches"].append(len(q))
+            if len(q) >= 8:                               # :1136-1153
+                m = stages.fundamental_inliers(pts_of(prev_k, tr), pts_of(fk, q), seed=2 * t)
+                q, tr = q[m], tr[m]
+            stats["geometric"].append(len(q))
+            # feature culling (:1171-1219)
+            matched = set(q.tolist())
+            order = list(q)
+            un = [i for i in range(len(fk)) if i not in matched]
+            un.sort(key=lambda i: -float(fk["response"][i]))
+            order += [i for i in un[:200] if fk["response"][i] >= 50.0][:200]
+            sel = np.array(order, np.int64)
+            backend_k, backend_d = fk[sel], fd[sel]
+            # estimateCameraPose (:843-962)
+            if len(q) >= 5:
+                pp = pts_of(prev_k, tr); cp = pts_of(fk, q)
+                xi = np.floor(pp[:, 0] + 0.5).astype(np.int64); yi = np.floor(pp[:, 1] + 0.5).astype(np.int64)   # std::round, positive coordinates
+                inb = (xi >= 0) & (yi >= 0) & (xi < cols) & (yi < rows)
+                dp = np.zeros(len(pp), np.float32)
+                dp[inb] = depth[yi[inb], xi[inb]].astype(np.float32) * np.float32(0.001)
+                ok = inb & ~((dp <= np.float32(0.3)) | (dp > np.float32(3.0)))
+                obj = np.stack([(pp[:, 0] - np.float32(cx)) * dp / np.float32(f), (pp[:, 1] - np.float32(cy)) * dp / np.float32(f), dp], 1)[ok]
+                img = cp[ok]
+                if len(obj) >= 6:
+                    good, rvec, tvec, nin = stages.pnp(obj, img, K4, seed=2 * t + 1)
+                    if good:
+                        stats["pnp_inliers"].append(nin)
+                        Rr = rodrigues_to_R(rvec)
+                        Ri, ti = Rr.T, -Rr.T @ tvec
+                        if np.linalg.norm(ti) > 0.5 or rot_angle(Ri) > 0.2:      # isMotionOutlier (:549-570)
+                            stats["motion_outliers"] += 1
+                        else:
+                            t_ = t_ + R_ @ ti
+                            R_ = R_ @ Ri
+                            stats["pose_updates"] += 1
+                    else:
+                        stats["pnp_failures"] += 1
+            # isKeyframe (:601-662)
+            crit = False
+            if last_kf_d is not None and len(last_kf_d) and len(backend_d):
+                ki, kd = stages.match(backend_d, last_kf_d)
+                kq = np.nonzero(kd < 50)[0]
+                ktr = ki[kq]
+                if len(kq) >= 8:
+                    km = stages.fundamental_inliers(pts_of(last_kf_k, ktr), pts_of(backend_k, kq), seed=2 * t + 1000003)
+                    kq = kq[km]
+                crit = len(kq) < 150
+            if crit or since_kf > 30:
+                since_kf = 0; publish = True
+            else:
+                since_kf += 1; publish = False
+        if publish:
+            last_kf_k, last_kf_d = backend_k, backend_d
+            payload = stages.publish(backend_k, backend_d, depth, f, f, cx, cy, R_, t_, stamp=(t, 0), frame_id="camera_link", keyframe_id=len(kf_frames),
+                                     q_xyzw=quat_xyzw(R_))
+            kf_frames.append(t); kf_payloads.append(payload); kf_poses.append((R_.copy(), t_.copy()))
+        prev_k, prev_d = fk, fd
+        t_stage += time.perf_counter() - t0
+        poses.append((R_.copy(), t_.copy()))
+        if verbose and t % 100 == 0:
+            print(f"[{stages.name}] frame {t}: {len(fk)} keypoints, {len(kf_frames)} keyframes", flush=True)
+    backend = run_backend(stages, kf_payloads, kf_poses, f, cx, cy, ba_every)
+    return dict(poses=poses, keyframes=kf_frames, stats=stats, backend=backend, seconds_in_stages=t_stage)
+
+
+def run_backend(stages, payloads, kf_poses, f, cx, cy, ba_every, window=5, max_iterations=20):
+    """Backend::syncCallback's association + landmark database, and SlidingWindowBA::optimize over the last `window` keyframes
+    every `ba_every` keyframes (backend.cpp:895-960; the optimised poses replace the stored keyframe poses, :1356-1392)"""
+    db_xyz, db_desc = np.zeros((0, 3), np.float32), np.zeros((0, 32), np.uint8)
+    kf_R, kf_t, obs_by_kf, assoc, ba_runs = [], [], [], [], []
+    for k, payload in enumerate(payloads):
+        msg = stages.unpack(payload)
+        Rk, Tk = kf_poses[k]
+        px = msg["obs_pixels"].astype(np.float32)
+        best = (stages.associate(msg["obs_desc"], px, db_desc, db_xyz, Rk, Tk, f, f, cx, cy, 50.0, 5.0) if len(db_xyz)
+                else np.full(len(px), -1, np.int32))
+        taken, new_xyz, new_desc, obs, n_assoc = set(), [], [], [], 0
+        for i in range(len(px)):
+            j = int(best[i])
+            if j >= 0 and j not in taken:
+                taken.add(j); lid = j; n_assoc += 1
+            else:
+                lid = len(db_xyz) + len(new_xyz)
+                new_xyz.append(msg["landmark_xyz"][i]); new_desc.append(msg["obs_desc"][i])
+            obs.append((float(px[i, 0]), float(px[i, 1]), lid))
+        if new_xyz:
+            db_xyz = np.vstack([db_xyz, np.asarray(new_xyz, np.float32)]); db_desc = np.vstack([db_desc, np.asarray(new_desc, np.uint8)])
+        kf_R.append(Rk.copy()); kf_t.append(Tk.copy()); obs_by_kf.append(obs); assoc.append(n_assoc)
+        if ba_every and (k + 1) % ba_every == 0 and k + 1 >= 2:
+            win = list(range(max(0, k + 1 - window), k + 1))
+            seen = {}
+            for w in win:
+                for (_, _, lid) in obs_by_kf[w]:
+                    seen[lid] = seen.get(lid, 0) + 1
+            lids = sorted(l for l, c in seen.items() if c >= 2)
+            if len(lids) < 10:
+                continue
+            slot = {l: i for i, l in enumerate(lids)}
+            q = np.zeros((len(win), 4)); tt = np.zeros((len(win), 3))
+            for wi, w in enumerate(win):                  # CameraPose::fromRt: world->camera quaternion (w, x, y, z) + translation
+                Rcw = kf_R[w].T
+                xyzw = quat_xyzw(Rcw)
+                q[wi] = [xyzw[3], xyzw[0], xyzw[1], xyzw[2]]; tt[wi] = -Rcw @ kf_t[w]
+            cam, lm, uv = [], [], []
+            for wi, w in enumerate(win):
+                for (u, v, lid) in obs_by_kf[w]:
+                    if lid in slot:
+                        cam.append(wi); lm.append(slot[lid]); uv.append((u, v))
+            pf = np.zeros(len(win), np.uint8); pf[0] = 1
+            prob = dict(K=len(win), L=len(lids), q=q, t=tt, X=db_xyz[lids].astype(np.float64), cam_idx=np.array(cam, np.int32),
+                        lm_idx=np.array(lm, np.int32), uv=np.array(uv, np.float64), pose_fixed=pf, lm_fixed=np.zeros(len(lids), np.uint8),
+                        fx=f, fy=f, cx=cx, cy=cy, sigma=1.0, huber=1.345)
+            s, (qo, to, Xo) = stages.solve_ba(prob, max_iterations)
+            ba_runs.append(dict(keyframe=k, window=len(win), landmarks=len(lids), observations=len(cam), termination=int(s.termination),
+                                steps=int(s.num_successful_steps), initial_cost=float(s.initial_cost), final_cost=float(s.final_cost)))
+            if s.termination == 0:                        # updateOptimizedResults only on success (backend.cpp:967)
+                for wi, w in enumerate(win):
+                    ww, x, y, z = qo[wi] / np.linalg.norm(qo[wi])
+                    Rcw = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                                    [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                                    [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+                    kf_R[w] = Rcw.T; kf_t[w] = -Rcw.T @ to[wi]
+                db_xyz[lids] = Xo.astype(np.float32)
+    return dict(landmarks=int(len(db_xyz)), associations=assoc, ba=ba_runs, kf_R=kf_R, kf_t=kf_t)
+
+
+def ground_truth(n_frames, f, z0):
+    from dvslam_amd import synth
+    R0, T0 = synth.traj_pose(0, f, z0)
+    out = []
+    for t in range(n_frames):
+        R, T = synth.traj_pose(t, f, z0)
+        out.append((R0.T @ R, R0.T @ (T - T0)))            # relative to frame 0, where the frontend starts from identity
+    return out
+
+
+def rmse(a, b):
+    e = [np.linalg.norm(pa[1] - pb[1]) for pa, pb in zip(a, b)]
+    r = [np.degrees(rot_angle(pa[0].T @ pb[0])) for pa, pb in zip(a, b)]
+    return dict(translation_m=float(np.sqrt(np.mean(np.square(e)))), rotation_deg=float(np.sqrt(np.mean(np.square(r)))),
+                max_translation_m=float(np.max(e)), max_rotation_deg=float(np.max(r)))
+
+
+def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_every=5, with_cpu=True, verbose=False):
+    from dvslam_amd import synth
+    frames = [synth.make_traj_frame(t, cols, rows) for t in range(n_frames)]
+    gt = ground_truth(n_frames, f, z0)
+    res = dict(config=dict(frames=n_frames, resolution=[cols, rows], nfeatures=nfeatures, focal_px=f, plane_depth_m=z0, ba_every_keyframes=ba_every,
+                           ransac="findFundamentalMat(RANSAC, 2 px, 0.99) / solvePnPRansac(100, 4 px, 0.99), seeds = frame index"))
+    t0 = time.perf_counter()
+    hip = track(HipStages(nfeatures), n_frames, cols, rows, f, z0, nfeatures, ba_every, verbose, frames)
+    res["hip"] = dict(wall_s=time.perf_counter() - t0, ms_per_frame_in_stages=1e3 * hip["seconds_in_stages"] / n_frames,
+                      keyframes=len(hip["keyframes"]), rmse_vs_ground_truth=rmse(hip["poses"], gt),
+                      median_matches=float(np.median(hip["stats"]["matches"])), median_geometric=float(np.median(hip["stats"]["geometric"])),
+                      median_pnp_inliers=float(np.median(hip["stats"]["pnp_inliers"])), pose_updates=hip["stats"]["pose_updates"],
+                      motion_outliers=hip["stats"]["motion_outliers"], pnp_failures=hip["stats"]["pnp_failures"],
+                      landmarks=hip["backend"]["landmarks"], ba_runs=len(hip["backend"]["ba"]),
+                      ba_converged=sum(1 for b in hip["backend"]["ba"] if b["termination"] == 0))
+    if with_cpu:
+        t0 = time.perf_counter()
+        cpu = track(CpuStages(nfeatures), n_frames, cols, rows, f, z0, nfeatures, ba_every, verbose, frames)
+        res["cpu"] = dict(wall_s=time.perf_counter() - t0, ms_per_frame_in_stages=1e3 * cpu["seconds_in_stages"] / n_frames,
+                          keyframes=len(cpu["keyframes"]), rmse_vs_ground_truth=rmse(cpu["poses"], gt), landmarks=cpu["backend"]["landmarks"],
+                          ba_runs=len(cpu["backend"]["ba"]), ba_converged=sum(1 for b in cpu["backend"]["ba"] if b["termination"] == 0))
+        res["hip_vs_cpu"] = dict(rmse=rmse(hip["poses"], cpu["poses"]), same_keyframes=hip["keyframes"] == cpu["keyframes"],
+                                 keyframes_in_common=len(set(hip["keyframes"]) & set(cpu["keyframes"])))
+        res["_raw"] = dict(hip=hip, cpu=cpu)
+    else:
+        res["_raw"] = dict(hip=hip)
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import torch  # noqa: F401  (one ROCm stack per process: tests/conftest.py)
+    r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True)
+    r.pop("_raw")
+    print(json.dumps(r, indent=1))
+    if a.out:
+        json.dump(r, open(a.out, "w"), indent=1)
