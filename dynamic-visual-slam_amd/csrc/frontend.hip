@@ -478,10 +478,17 @@ dvs_status dvs_backproject(dvs_matcher* ctx, const dvs_keypoint* kps, int32_t n,
   return DVS_OK;
 }
 
-dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
-                         const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
-                         double max_descriptor_distance, double max_reprojection_distance, int32_t* best) {
+// snapshot association; optionally also hands back every observation's candidate list (landmarks with Hamming distance below the
+// gate, in landmark order) so that a caller applying associations ONE BY ONE — the reference re-triangulates a landmark after each
+// association (backend.cpp:758-777), which can move it before a later observation of the same keyframe is tested — re-evaluates
+// exactly the observations whose candidates changed (include/dvslam/association.hpp)
+static dvs_status associate_impl(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                                 const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
+                                 double max_descriptor_distance, double max_reprojection_distance, int32_t* best, int64_t* cand_offsets,
+                                 int32_t* cand_lm, int64_t cand_cap, int64_t* n_cand) {
   DVS_ARG(ctx && nobs >= 0 && nlm >= 0);
+  if (n_cand) *n_cand = 0;
+  if (cand_offsets) for (int i = 0; i <= nobs; i++) cand_offsets[i] = 0;
   if (nobs == 0) return DVS_OK;
   DVS_ARG(obs_desc && obs_px && best && R && t);
   for (int i = 0; i < nobs; i++) best[i] = -1;
@@ -493,6 +500,7 @@ dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float*
   const int thr = (int)std::min<double>(ceil(max_descriptor_distance), 257.0);
   const long long* d_offs; const int* d_pairs; long long total = 0;
   DVS_TRY(matcher_thresh_device(ctx, obs_desc, nobs, lm_desc, nlm, thr, &d_offs, &d_pairs, &total));
+  if (n_cand) *n_cand = total;
   if (total == 0) return DVS_OK;
   uint8_t* base;
   const size_t pb = ((size_t)nobs * 8 + 15) & ~(size_t)15, lb = ((size_t)nlm * 12 + 15) & ~(size_t)15;
@@ -510,7 +518,35 @@ dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float*
   DVS_HIP(hipGetLastError());
   DVS_HIP(hipMemcpyAsync(best, d_best, (size_t)nobs * 4, hipMemcpyDeviceToHost, st));
   DVS_HIP(hipStreamSynchronize(st));
+  if (cand_offsets) {
+    static_assert(sizeof(long long) == sizeof(int64_t), "offset width");
+    DVS_HIP(hipMemcpy(cand_offsets, d_offs, ((size_t)nobs + 1) * 8, hipMemcpyDeviceToHost));
+    if (cand_lm && total <= cand_cap) {
+      std::vector<int> tri((size_t)total * 3);
+      DVS_HIP(hipMemcpy(tri.data(), d_pairs, tri.size() * 4, hipMemcpyDeviceToHost));
+      for (long long p = 0; p < total; p++) cand_lm[p] = tri[3 * (size_t)p + 1];
+    } else if (cand_lm) {
+      set_error("candidate list needs %lld entries, capacity %lld", total, (long long)cand_cap);
+      return DVS_ERR_CAPACITY;
+    }
+  }
   return DVS_OK;
+}
+
+dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                         const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
+                         double max_descriptor_distance, double max_reprojection_distance, int32_t* best) {
+  return associate_impl(ctx, obs_desc, obs_px, nobs, lm_desc, lm_xyz, nlm, R, t, fx, fy, cx, cy, max_descriptor_distance, max_reprojection_distance, best,
+                        nullptr, nullptr, 0, nullptr);
+}
+
+dvs_status dvs_associate_candidates(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                                    const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx,
+                                    double cy, double max_descriptor_distance, double max_reprojection_distance, int32_t* best,
+                                    int64_t* cand_offsets, int32_t* cand_lm, int64_t cand_cap, int64_t* n_cand) {
+  DVS_ARG(cand_offsets && n_cand);
+  return associate_impl(ctx, obs_desc, obs_px, nobs, lm_desc, lm_xyz, nlm, R, t, fx, fy, cx, cy, max_descriptor_distance, max_reprojection_distance, best,
+                        cand_offsets, cand_lm, cand_cap, n_cand);
 }
 
 

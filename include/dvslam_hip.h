@@ -290,6 +290,16 @@ dvs_status dvs_associate(dvs_matcher* ctx, const uint8_t* obs_desc, const float*
                          const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx, double cy,
                          double max_descriptor_distance, double max_reprojection_distance, int32_t* best);
 
+/* The same, plus every observation's candidate list: cand_lm[cand_offsets[i] .. cand_offsets[i + 1]) = the landmarks with Hamming
+ * distance < max_descriptor_distance for observation i, in landmark order (cand_offsets: nobs + 1 entries; *n_cand = total; if
+ * it exceeds cand_cap nothing is written to cand_lm and DVS_ERR_CAPACITY is returned with *n_cand set).  The reference applies
+ * associations one by one and re-triangulates the landmark after each (backend.cpp:758-777): include/dvslam/association.hpp
+ * uses the lists to re-evaluate exactly the observations whose candidates moved, in observation order. */
+dvs_status dvs_associate_candidates(dvs_matcher* ctx, const uint8_t* obs_desc, const float* obs_px, int32_t nobs, const uint8_t* lm_desc,
+                                    const float* lm_xyz, int32_t nlm, const double* R, const double* t, double fx, double fy, double cx,
+                                    double cy, double max_descriptor_distance, double max_reprojection_distance, int32_t* best,
+                                    int64_t* cand_offsets, int32_t* cand_lm, int64_t cand_cap, int64_t* n_cand);
+
 /* ======================================= B3: bundle adjustment ================================= */
 
 typedef struct dvs_ba dvs_ba;

@@ -46,6 +46,28 @@ def test_opencv_typed_adapters_run_on_gpu(tmp_path, gpu, hiplib):
     assert "opencv-typed adapters ok" in out.stdout
 
 
+def _build_cpp(tmpdir, src, name):
+    exe = os.path.join(str(tmpdir), name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", src),
+                           "-o", exe, "-L" + LIBDIR, "-ldvslam_hip", "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_sequential_association_adapter_compiles(tmp_path, hiplib):
+    from dvslam_amd import device_count
+    assert subprocess.call([_build_cpp(tmp_path, "association_seq.cpp", "association_seq")]) == (0 if device_count() > 0 else 3)
+
+
+@pytest.mark.gpu
+def test_sequential_association_matches_the_one_by_one_loop(tmp_path, gpu, hiplib):
+    """backend.cpp:735-797: an association re-triangulates its landmark before the next observation is tested.  Two observations of
+    one keyframe choose landmark 5; after the first moved it, the second must fall to the twin landmark — and the whole keyframe
+    must come out exactly as a literal one-by-one loop over a live database gives it (include/dvslam/association.hpp)"""
+    out = subprocess.run([_build_cpp(tmp_path, "association_seq.cpp", "association_seq")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter vs sequential loop: 0 differences" in out.stdout and "obs1 -> 210 (snapshot 5)" in out.stdout
+
+
 def test_adapters_compile_and_refuse_without_gpu(tmp_path, hiplib):
     from dvslam_amd import device_count
     exe = _build_adapter_smoke(tmp_path, hiplib)
