@@ -111,9 +111,13 @@ print("rank", rank, "ok")
 def test_boundary_exchange_two_gloo_ranks(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    import socket
+    with socket.socket() as so:     # a free port: a fixed one may still sit in TIME_WAIT from the previous test run
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29631", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+                          "--master-port", port, str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
 
