@@ -202,6 +202,86 @@ def make_batches(synth, torch, dev, B, NB, rank, rows, cols, distinct):
     return d, NB * B
 
 
+def level_sharded_bench(args, world, rank, local, dev):
+    """SURVEY.md section 8e, small batches: the SAME `--batch` frames on every rank (the broadcast of level 0 is the caller's and
+    outside the timed region, like the resident input of the frame-sharded mode), levels sharded over the ranks, one all-gather
+    per step, merge on every rank; the sequence match is split contiguously over the ranks (pair t on rank t*world//B)."""
+    import torch
+    import torch.distributed as dist
+    import dvslam_amd
+    from dvslam_amd import synth
+    from dvslam_amd import dist as dvdist
+    rows, cols, B, NB = 720, 1280, args.batch, max(1, args.resident_batches)
+    d_img, frames_distinct = make_batches(synth, torch, dev, B, NB, 0, rows, cols, True)     # rank 0's seed on every rank
+    orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
+    ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
+    mat = dvslam_amd.BFMatcher(device=local, stream=ts.cuda_stream)
+    cap = orb.capacity
+    with torch.cuda.stream(ts):
+        kps = torch.empty((B, cap, 28), dtype=torch.uint8, device=dev); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(B, dtype=torch.int32, device=dev)
+        idx = torch.empty((B, cap), dtype=torch.int32, device=dev); dst = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
+        def bcast_id(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = dvdist.Comm(local, rank, world, bcast_id)
+        print(f"[bench] rank {rank}: RCCL communicator of {world} ranks (version {comm.rccl_version})", file=sys.stderr, flush=True)
+    lx = dvdist.LevelShardedExtractor(orb, comm, rank, world, rows, cols, B)
+    p0, p1 = rank * B // world, (rank + 1) * B // world       # this rank's match pairs (t, t-1), t in [max(p0,1), p1)
+    state = {"i": 0}
+
+    def step():
+        i = state["i"]; state["i"] += 1
+        with torch.cuda.stream(ts):
+            lx.extract(d_img[i % NB].data_ptr(), rows, cols, cols, rows * cols, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr())
+        t0 = max(p0, 1)
+        if p1 > t0:
+            mat.match_sequence_device(desc[t0].data_ptr(), n[t0:].data_ptr(), cap, p1 - t0, desc[t0 - 1].data_ptr(), n[t0 - 1:].data_ptr(),
+                                      idx[t0].data_ptr(), dst[t0].data_ptr())
+
+    def barrier():
+        ts.synchronize(); torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec ORB+match @1280x720x2000kp", "value": round(B * args.steps / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1280x720 gray frames, ORBextractor(2000,1.2,8,20,7) extract + BFMatcher(HAMMING) match vs previous frame, "
+                                   "small batch", "frames_per_step_total": B, "frames_distinct": frames_distinct,
+                       "parallelism": f"level-sharded x{world}: masks {[hex(m) for m in lx.masks]}, all_gather of {lx.block_bytes} B blocks, merge on "
+                                      f"every rank", "keypoints_frame0": int(n[0].item())},
+            "rccl": None if comm is None else {"nranks": world, "version": comm.rccl_version}}), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +301,9 @@ def main():
                     help="build every batch's pyramid inside its own step (default: the next batch's pyramid overlaps this batch's "
                          "FAST, dvs_orb_hint_next_batch_device)")
     ap.add_argument("--torch-exchange", action="store_true", help="exchange through torch.distributed (dist.py) instead of the C-ABI")
+    ap.add_argument("--shard", choices=("frames", "levels"), default="frames",
+                    help="levels: SURVEY.md section 8e's small-batch mode (use with --batch < 8): every rank holds the same frames, extracts its "
+                         "own pyramid levels, one all-gather of level-slotted blocks, on-device merge; total work fixed (strong scaling)")
     ap.add_argument("--dry-launch", action="store_true", help="only start the ranks and report them (no GPU work): launcher self-test")
     args = ap.parse_args()
 
@@ -243,6 +326,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.shard == "levels":
+        return level_sharded_bench(args, world, rank, local, dev)
     rows, cols, B = 720, 1280, args.batch
     NB = 1 if args.single_resident_batch else max(1, args.resident_batches)
     # synthetic input, resident in HBM before the timed region: this rank's shard of NB global batches

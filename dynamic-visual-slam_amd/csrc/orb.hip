@@ -440,9 +440,10 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
 }
 
 // the level chain: level l from level l-1 (ORBextractor.cpp:1171-1192) into `pyr`, one launch per level on `pst`
-dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr, hipStream_t pst, bool level_events) {
+dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr, hipStream_t pst, bool level_events, int top_level = -1) {
   const Geom& G = h->geom;
-  for (int l = 1; l < G.nlevels; l++) {
+  const int last = top_level < 0 ? G.nlevels - 1 : std::min(top_level, G.nlevels - 1);   // level sharding: only up to the highest level owned
+  for (int l = 1; l <= last; l++) {
     const LevelGeom& S = G.lv[l - 1];
     const LevelGeom& D = G.lv[l];
     const u8* sp = l == 1 ? src.img0 : pyr + S.off;
@@ -493,8 +494,12 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // few frames (the live one-frame-per-callback pattern): the launch chain, not the arithmetic, sets the latency -> all levels in
   // one launch (0.31 -> 0.25 ms per 1280x720 frame); larger batches keep the per-level chain that runs beside FAST
   const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 8;  // measured: +26 % at 2, +12 % at 8, -2 % at 16 frames
-  const bool cascade = !prefetched && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
-  const bool ov = !prefetched && !cascade && h->overlap && G.nlevels >= 2;
+  const uint32_t allLevels = G.nlevels >= 32 ? ~0u : ((1u << G.nlevels) - 1u);
+  const bool sharded = (src.levelMask & allLevels) != allLevels || src.slotted;   // level-sharded call: the chain up to its top level, its levels only
+  int topLevel = 0;
+  for (int l = 0; l < G.nlevels; l++) if ((src.levelMask >> l) & 1u) topLevel = l;
+  const bool cascade = !prefetched && !sharded && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
+  const bool ov = !prefetched && !cascade && !sharded && h->overlap && G.nlevels >= 2;
   hipStream_t pst = st;
   if (prefetched) {
     // nothing to build
@@ -511,7 +516,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
       DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
     }
     h->timer.begin(DVS_STAGE_PYRAMID, pst);
-    DVS_TRY(launch_pyramid_chain(h, src, nimg, h->d_pyr, pst, ov));
+    DVS_TRY(launch_pyramid_chain(h, src, nimg, h->d_pyr, pst, ov, sharded ? topLevel : -1));
     h->timer.end(pst);
   }
   // the next batch's pyramid (if announced) runs on the auxiliary stream beside THIS batch's FAST: the chain is latency-bound
@@ -592,6 +597,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
         launch_fast(src, st, h->cset, G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
         h->timer.end(st);
       }
+    } else if (sharded) {
+      h->timer.begin(DVS_STAGE_FAST, st);
+      for (int l = 0; l < G.nlevels; l++)
+        if ((src.levelMask >> l) & 1u) launch_fast(src, st, h->cset, G.lv[l].cellBase, G.lv[l].cellBase + G.lv[l].nCells);
+      h->timer.end(st);
     } else {
       h->timer.begin(DVS_STAGE_FAST, st);
       launch_fast(src, st, h->cset, 0, G.totalCells);
@@ -612,7 +622,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
   // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
   hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(h->env_oct_threads ? h->env_oct_threads : kOctTMax), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
-                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap);
+                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
   if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
@@ -815,10 +825,58 @@ dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32
   DVS_HIP(hipSetDevice(h->device));
   DVS_TRY(ensure_workspace(h, rows, cols));
   if (nimg == 0) return DVS_OK;
-  ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr};
+  ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr, ~0u, 0};
   const u8* next = h->next_hint;
   h->next_hint = nullptr;
   return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out, next);
+}
+
+// ---- level-sharded extraction -----------------------------------------------------------------------------------
+static LevelBlockLayout level_block_layout(const dvs_orb* h, int nimg) {
+  LevelBlockLayout Y{};
+  Y.nl = h->prm.nlevels;
+  int off = 0;
+  for (int l = 0; l < Y.nl; l++) { Y.kpOff[l] = off; off += h->feat_per_level[l] + 4; }   // = LevelGeom::kpOff (build_geometry)
+  Y.kpBlock = off;
+  Y.kpsOff = align_up((uint64_t)nimg * Y.nl * 4, 64);
+  Y.descOff = Y.kpsOff + align_up((uint64_t)nimg * Y.kpBlock * sizeof(dvs_keypoint), 64);
+  Y.blockBytes = Y.descOff + align_up((uint64_t)nimg * Y.kpBlock * 32, 64);
+  return Y;
+}
+
+size_t dvs_orb_level_block_bytes(const dvs_orb* h, int32_t nimg) { return h && nimg > 0 ? (size_t)level_block_layout(h, nimg).blockBytes : 0; }
+
+dvs_status dvs_orb_extract_levels_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                         size_t frame_stride, uint32_t level_mask, uint8_t* d_block) {
+  DVS_ARG(h && d_block && nimg >= 0);
+  if (!d_imgs || rows <= 0 || cols <= 0) { set_error("empty image"); return DVS_ERR_EMPTY; }
+  DVS_ARG(step >= (size_t)cols && ((uintptr_t)d_block) % 16 == 0);
+  if (nimg > h->max_batch) { set_error("nimg %d exceeds max_batch %d", nimg, h->max_batch); return DVS_ERR_CAPACITY; }
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_TRY(ensure_workspace(h, rows, cols));
+  if (nimg == 0) return DVS_OK;
+  const LevelBlockLayout Y = level_block_layout(h, nimg);
+  if (Y.kpBlock != h->geom.kpBlock) { set_error("level block layout mismatch"); return DVS_ERR_ARG; }
+  const uint32_t all = h->prm.nlevels >= 32 ? ~0u : ((1u << h->prm.nlevels) - 1u);
+  ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr, level_mask & all, 1};
+  h->next_hint = nullptr;
+  return enqueue_extract(h, src, nimg, (dvs_keypoint*)(d_block + Y.kpsOff), d_block + Y.descOff, Y.kpBlock, (int*)d_block, nullptr);
+}
+
+dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int32_t world, const int32_t* level_owner, int32_t nimg,
+                                       dvs_keypoint* d_kps, uint8_t* d_desc, int32_t capacity, int32_t* d_n_out) {
+  DVS_ARG(h && d_blocks && level_owner && d_kps && d_desc && d_n_out && world >= 1 && nimg >= 0);
+  if (capacity < dvs_orb_max_keypoints(h)) { set_error("capacity %d < %d", capacity, dvs_orb_max_keypoints(h)); return DVS_ERR_CAPACITY; }
+  if (nimg == 0) return DVS_OK;
+  DVS_HIP(hipSetDevice(h->device));
+  LevelBlockLayout Y = level_block_layout(h, nimg);
+  for (int l = 0; l < Y.nl; l++) {
+    DVS_ARG(level_owner[l] >= 0 && level_owner[l] < world);
+    Y.owner[l] = level_owner[l];
+  }
+  hipLaunchKernelGGL(k_merge_levels, dim3((Y.kpBlock + 255) / 256, nimg), dim3(256), 0, h->stream, Y, d_blocks, nimg, d_kps, d_desc, capacity, d_n_out);
+  DVS_HIP(hipGetLastError());
+  return DVS_OK;
 }
 
 dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs) {
@@ -844,7 +902,7 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
     for (int i = 0; i < nb; i++)
       DVS_HIP(hipMemcpy2DAsync(h->d_pyr + (uint64_t)i * G.frameBytes + G.lv[0].off, G.lv[0].pitch, imgs[b0 + i], step, cols, rows,
                                hipMemcpyHostToDevice, h->stream));
-    ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr};
+    ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr, ~0u, 0};
     DVS_TRY(enqueue_extract(h, src, nb, h->d_kps, h->d_desc, cap, h->d_nout));
     DVS_HIP(hipMemcpyAsync(h->h_nout, h->d_nout, nb * 4, hipMemcpyDeviceToHost, h->stream));
     DVS_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nb * cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream));

@@ -28,6 +28,11 @@ struct ImgSrc {
   uint64_t step0;     // bytes between rows of level 0
   uint64_t fstride0;  // bytes between frames of level 0
   u8* pyr;            // levels >= 1: pyr + f * frameBytes + lv[l].off
+  // level-sharded extraction (small batches on several GPUs): only the levels in levelMask are processed, and the
+  // descriptor stage writes keypoint i of level l to the fixed slot lv[l].kpOff + i of a level-slotted block instead of the
+  // level-major compacted position (the other ranks' levels are gathered around it, dvs_orb_merge_levels_device)
+  uint32_t levelMask; // bit l = level l is processed here (all ones: the whole frame)
+  int32_t slotted;    // 1: slotted output + per-level counts, 0: the reference's compacted output + total
 };
 
 __device__ __forceinline__ const u8* level_ptr(const Geom* g, const ImgSrc& s, int f, int l, int& pitch) {
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
-                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap) {
+                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int wsum[kOctTMax / 64 + 1];
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
@@ -1240,6 +1245,10 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   const int tid = threadIdx.x;
   const int level = blockIdx.x, f = blockIdx.y;
   if (tid >= OCT_T) return;  // wavefronts this level does not use leave before the first barrier
+  if (!((levelMask >> level) & 1u)) {  // a level another rank owns: no keypoints from here
+    if (tid == 0) { lvlKpCount[f * g->nlevels + level] = 0; candTotal[f * g->nlevels + level] = 0; }
+    return;
+  }
   const LevelGeom& L = g->lv[level];
 
   QtShared sh;
@@ -1487,6 +1496,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, const 
   __shared__ uint16_t hb[22][64];
   const BlurTile t = tiles[blockIdx.x];
   const int f = blockIdx.y;
+  if (!((src.levelMask >> t.level) & 1u)) return;
   const LevelGeom& L = g->lv[t.level];
   int pitch;
   const u8* img = level_ptr(g, src, f, t.level, pitch);
@@ -1544,6 +1554,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: strip geometry in SGPRs
   if (wi >= nstrips) return;
   const BlurStrip s = strips[wi];
+  if (!((src.levelMask >> s.level) & 1u)) return;
   const int lane = lane_id();
   const int f = blockIdx.y;
   const LevelGeom& L = g->lv[s.level];
@@ -1699,9 +1710,13 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int* cnt = lvlKpCount + f * nl;
   const int slot0 = (bx * 4 + wv) * kDescKP;
   if (MODE != 1 && bx == 0 && threadIdx.x == 0) {
-    int total = 0;
-    for (int l = 0; l < nl; l++) total += cnt[l];
-    nOut[f] = min(total, capacity);
+    if (src.slotted) {
+      for (int l = 0; l < nl; l++) nOut[f * nl + l] = cnt[l];   // per-level counts of the slotted block
+    } else {
+      int total = 0;
+      for (int l = 0; l < nl; l++) total += cnt[l];
+      nOut[f] = min(total, capacity);
+    }
   }
   if (slot0 >= g->kpBlock) return;
   // ---- slot resolve (lane & 7 = keypoint of the wave; lanes >= 8 repeat lanes 0..7)
@@ -1714,7 +1729,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   }
   const LevelGeom& L = g->lv[level];
   const int idx = slot - L.kpOff;
-  const int gi = pre + idx;
+  const int gi = src.slotted ? slot : pre + idx;
   const bool valid = slot0 + (lane & 7) < g->kpBlock && idx < cnt[level] && gi < capacity;
   if ((__ballot(valid) & 0xffull) == 0) return;
   const uint32_t pk = valid ? pkRaw : 0u;
@@ -1872,6 +1887,38 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
 #undef DVS_REQUEST_WINDOW
 #undef DVS_RL
 #undef DVS_RLP
+}
+
+// ---------------------------------------------------------------------------------------------
+// level-sharded extraction (SURVEY.md §8e "Partitioning", small batches): every rank extracted its levels into a level-slotted
+// block {counts[nimg][nl], keypoints[nimg][kpBlock], descriptors[nimg][kpBlock]}; after the all-gather each rank restores the
+// reference's level-major order: thread = (frame, slot) copies its 28 + 32 bytes from the block of the rank that owns the
+// slot's level to the compacted position (sum of the lower levels' counts + index)
+// ---------------------------------------------------------------------------------------------
+struct LevelBlockLayout { uint64_t blockBytes, kpsOff, descOff; int nl, kpBlock; int kpOff[DVS_MAX_LEVELS]; int owner[DVS_MAX_LEVELS]; };
+
+__global__ __launch_bounds__(256) void k_merge_levels(LevelBlockLayout Y, const u8* __restrict__ blocks, int nimg, dvs_keypoint* __restrict__ outKp,
+                                                      u8* __restrict__ outDesc, int capacity, int* __restrict__ nOut) {
+  const int f = blockIdx.y;
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  int level = 0, pre = 0, acc = 0, cntL = 0;
+  for (int l = 0; l < Y.nl; l++) {
+    const int c = reinterpret_cast<const int*>(blocks + (uint64_t)Y.owner[l] * Y.blockBytes)[f * Y.nl + l];
+    if (slot >= Y.kpOff[l]) { level = l; pre = acc; cntL = c; }
+    acc += c;
+  }
+  if (slot == 0) nOut[f] = min(acc, capacity);
+  if (slot >= Y.kpBlock) return;
+  const int idx = slot - Y.kpOff[level], gi = pre + idx;
+  if (idx >= cntL || gi >= capacity) return;
+  const u8* blk = blocks + (uint64_t)Y.owner[level] * Y.blockBytes;
+  const uint32_t* sk = reinterpret_cast<const uint32_t*>(blk + Y.kpsOff) + ((uint64_t)f * Y.kpBlock + slot) * 7;
+  uint32_t* dk = reinterpret_cast<uint32_t*>(outKp) + ((uint64_t)f * capacity + gi) * 7;
+#pragma unroll
+  for (int k = 0; k < 7; k++) dk[k] = sk[k];
+  const uint4* sd = reinterpret_cast<const uint4*>(blk + Y.descOff) + ((uint64_t)f * Y.kpBlock + slot) * 2;
+  uint4* dd = reinterpret_cast<uint4*>(outDesc) + ((uint64_t)f * capacity + gi) * 2;
+  dd[0] = sd[0]; dd[1] = sd[1];
 }
 
 }  // namespace dvs

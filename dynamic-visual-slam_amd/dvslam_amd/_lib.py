@@ -78,6 +78,9 @@ def lib():
     L.dvs_stream_synchronize.argtypes = [vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
+    L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
+    L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]
+    L.dvs_orb_merge_levels_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp]
     L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
     L.dvs_orb_get_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.dvs_orb_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]

@@ -12,6 +12,7 @@ Two implementations of the same block layout:
   and the gather buffer preallocated once."""
 import ctypes as C
 import os
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -131,3 +132,28 @@ class Comm:
         if self.h:
             self._L.dvs_comm_destroy(self.h)
             self.h = None
+
+
+class LevelShardedExtractor:
+    """SURVEY.md §8e, batches of fewer than 8 frames: every rank holds the same level-0 frames, extracts only its own pyramid
+    levels (dvs_orb_extract_levels_device, the resize chain rebuilt up to its top level), one in-place ncclAllGather of the
+    level-slotted blocks, then dvs_orb_merge_levels_device restores the reference's level-major order on every rank.  Results are
+    bit-identical to extract_batch_device (tests/test_gpu_orb.py).  `comm` is a Comm (or None with world == 1)."""
+
+    def __init__(self, orb, comm, rank: int, world: int, rows: int, cols: int, nimg: int):
+        from ._lib import DeviceBuffer
+        self.orb, self.comm, self.rank, self.world, self.nimg = orb, comm, rank, world, nimg
+        px = [int(np.prod(orb.level_size(rows, cols, l))) for l in range(orb.nlevels)]
+        self.masks = level_shards(px, world)
+        self.owner = np.array([next(r for r in range(world) if self.masks[r] >> l & 1) for l in range(orb.nlevels)], np.int32)
+        self.block_bytes = orb.level_block_bytes(nimg)
+        self.gather = DeviceBuffer(world * self.block_bytes, device=orb.device)
+
+    def extract(self, d_imgs, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout):
+        """asynchronous on the extractor's stream (the gather is enqueued on the same stream: it depends on the extraction and the
+        merge depends on it)"""
+        mine = self.gather.ptr + self.rank * self.block_bytes
+        self.orb.extract_levels_device(d_imgs, self.nimg, rows, cols, step, frame_stride, self.masks[self.rank], mine)
+        if self.world > 1:
+            self.comm.all_gather(self.orb.get_stream(), mine, self.gather.ptr, self.block_bytes)
+        self.orb.merge_levels_device(self.gather.ptr, self.world, self.owner, self.nimg, d_kps, d_desc, capacity, d_nout)

@@ -110,6 +110,19 @@ class ORBextractor:
         check(self._L.dvs_orb_extract_batch_device(self._h, d_imgs, nimg, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout))
         self._shape = (rows, cols)
 
+    def level_block_bytes(self, nimg):
+        return int(self._L.dvs_orb_level_block_bytes(self._h, nimg))
+
+    def extract_levels_device(self, d_imgs, nimg, rows, cols, step, frame_stride, level_mask, d_block):
+        """level-sharded extraction: this rank's levels into a level-slotted block; asynchronous"""
+        check(self._L.dvs_orb_extract_levels_device(self._h, d_imgs, nimg, rows, cols, step, frame_stride, level_mask, d_block))
+        self._shape = (rows, cols)
+
+    def merge_levels_device(self, d_blocks, world, level_owner, nimg, d_kps, d_desc, capacity, d_nout):
+        """gathered level-slotted blocks of all ranks -> the reference's level-major output; asynchronous"""
+        own = np.ascontiguousarray(level_owner, np.int32)
+        check(self._L.dvs_orb_merge_levels_device(self._h, d_blocks, world, ptr(own), nimg, d_kps, d_desc, capacity, d_nout))
+
     def synchronize(self):
         check(self._L.dvs_orb_synchronize(self._h))
 

@@ -120,6 +120,21 @@ dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32
  * ORBextractor.cpp:1081; this is the MI355X replacement for running consecutive frames on separate CPU threads.) */
 dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs);
 
+/* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
+ * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per
+ * level (ORBextractor.cpp:787, 894, 1123), so every rank takes the same frames and a subset of the LEVELS: it rebuilds the
+ * (cheap) level chain up to its highest level, runs FAST / quad-tree / blur / descriptors for its levels only and writes a
+ * level-slotted block {int32 counts[nimg][nlevels]; dvs_keypoint[nimg][K]; uint8 desc[nimg][K][32]}, K = sum(quota_l + 4), in which
+ * level l owns fixed slots.  One all-gather of the blocks (dvs_comm_all_gather) and dvs_orb_merge_levels_device then restore
+ * the reference's level-major output on every rank — bit-identical to dvs_orb_extract_batch_device.  level_mask: bit l = this
+ * rank owns level l (dvslam_amd.dist.level_shards balances them by pixel count). */
+size_t dvs_orb_level_block_bytes(const dvs_orb* h, int32_t nimg);
+dvs_status dvs_orb_extract_levels_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols, size_t step,
+                                         size_t frame_stride, uint32_t level_mask, uint8_t* d_block /* 16-byte aligned, level_block_bytes */);
+/* d_blocks: [world][dvs_orb_level_block_bytes] as gathered; level_owner[nlevels] (host): the rank whose block holds level l */
+dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int32_t world, const int32_t* level_owner, int32_t nimg,
+                                       dvs_keypoint* d_kps, uint8_t* d_desc, int32_t capacity, int32_t* d_n_out);
+
 /* parity introspection of the LAST extract call (mvImagePyramid is a public member, ORBextractor.hpp:84) */
 dvs_status dvs_orb_get_level(dvs_orb* h, int32_t frame, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes);
 /* FAST candidates handed to the quad-tree, in candidate order: int32 triplets (x, y, score), region-relative */

@@ -271,3 +271,37 @@ def test_randomized_configurations(gpu, oracle):
         g.close()
         done += 1
     assert done >= 25
+
+
+@pytest.mark.parametrize("world,rows,cols,nf,nimg", [(3, 480, 640, 1000, 2), (8, 720, 1280, 2000, 1), (2, 240, 320, 500, 3)])
+def test_level_sharded_extraction_equals_whole_frame_extraction(gpu, world, rows, cols, nf, nimg):
+    """SURVEY.md §8e, small batches: every rank extracts only its pyramid levels into a level-slotted block; the gathered blocks
+    merged (dvs_orb_merge_levels_device) are bit-identical to the unsharded extraction.  The `world` ranks run one after the other
+    on this one GPU, each with its own handle as on its own GPU; the all-gather itself is the plain byte gather covered by
+    test_comm_exchange_single_rank_on_gpu and the gloo tests."""
+    from dvslam_amd import ORBextractor, _lib
+    from dvslam_amd import dist as dvdist
+    frames = np.stack([synth.make_frame(3 + i, cols=cols, rows=rows) for i in range(nimg)])
+    d_img = _lib.DeviceBuffer(frames.nbytes).upload(frames)
+    ref = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=nimg)
+    cap = ref.capacity
+    d_k = _lib.DeviceBuffer(nimg * cap * 28); d_d = _lib.DeviceBuffer(nimg * cap * 32); d_n = _lib.DeviceBuffer(nimg * 4)
+    ref.extract_batch_device(d_img.ptr, nimg, rows, cols, cols, rows * cols, d_k.ptr, d_d.ptr, cap, d_n.ptr); ref.synchronize()
+    n0 = d_n.download(np.int32, nimg); k0 = d_k.download(np.uint8, nimg * cap * 28).reshape(nimg, cap, 28)
+    de0 = d_d.download(np.uint8, nimg * cap * 32).reshape(nimg, cap, 32)
+    px = [int(np.prod(ref.level_size(rows, cols, l))) for l in range(8)]
+    masks = dvdist.level_shards(px, world)
+    owner = [next(r for r in range(world) if masks[r] >> l & 1) for l in range(8)]
+    bb = ref.level_block_bytes(nimg)
+    gathered = _lib.DeviceBuffer(world * bb)                       # what ncclAllGather leaves on every rank: [world][block]
+    for r in range(world):
+        h = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=nimg)
+        assert h.level_block_bytes(nimg) == bb
+        h.extract_levels_device(d_img.ptr, nimg, rows, cols, cols, rows * cols, masks[r], gathered.ptr + r * bb); h.synchronize()
+    d_k2 = _lib.DeviceBuffer(nimg * cap * 28); d_d2 = _lib.DeviceBuffer(nimg * cap * 32); d_n2 = _lib.DeviceBuffer(nimg * 4)
+    ref.merge_levels_device(gathered.ptr, world, owner, nimg, d_k2.ptr, d_d2.ptr, cap, d_n2.ptr); ref.synchronize()
+    n1 = d_n2.download(np.int32, nimg); k1 = d_k2.download(np.uint8, nimg * cap * 28).reshape(nimg, cap, 28)
+    de1 = d_d2.download(np.uint8, nimg * cap * 32).reshape(nimg, cap, 32)
+    assert (n1 == n0).all() and n0.min() > 100
+    for f in range(nimg):
+        assert (k1[f, :n0[f]] == k0[f, :n0[f]]).all() and (de1[f, :n0[f]] == de0[f, :n0[f]]).all(), f
