@@ -301,6 +301,8 @@ def main():
                     help="build every batch's pyramid inside its own step (default: the next batch's pyramid overlaps this batch's "
                          "FAST, dvs_orb_hint_next_batch_device)")
     ap.add_argument("--torch-exchange", action="store_true", help="exchange through torch.distributed (dist.py) instead of the C-ABI")
+    ap.add_argument("--pipes", type=int, default=1, help="independent extractor/matcher pipelines per GPU; step i runs on pipeline i %% pipes "
+                    "(experiment: lets one batch's FAST fill the issue slots the other batch's quad-tree / descriptor / match leave idle)")
     ap.add_argument("--shard", choices=("frames", "levels"), default="frames",
                     help="levels: SURVEY.md section 8e's small-batch mode (use with --batch < 8): every rank holds the same frames, extracts its "
                          "own pyramid levels, one all-gather of level-slotted blocks, on-device merge; total work fixed (strong scaling)")

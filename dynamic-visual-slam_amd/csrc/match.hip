@@ -194,6 +194,9 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict_
                                                        const int* __restrict__ ntArr, int tStrideRows, const int* __restrict__ nt0,
                                                        int* __restrict__ outIdx, int* __restrict__ outDist) {
   extern __shared__ __attribute__((aligned(16))) int8_t mlds[];
+#if defined(DVS_CHAIN_PRIO_LEVEL) && DVS_CHAIN_PRIO_LEVEL
+  __builtin_amdgcn_s_setprio(DVS_CHAIN_PRIO_LEVEL);
+#endif
   const int pair = blockIdx.y, qt = blockIdx.x;
   const int nq = min(max(nqArr[pair], 0), qStrideRows);
   const int nt = min(max(pair == 0 && nt0 ? *nt0 : ntArr[pair], 0), tStrideRows);

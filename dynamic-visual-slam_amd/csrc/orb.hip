@@ -46,6 +46,10 @@ struct dvs_orb {
   Cell* d_cells = nullptr;
   BlurTile* d_tiles = nullptr;
   BlurStrip* d_strips = nullptr;
+  BlurCol* d_blurcols = nullptr;   // matrix-core blur: work items + operand fragment table (k_blur_mfma)
+  uint4* d_blurtab = nullptr;
+  int n_blurcols = 0, blur_avt = 0;
+  bool blur_mfma_ok = false;       // weights fit the int8 band products (0 .. 127, sum 256)
   ResizeGroup* d_rgroups = nullptr;
   PyrTile* d_pyrtiles = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
@@ -56,8 +60,10 @@ struct dvs_orb {
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
   int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
   int env_fast_tail = 0;
+  int fast_byte_dma = 0;           // LDS-DMA with byte-aligned global addresses probed exact (DVS_FAST_BYTE_DMA=0 turns it off)
   int env_fast_v = 2;              // DVS_FAST_V=1: the round-1 FAST kernel
   int env_desc_split = 0;          // DVS_DESC_SPLIT=1: orientation kernel before the blur joins, descriptor kernel after (round 1's schedule)
+  int env_blur_mfma = 0;           // DVS_BLUR_MFMA=1: the matrix-core blur (k_blur_mfma) instead of the VALU streaming one; measured slower (memory side)
   int env_oct_threads = 0;         // DVS_OCT_T=512: quad-tree workgroup size for every batch size
   int env_pf_after_fast = 0;       // DVS_PF_AFTER_FAST=1: the next batch's level chain starts when this batch's FAST has finished
   hipEvent_t ev_fast = nullptr;
@@ -96,13 +102,14 @@ void free_workspace(dvs_orb* h) {
   if (h->d_cand2[1]) (void)hipFree(h->d_cand2[1]);
   if (h->d_cellcount2[1]) (void)hipFree(h->d_cellcount2[1]);
   h->d_cand2[0] = h->d_cand2[1] = nullptr; h->d_cellcount2[0] = h->d_cellcount2[1] = nullptr; h->la_valid = false;
-  void* ptrs[] = {h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
+  void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
                   h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
+  h->d_blurcols = nullptr; h->d_blurtab = nullptr;
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
@@ -360,6 +367,7 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
     G.fastRows = maxh;
     const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
+    G.fastByteDma = h->fast_byte_dma;
     G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
     G.fastWaveLds = (int)align_up((size_t)G.fastTile + (size_t)G.fastRows * G.fastP + listBytes, 16);
   }
@@ -371,6 +379,92 @@ dvs_status upload(T** dptr, const std::vector<T>& v) {
   DVS_HIP(hipMalloc((void**)dptr, std::max<size_t>(v.size(), 1) * sizeof(T)));
   if (!v.empty()) DVS_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return DVS_OK;
+}
+
+// k_blur_mfma: work items (level, 32-column strip, band of <= kBlurMfmaBand row tiles) and the int8 operand fragments in lane order
+// (lane = 32 half + (index & 31) holds k = 16 half .. 16 half + 15):  per strip the two horizontal band matrices
+// B[k][n] = sum_t gk[t] [reflect101(c0 + n + t - 3) == cin0 + k]  for source columns cin0 = c0 - 16 and c0 + 16, and once the two
+// vertical band matrices with k in accumulator order (h-row (k & 3) + 8 ((k & 15) >> 2) + 4 half of the carried / the next block).
+static bool build_blur_mfma(const Geom& G, std::vector<BlurCol>& items, std::vector<uint4>& tab, int& avt) {
+  int sum = 0;
+  for (int t = 0; t < 7; t++) { if (G.gk[t] < 0 || G.gk[t] > 127) return false; sum += G.gk[t]; }
+  if (sum != 256) return false;
+  auto refl = [](int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p; return p; };
+  int nstrip = 0;
+  for (int l = 0; l < G.nlevels; l++) {
+    const LevelGeom& L = G.lv[l];
+    const int SS = (L.w + 127) / 128, S = 4 * SS;   // strips of whole super-strips: the ones past the width get all-zero weights
+    const int T = (L.h + 31) / 32, bands = (T + kBlurMfmaBand - 1) / kBlurMfmaBand, nt = (T + bands - 1) / bands;
+    for (int sI = 0; sI < S; sI++) {
+      const int c0 = 32 * sI;
+      for (int mtx = 0; mtx < 2; mtx++) {
+        const int cin0 = mtx == 0 ? c0 - 16 : c0 + 16;
+        for (int lane = 0; lane < 64; lane++) {
+          const int n = lane & 31, half = lane >> 5;
+          uint8_t b[16];
+          for (int k = 0; k < 16; k++) {
+            const int incol = cin0 + 16 * half + k;
+            int w = 0;
+            if (c0 + n < L.w && incol >= 0 && incol < L.w)
+              for (int t = 0; t < 7; t++) if (refl(c0 + n + t - 3, L.w) == incol) w += G.gk[t];
+            b[k] = (uint8_t)w;   // <= 2 * 56 at a border: still int8
+            if (w > 127) return false;
+          }
+          uint4 v; memcpy(&v, b, 16); tab.push_back(v);
+        }
+      }
+    }
+    for (int t0 = 0; t0 < T; t0 += nt)
+      for (int ss = 0; ss < SS; ss++) items.push_back(BlurCol{(int16_t)l, (int16_t)ss, (int16_t)t0, (int16_t)std::min(nt, T - t0), nstrip + 4 * ss});
+    nstrip += S;
+  }
+  avt = nstrip;
+  for (int mtx = 0; mtx < 2; mtx++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int i = lane & 31, half = lane >> 5;
+      uint8_t b[16];
+      for (int k = 0; k < 16; k++) {
+        const int rho = (k & 3) + 8 * (k >> 2) + 4 * half, tau = (mtx ? 32 : 0) + rho - i;
+        b[k] = (uint8_t)(tau >= 0 && tau <= 6 ? G.gk[tau] : 0);
+      }
+      uint4 v; memcpy(&v, b, 16); tab.push_back(v);
+    }
+  return true;
+}
+
+// look-ahead experiment: the stream of the next batch's FAST, optionally confined to a subset of the CUs (DVS_FA_CUMASK = one
+// 32-bit pattern repeated over the 256 CU bits) so that this batch's latency-bound kernels find free CUs beside it
+static hipError_t create_fa_stream(hipStream_t* st, int prio_lo, int prio_hi) {
+  if (const char* m = getenv("DVS_FA_CUMASK")) {
+    const uint32_t pat = (uint32_t)strtoul(m, nullptr, 16);
+    uint32_t mask[8];
+    for (int i = 0; i < 8; i++) mask[i] = pat;
+    return hipExtStreamCreateWithCUMask(st, 8, mask);
+  }
+  const char* p = getenv("DVS_FA_PRIO");
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, p ? (atoi(p) > 0 ? prio_hi : (atoi(p) < 0 ? prio_lo : 0)) : prio_lo);
+}
+
+// one probe per process and device (see k_probe_lds_dma)
+static int probe_byte_dma(int device, hipStream_t st) {
+  static int cache[64]; static bool done[64];
+  if (device < 0 || device >= 64) return 0;
+  if (done[device]) return cache[device];
+  uint8_t hsrc[512]; uint32_t hout[64];
+  for (int i = 0; i < 512; i++) hsrc[i] = (uint8_t)(i * 7 + 3);
+  uint8_t* d = nullptr; uint32_t* o = nullptr;
+  int ok = 1;
+  if (hipMalloc((void**)&d, 512) != hipSuccess || hipMalloc((void**)&o, 256) != hipSuccess) ok = 0;
+  if (ok && hipMemcpy(d, hsrc, 512, hipMemcpyHostToDevice) != hipSuccess) ok = 0;
+  for (int shift = 1; ok && shift < 4; shift++) {
+    hipLaunchKernelGGL(k_probe_lds_dma, dim3(1), dim3(64), 0, st, d, o, shift);
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(hout, o, 256, hipMemcpyDeviceToHost) != hipSuccess) { ok = 0; break; }
+    for (int l = 0; l < 64; l++) { uint32_t e; memcpy(&e, hsrc + shift + 4 * l, 4); if (e != hout[l]) ok = 0; }
+  }
+  if (d) (void)hipFree(d);
+  if (o) (void)hipFree(o);
+  cache[device] = ok; done[device] = true;
+  return ok;
 }
 
 dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
@@ -392,6 +486,11 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_TRY(upload(&h->d_cells, cells));
   DVS_TRY(upload(&h->d_tiles, tiles));
   DVS_TRY(upload(&h->d_strips, strips));
+  {
+    std::vector<BlurCol> bcols; std::vector<uint4> btab;
+    h->blur_mfma_ok = build_blur_mfma(G, bcols, btab, h->blur_avt);
+    if (h->blur_mfma_ok) { DVS_TRY(upload(&h->d_blurcols, bcols)); DVS_TRY(upload(&h->d_blurtab, btab)); h->n_blurcols = (int)bcols.size(); }
+  }
   DVS_TRY(upload(&h->d_rgroups, rgroups));
   DVS_TRY(upload(&h->d_pyrtiles, ptiles));
   if (G.pyrLds > 0) DVS_HIP(hipFuncSetAttribute((const void*)k_pyr_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G.pyrLds));
@@ -631,7 +730,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
   bool stream_ok = aligned0 && G.lv[0].w % 4 == 0;
   for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && (cascade || G.lv[l].gtab >= 0);
-  if (stream_ok)
+  // matrix-core blur: 16-byte aligned rows (the pyramid block always is; a caller's level 0 when its pointer and strides are)
+  const bool mfma_ok = h->env_blur_mfma && h->blur_mfma_ok && stream_ok &&
+                       (((uintptr_t)src.img0 | src.step0 | src.fstride0) % 16 == 0) && src.step0 >= 16;
+  if (mfma_ok)
+    hipLaunchKernelGGL(k_blur_mfma, dim3(h->n_blurcols, nimg), dim3(256), 0, bst, h->d_geom, h->d_blurcols, h->n_blurcols, src, h->d_blur,
+                       h->d_blurtab, h->blur_avt);
+  else if (stream_ok)
     hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
   else
     hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
@@ -697,15 +802,19 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1' ? 1 : 0;
   if (const char* e4 = getenv("DVS_FAST_TAIL")) h->env_fast_tail = atoi(e4);
   if (const char* e5 = getenv("DVS_FAST_V")) h->env_fast_v = atoi(e5);
+  // byte-aligned tile origin: measured neutral for 35-pixel cells (6 trips of the rejection loop either way, -1.4 % instructions,
+  // same time), so it is opt-in (DVS_FAST_BYTE_DMA=1) and the probe only runs then
+  if (const char* e9 = getenv("DVS_FAST_BYTE_DMA")) h->fast_byte_dma = atoi(e9) ? probe_byte_dma(device, h->stream) : 0;
   if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
   if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
+  if (const char* e8 = getenv("DVS_BLUR_MFMA")) h->env_blur_mfma = atoi(e8);
   if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
   if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
   int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      (h->env_lookahead && hipStreamCreateWithPriority(&h->fa_stream, hipStreamNonBlocking, getenv("DVS_FA_PRIO") ? (atoi(getenv("DVS_FA_PRIO")) > 0 ? prio_hi : (atoi(getenv("DVS_FA_PRIO")) < 0 ? prio_lo : 0)) : prio_lo) != hipSuccess) ||
+      (h->env_lookahead && create_fa_stream(&h->fa_stream, prio_lo, prio_hi) != hipSuccess) ||
       hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_back[1], hipEventDisableTiming) != hipSuccess ||

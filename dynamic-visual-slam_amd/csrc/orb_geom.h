@@ -46,6 +46,7 @@ struct Geom {
   int32_t fastRows;     // max cell height (rows of the LDS tile)
   int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
   int32_t fastTile;     // bytes of the staged tile, a multiple of 256 (whole LDS-DMA wave-instructions)
+  int32_t fastByteDma;  // 1: the LDS-DMA takes byte-aligned global addresses here (checked at start-up): tiles start 1 column left of the cell
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
   int32_t debug;        // diagnostics only (DVS_DEBUG env): bit 0 = skip the quad-tree sort (results invalid)
@@ -75,6 +76,11 @@ struct ResizeGroup { int32_t base; uint32_t shift; uint32_t sel[4]; int32_t alph
 // streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
 constexpr int kBlurBand = 64;
 struct BlurStrip { int16_t level, x0, w, y0; };
+
+// matrix-core blur work item: one workgroup filters the 128-column super-strip `strip` of a level (wavefront w its 32-column strip
+// 4 strip + w) over `nt` tiles of 32 rows from tile t0; tab = index of the first strip's pair of horizontal operand fragments
+constexpr int kBlurMfmaBand = 8;
+struct BlurCol { int16_t level, strip, t0, nt; int32_t tab; };
 
 // pyramid cascade: one workgroup builds its share of EVERY level from one staged level-0 region (LDS ping-pong).
 // Ownership: level-1 tiles partition level 1; a pixel of level k >= 2 belongs to the tile that owns its top-left source tap,

@@ -41,6 +41,13 @@ __device__ __forceinline__ const u8* level_ptr(const Geom* g, const ImgSrc& s, i
   return s.pyr + (uint64_t)f * g->frameBytes + g->lv[l].off;
 }
 
+// latency-bound kernels of the chain behind FAST (quad-tree, descriptors, match): raised issue priority, so that a wave that has an
+// instruction ready is not queued behind the throughput-bound waves it shares a SIMD with (experiment switch)
+#ifndef DVS_CHAIN_PRIO_LEVEL
+#define DVS_CHAIN_PRIO_LEVEL 0
+#endif
+#define DVS_CHAIN_PRIO() do { if (DVS_CHAIN_PRIO_LEVEL) __builtin_amdgcn_s_setprio(DVS_CHAIN_PRIO_LEVEL); } while (0)
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // XCD-aware work-item id (speed only): workgroups are dealt round-robin over the 8 XCDs, each with a private 4 MiB L2.  Remap
@@ -593,6 +600,19 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// start-up probe: does the LDS-DMA take global addresses that are not dword aligned on this device / driver configuration?
+// (it does on gfx950 under ROCm's unaligned-access mode; if it ever masked the low address bits the tiles would be wrong, so
+// k_fast_wave only relies on it when this returned the exact bytes)
+__global__ void k_probe_lds_dma(const u8* __restrict__ src, uint32_t* __restrict__ out, int shift) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[64];
+  const int lane = (int)threadIdx.x;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + shift + 4 * lane),
+                                   (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[lane] = lds[lane];
+}
+
 // round-1 form of the kernel (register staging, one survivor per lane in the score stage); kept selectable (DVS_FAST_V=1) as the
 // A/B reference of the round-2 instruction diet below
 template <int P>
@@ -844,7 +864,10 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   const int iw = cw - 6, ih = ch - 6;
   int* countOut = cellCount + (uint64_t)f * g->totalCells + ci;
   if (iw <= 0 || ih <= 0) { if (lane == 0) *countOut = 0; return; }
-  const int xa = cell.x0 & ~3, ox = cell.x0 - xa;
+  // tile origin: the dword holding the cell's first column — or, where the DMA engine takes byte addresses, one column left of it,
+  // which puts the first interior column (x0 + 3) on a dword of the tile for EVERY cell: 31 interior columns then are 8 four-pixel
+  // groups instead of 8 or 9 by the cell's phase, and a 32-row cell is 4 trips of the rejection loop instead of 4.5 on average
+  const int xa = g->fastByteDma ? cell.x0 - 1 : (cell.x0 & ~3), ox = cell.x0 - xa;
   // 1. stage by LDS-DMA.  One wave-instruction lands RP whole tile rows (RP * W consecutive LDS dwords, W = P / 4 dwords per
   //    row; lanes >= RP * W idle): lane -> (row-in-piece, dword column) is fixed, so a lane's global offset is computed once
   //    and each further piece only advances the SCALAR base by RP rows — no vector arithmetic in the loop beyond the
@@ -1239,6 +1262,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
                                                 int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  DVS_CHAIN_PRIO();
   __shared__ int wsum[kOctTMax / 64 + 1];
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
   __shared__ SortShared s_sort;
@@ -1649,6 +1673,141 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core form of the same blur (round 2).  The 7 Q8 weights (18 .. 56) fit int8, so both passes are banded (Toeplitz)
+// int8 products on v_mfma_i32_32x32x32_i8 with exact int32 accumulation — the pipe every other kernel of the path leaves idle —
+// and the VALU keeps only the byte packing between them: 0.07 wave-instructions per pixel instead of 0.29.
+//   horizontal  h[r][c] = sum_t k_t p[r][c + t - 3]          A = 32 rows x 64 source columns of (p - 128)   (two 16-byte loads per lane)
+//                                                             B = the strip's 64 x 32 band matrix (host table; REFLECT_101 at the
+//                                                                 left / right border is folded into its weights)
+//               acc = h - 32768, so byte 1 of acc is (h >> 8) - 128 and byte 0 is h & 255: the two int8 operands of pass two.
+//   vertical    V = sum_t k_t h[r + t - 3] = 256 (S_hi + 32768) + (S_lo + 32768)   with S_hi / S_lo the band products of the
+//               high / low bytes;  out = (V + 32768) >> 16 = (S_hi + 32768 + ((S_lo + 65536) >> 8)) >> 8  (nested floors are
+//               exact), i.e. the low chain starts from the constant 65536 + (32768 << 8) and its >> 8 is the high chain's C input.
+//               A tile of 32 output rows takes the 32 h-rows from 3 above it (the carried block) and the block after it.
+//   rows outside the image are fetched from their REFLECT_101 source row, so the vertical band matrix is always the interior one.
+// A lane's accumulators of pass one (column = lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) are exactly the 16 k-values
+// of one operand fragment of pass two once the band matrix' k order is permuted the same way (host table), so no data moves between
+// lanes.  Pass two runs transposed (A = h bytes, B = band matrix): a lane then holds 4 x 4 consecutive output columns of one row.
+// Same results as k_blur_stream bit for bit (integer arithmetic throughout).
+// ---------------------------------------------------------------------------------------------
+typedef int bv4i __attribute__((ext_vector_type(4)));
+typedef int bv16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_blur_mfma(const Geom* __restrict__ g, const BlurCol* __restrict__ items, int nitems, ImgSrc src,
+                                                   u8* __restrict__ blur, const uint4* __restrict__ tab, int avt) {
+  // A workgroup filters a 128-column super-strip: wavefront w owns the 32-column strip w of it.  LDS exists for the memory side
+  // only — a lane of an operand fragment owns one ROW, so fragment-shaped global accesses touch 32 different lines per instruction
+  // (measured: 0.25 ms against 0.04 ms of arithmetic).  Through LDS, ten consecutive lanes fetch the 160 contiguous source bytes
+  // of a row once for all four strips (LDS-DMA, two blocks in flight) and eight consecutive lanes store the 128 contiguous bytes
+  // of an output row.
+  constexpr int kRowB = 160, kBlkB = 32 * kRowB;     // source block: 32 rows x (16 + 128 + 16) bytes
+  __shared__ __attribute__((aligned(16))) unsigned char sblk[2][kBlkB];
+  __shared__ __attribute__((aligned(16))) unsigned char sout[2][32 * 128];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xid = xcd_contiguous_id();            // frames -> XCDs contiguously: neighbouring workgroups share one L2
+  const int f = xid / (int)gridDim.x;
+  const BlurCol it = items[xid - f * (int)gridDim.x];
+  if (!((src.levelMask >> it.level) & 1u)) return;
+  const int lane = lane_id(), m = lane & 31, half = lane >> 5;
+  const LevelGeom& L = g->lv[it.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, it.level, pitch);
+  u8* dst = blur + (uint64_t)f * g->frameBytes + L.off;
+  const int W = L.w, H = L.h, dp = L.pitch;
+  const int C0 = it.strip * 128;                  // first column of the super-strip
+  const int ti = (it.tab + wv) * 2;
+  const bv4i Bh1 = __builtin_bit_cast(bv4i, tab[(ti + 0) * 64 + lane]), Bh2 = __builtin_bit_cast(bv4i, tab[(ti + 1) * 64 + lane]);
+  const bv4i Av0 = __builtin_bit_cast(bv4i, tab[(avt * 2 + 0) * 64 + lane]), Av1 = __builtin_bit_cast(bv4i, tab[(avt * 2 + 1) * 64 + lane]);
+  const bv4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+  const bv16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr uint32_t kC = 65536u + (32768u << 8);
+
+  // DMA side: wavefront w fetches rows 8 w .. 8 w + 7 of a block = 80 consecutive 16-byte slots (64 + 16 lanes).  Chunks outside
+  // the row carry zero weights and are fetched from inside it.
+  const int sA = lane, sB = 64 + (lane & 15);
+  const int rA = 8 * wv + sA / 10, rB = 8 * wv + sB / 10;
+  const uint32_t cA = (uint32_t)min(max(C0 - 16 + 16 * (sA % 10), 0), pitch - 16), cB = (uint32_t)min(max(C0 - 16 + 16 * (sB % 10), 0), pitch - 16);
+  auto src_off = [&](int vr, uint32_t col) -> uint32_t {   // virtual row -> REFLECT_101 source row (clamped: rows further out than
+    int r = vr < 0 ? -vr : vr;                             // the 3-row border only feed rows that are not stored)
+    r = r >= H ? 2 * H - 2 - r : r;
+    r = min(max(r, 0), H - 1);
+    return mad_u24((uint32_t)r, (uint32_t)pitch, col);
+  };
+  auto fetch = [&](int b, unsigned char* buf) {   // h-block b = source rows 32 b - 3 .. 32 b + 28
+    unsigned char* wb = buf + wv * (80 * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + src_off(32 * b - 3 + rA, cA)),
+                                     (__attribute__((address_space(3))) void*)wb, 16, 0, 0);
+    if (lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + src_off(32 * b - 3 + rB, cB)),
+                                       (__attribute__((address_space(3))) void*)(wb + 1024), 16, 0, 0);
+  };
+  // fragment side: lane (m, half) of wavefront w holds source chunks 2 w + half and 2 w + 2 + half of row m
+  const int fo1 = m * kRowB + 16 * (2 * wv + half), fo2 = fo1 + 32;
+  auto hblock = [&](const unsigned char* buf, bv4i& hi, bv4i& lo) {
+    const bv4i a1 = *reinterpret_cast<const bv4i*>(buf + fo1) ^ bias;
+    const bv4i a2 = *reinterpret_cast<const bv4i*>(buf + fo2) ^ bias;
+    bv16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, Bh1, zero, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, Bh2, acc, 0, 0, 0);
+    uint32_t P[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) P[q] = __builtin_amdgcn_perm((uint32_t)acc[2 * q + 1], (uint32_t)acc[2 * q], 0x05040100u);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      hi[d] = (int)__builtin_amdgcn_perm(P[2 * d + 1], P[2 * d], 0x07050301u);
+      lo[d] = (int)(__builtin_amdgcn_perm(P[2 * d + 1], P[2 * d], 0x06040200u) ^ 0x80808080u);
+    }
+  };
+  const int wo = m * 128 + 32 * wv + 4 * half;                               // + 8 d: this lane's 4 x 4 output columns of row m
+  const int orow = (int)threadIdx.x >> 3, ocol = C0 + 16 * ((int)threadIdx.x & 7);   // store side: 8 lanes per 128-byte output row
+  uint32_t so = mad_u24((uint32_t)(32 * it.t0 + orow), (uint32_t)dp, (uint32_t)ocol);
+  auto vtile = [&](int t, const bv4i& chi, const bv4i& clo, const bv4i& nhi, const bv4i& nlo) {
+    bv16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(clo, Av0, zero, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(nlo, Av1, lo, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo[k] = (int)(((uint32_t)lo[k] + kC) >> 8);   // only bits 8 .. 23 of the sum reach the output
+    bv16i u = __builtin_amdgcn_mfma_i32_32x32x32_i8(chi, Av0, lo, 0, 0, 0);
+    u = __builtin_amdgcn_mfma_i32_32x32x32_i8(nhi, Av1, u, 0, 0, 0);
+    unsigned char* ot = sout[t & 1];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)u[4 * d + 1], (uint32_t)u[4 * d], 0x0c0c0501u);
+      const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)u[4 * d + 3], (uint32_t)u[4 * d + 2], 0x0c0c0501u);
+      *reinterpret_cast<uint32_t*>(ot + wo + 8 * d) = p01 | (p23 << 16);
+    }
+    __syncthreads();
+    const bv4i o = *reinterpret_cast<const bv4i*>(ot + threadIdx.x * 16);
+    // columns past the width land in the row's padding (pitch >= w + 8 rounded up to 64); whole 16-byte groups past it are skipped
+    if (32 * t + orow < H && ocol < W) *reinterpret_cast<bv4i*>(dst + so) = o;
+    so += 32u * (uint32_t)dp;
+  };
+
+  bv4i hiA, loA, hiB, loB;
+  fetch(it.t0, sblk[0]);
+  fetch(it.t0 + 1, sblk[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  hblock(sblk[0], hiA, loA);
+  const int tend = it.t0 + it.nt;
+  // two tiles per trip (the carried block alternates between the register sets).  Per tile: every wavefront waits for its own DMA,
+  // the barrier makes the block complete, the fragments are read, and the buffer two blocks back — read by everybody before
+  // this barrier — takes the next DMA, which lands while the tile is computed.
+  for (int t = it.t0; t < tend; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    hblock(sblk[1], hiB, loB);              // block t + 1
+    if (t + 1 < tend) fetch(t + 2, sblk[0]);
+    vtile(t, hiA, loA, hiB, loB);
+    if (t + 1 < tend) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      hblock(sblk[0], hiA, loA);            // block t + 2
+      if (t + 2 < tend) fetch(t + 3, sblk[1]);
+      vtile(t + 1, hiB, loB, hiA, loA);
+    }
+  }
+}
+
 // =============================================================================================
 // orientation + descriptor + final keypoint record.  One wavefront per keypoint.
 // =============================================================================================
@@ -1702,6 +1861,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
                                                   int* __restrict__ nOut, int capacity, float4* __restrict__ orient) {
   typedef uint4 __attribute__((aligned(1))) uint4u;
   __shared__ __attribute__((aligned(16))) u8 win[4][2][kWinRows * kWinPitch];
+  DVS_CHAIN_PRIO();
   const int wg = xcd_contiguous_id();
   const int f = wg / (int)gridDim.x, bx = wg - f * (int)gridDim.x;
   const int lane = lane_id();
