@@ -292,6 +292,11 @@ def main():
     ap.add_argument("--match-stream", dest="match_stream", action="store_true",
                     help="give the match its own stream so that it can overlap the next batch's extraction (default: enqueued behind its "
                          "own batch's extraction on the same stream; measured faster, DESIGN.md section 5)")
+    ap.add_argument("--serial-match", dest="match_late", action="store_false",
+                    help="match batch i in step i behind its own extraction (round 1's schedule).  Default: software-pipelined — step i "
+                         "extracts batch i and matches batch i - 1 on a second stream that the extractor releases behind FAST "
+                         "(dvs_orb_set_after_fast_event), so the matrix-core match runs beside the quad-tree / blur phase; every step "
+                         "still runs one extraction and one match of 64 frames")
     ap.add_argument("--resident-batches", type=int, default=6,
                     help="distinct resident input batches the steps rotate over (6 x 64 x 0.92 MB of level 0 + 6 x 180 MB of pyramids and "
                          "blurred levels per pass: far beyond the 256 MB Infinity Cache)")
@@ -352,8 +357,10 @@ def main():
     # (measured: an unused fourth stream in the extractor handle, 0.74 -> 0.93 ms)
     need_x = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ) or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
     ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
-    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if args.match_stream else ts   # match
-    xs = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if need_x else ts              # boundary exchange
+    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if (args.match_stream or args.match_late) else ts   # match
+    # boundary exchange: with the pipelined match it shares the match stream (the match is its only consumer and a fifth hardware
+    # queue cost 0.28 ms per step under the launcher); the serial schedule gives it a stream of its own beside the extraction
+    xs = (ms if args.match_late else torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)) if need_x else ts
     mat = dvslam_amd.BFMatcher(device=local, stream=ms.cuda_stream)
     cap = orb.capacity
     with torch.cuda.stream(ts):
@@ -392,18 +399,28 @@ def main():
     if collective and comm is None and not dist.is_initialized():
         collective = False
 
+    lag = 1 if args.match_late else 0    # step i extracts batch i and matches batch i - lag
+    ev_fast = None
+    if lag:
+        ev_fast = torch.cuda.Event()
+        ev_fast.record(ts)               # creates the hipEvent_t the library records behind FAST from now on
+        orb.set_after_fast_event(ev_fast.cuda_event)
+
     def step():
         i = state["i"]; state["i"] += 1
         s = i % NSETS
         img = d_img[i % NB]; nxt = d_img[(i + 1) % NB]
         T, M, X = P["stream"], P["mstream"], P["xstream"]
+        j = i - lag                      # the batch matched in this step
+        sj = j % NSETS
         prev_desc = prev_n = 0
-        if i > 0:
-            qd, qn = P["last"]           # last frame of the previous step (this rank's)
+        if j > 0:
+            sp = (j - 1) % NSETS
+            qd, qn = P["desc"][sp][B - 1], P["n"][sp][B - 1:B]   # last frame of the batch before it (this rank's)
             if collective:
                 # the one exchange step: every rank's last-frame block, this rank needs its predecessor's.  It depends only on
-                # the previous step's extraction, so it runs on a side stream beside this step's and is joined before the match
-                X.wait_event(P["ext_done"][(i - 1) % NSETS])
+                # that batch's extraction, so it runs on a side stream beside this step's and is joined before the match
+                X.wait_event(P["ext_done"][sp])
                 if comm is not None:
                     prev_desc, prev_n = comm.exchange_boundary(X.cuda_stream, qd.data_ptr(), qn.data_ptr(), cap)
                     P["xdone"].record(X)
@@ -425,14 +442,16 @@ def main():
             P["orb"].extract_batch_device(img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
                                           P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
             P["ext_done"][s].record(T)
-        if M is not T:
-            M.wait_event(P["ext_done"][s])
-        if i > 0 and collective:
-            M.wait_event(P["xdone"])
-        P["mat"].match_sequence_device(P["desc"][s].data_ptr(), P["n"][s].data_ptr(), cap, B, prev_desc, prev_n,
-                                       P["idx"].data_ptr(), P["dist"].data_ptr())
-        P["match_done"][s].record(M)
-        P["last"] = (P["desc"][s][B - 1], P["n"][s][B - 1:B])
+        if j >= 0:
+            if M is not T:
+                M.wait_event(P["ext_done"][sj])
+                if lag:
+                    M.wait_event(ev_fast)    # recorded behind this step's FAST by the extraction just enqueued
+            if j > 0 and collective:
+                M.wait_event(P["xdone"])
+            P["mat"].match_sequence_device(P["desc"][sj].data_ptr(), P["n"][sj].data_ptr(), cap, B, prev_desc, prev_n,
+                                           P["idx"].data_ptr(), P["dist"].data_ptr())
+            P["match_done"][sj].record(M)
         P["cur"] = s
 
     def sync_all():
@@ -457,6 +476,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the pipelined match against the same job enqueued serially (outside the timed region): guards the event dependencies
+    match_check = None; nj = None
+    if not collective and state["i"] >= 3:
+        jl = state["i"] - 1 - lag
+        sj, sp = jl % NSETS, (jl - 1) % NSETS
+        idx2 = torch.empty_like(P["idx"]); dist2 = torch.empty_like(P["dist"])
+        sync_all()
+        P["mat"].match_sequence_device(P["desc"][sj].data_ptr(), P["n"][sj].data_ptr(), cap, B, P["desc"][sp][B - 1].data_ptr(),
+                                       P["n"][sp][B - 1:B].data_ptr(), idx2.data_ptr(), dist2.data_ptr())
+        sync_all()
+        nj = P["n"][sj].cpu().numpy()
+        same = all(bool(torch.equal(idx2[f, :nj[f]], P["idx"][f, :nj[f]]) and torch.equal(dist2[f, :nj[f]], P["dist"][f, :nj[f]])) for f in range(B))
+        match_check = "identical to the serial match of the same batch" if same else "MISMATCH"
+        assert same, "pipelined match differs from the serial one"
     # per-kernel durations: K more steps on ONE pipeline with hipEvents around every stage launch (the events cost ~10 us
     # of stream time per stage, so they stay out of the whole-job timing above)
     # (a) the same schedule as the timed region (overlap + pyramid prefetch), events on the streams the kernels run on: what a
@@ -489,7 +522,7 @@ def main():
     d_n = pipes[0]["n"][pipes[0]["cur"]]; d_dist = pipes[0]["dist"]
 
     n_host = d_n.cpu().numpy()
-    matched = int((d_dist[:, :].cpu().numpy()[1, :n_host[1]] < 50).sum()) if B > 1 else 0
+    matched = int((d_dist[:, :].cpu().numpy()[1, :(nj if nj is not None else n_host)[1]] < 50).sum()) if B > 1 else 0
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -519,7 +552,8 @@ def main():
                                    "(BASELINE configs[1])", "frames_per_gpu_per_step": B, "frames_distinct": frames_distinct,
                        "resident_batches": NB, "keypoints_frame1": int(n_host[min(1, B - 1)]),
                        "matches_lt50_frame1": matched, "parallelism": f"frame-sharded x{world}, boundary-descriptor all_gather, match of batch i on its own stream beside the extraction "
-                                      f"of batch i + 1" if args.match_stream else f"frame-sharded x{world}, boundary-descriptor all_gather, serial match"},
+                                      f"of batch i + 1" if args.match_stream else (f"frame-sharded x{world}, boundary-descriptor all_gather, step i = extraction of batch i + match of batch i - 1 "
+                                      f"released behind FAST" if args.match_late else f"frame-sharded x{world}, boundary-descriptor all_gather, serial match")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "ms_per_launch": round(dom_ms, 4), "algorithmic_bytes_per_launch": STAGE_BYTES[dom] * B},
@@ -527,7 +561,7 @@ def main():
             "hbm_read_roofline_frac": round(fps / world * READ_BYTES_PER_FRAME / HBM_PEAK, 5),
             "stage_ms_per_launch_isolated": {k: round(v / max(stage_calls[k], 1), 4) for k, v in stage_ms.items()},
             "stage_ms_per_launch_overlapped": {k: round(v / max(ov_calls[k], 1), 4) for k, v in ov_ms.items()},
-            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4), "pipelines_per_gpu": NP, "rccl": rccl,
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4), "pipelines_per_gpu": NP, "rccl": rccl, "match_check": match_check,
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_bindings as ob

@@ -57,6 +57,7 @@ struct dvs_orb {
   // cross-batch software pipeline (dvs_orb_hint_next_batch_device): the NEXT batch's pyramid is built into d_pyr_alt on the
   // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
   u8* d_pyr_alt = nullptr;
+  hipEvent_t after_fast_event = nullptr;   // caller's event, recorded on the main stream behind FAST (dvs_orb_set_after_fast_event)
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
   int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
   int env_fast_tail = 0;
@@ -712,6 +713,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
   // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
   hipStream_t bst = st;
+  if (h->after_fast_event) DVS_HIP(hipEventRecord(h->after_fast_event, st));
   if (h->overlap) {
     bst = h->aux_stream;
     DVS_HIP(hipEventRecord(h->ev_pyr, st));
@@ -720,7 +722,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   h->timer.begin(DVS_STAGE_OCTREE, st);
   // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
   // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(h->env_oct_threads ? h->env_oct_threads : kOctTMax), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  // ... and 256 threads for larger batches: two workgroups per CU run beside the blur (and a pipelined caller's match), and the wave
+  // slots 512-thread workgroups hold cost those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 and
+  // 384 threads: 0.729 / 0.690).  DVS_OCT_T=512 keeps 512 with the per-level grading of oct_threads().
+  const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
+  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
@@ -985,6 +991,12 @@ dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int3
   }
   hipLaunchKernelGGL(k_merge_levels, dim3((Y.kpBlock + 255) / 256, nimg), dim3(256), 0, h->stream, Y, d_blocks, nimg, d_kps, d_desc, capacity, d_n_out);
   DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event) {
+  DVS_ARG(h);
+  h->after_fast_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 

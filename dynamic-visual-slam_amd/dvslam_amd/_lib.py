@@ -77,6 +77,7 @@ def lib():
     L.dvs_stream_destroy.argtypes = [vp]
     L.dvs_stream_synchronize.argtypes = [vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
+    L.dvs_orb_set_after_fast_event.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]

@@ -105,6 +105,10 @@ class ORBextractor:
         beside this batch's descriptor stage and the match that follows; one-shot, results unchanged"""
         check(self._L.dvs_orb_hint_next_batch_device(self._h, d_next_imgs))
 
+    def set_after_fast_event(self, hip_event):
+        """hipEvent_t (int, 0 to clear) recorded behind FAST by every following extract_batch_device (scheduling hook)"""
+        check(self._L.dvs_orb_set_after_fast_event(self._h, hip_event or None))
+
     def extract_batch_device(self, d_imgs, nimg, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout):
         """raw device pointers (ints); asynchronous on the handle's stream"""
         check(self._L.dvs_orb_extract_batch_device(self._h, d_imgs, nimg, rows, cols, step, frame_stride, d_kps, d_desc, capacity, d_nout))

@@ -119,6 +119,12 @@ dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32
  * must not change between the two calls.  (No counterpart in the reference, whose ComputePyramid runs inside operator(),
  * ORBextractor.cpp:1081; this is the MI355X replacement for running consecutive frames on separate CPU threads.) */
 dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs);
+/* Scheduling hook for a pipelined caller: `hip_event` (a hipEvent_t of the caller, NULL to clear) is recorded on the handle's main
+ * stream by every following device-resident extraction right behind its FAST launch, i.e. at the point from which the machine's
+ * vector ALUs are mostly idle (quad-tree / blur / descriptor gathers).  A caller that has independent matrix-core or copy work —
+ * the PREVIOUS batch's match (BFMatcher call of frontend.cpp:1123) — makes its stream wait on it so that the work runs beside
+ * that phase instead of beside FAST.  Results are unaffected. */
+dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event);
 
 /* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
  * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per
