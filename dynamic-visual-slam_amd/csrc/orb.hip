@@ -57,6 +57,9 @@ struct dvs_orb {
   // cross-batch software pipeline (dvs_orb_hint_next_batch_device): the NEXT batch's pyramid is built into d_pyr_alt on the
   // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
   u8* d_pyr_alt = nullptr;
+  hipEvent_t output_event = nullptr;       // caller's event: outputs complete (dvs_orb_set_output_event => deferred descriptor stage)
+  hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // deferred mode: descriptor stage finished (auxiliary stream) / quad-tree finished
+  bool out_pending = false;                // the previous call's descriptor stage is still only ordered on the auxiliary stream
   hipEvent_t after_fast_event = nullptr;   // caller's event, recorded on the main stream behind FAST (dvs_orb_set_after_fast_event)
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
   int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
@@ -565,15 +568,24 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
 
 // enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`
 dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout,
-                           const u8* next_img0 = nullptr) {
+                           const u8* next_img0 = nullptr, bool may_defer = false) {
   const Geom& G = h->geom;
   hipStream_t st = h->stream;
+  // deferred descriptor stage of the previous call (dvs_orb_set_output_event): it runs on the auxiliary stream beside THIS call's
+  // FAST.  What it still reads — the other pyramid buffer, the blurred block, the level keypoint lists — is protected below: the
+  // prefetch chain and this call's quad-tree wait for it, the blur follows it on the same stream.
+  bool pend = h->out_pending;
+  h->out_pending = false;
   // a pyramid prefetched for exactly this batch (same buffer, layout and count)?  then it is already (being) built in d_pyr_alt
   const bool prefetched = h->pf_valid && h->overlap && h->pf_img == src.img0 && h->pf_step == src.step0 &&
                           h->pf_fstride == src.fstride0 && h->pf_nimg == nimg;
   h->pf_valid = false;
   const bool la_hit = prefetched && h->la_valid;   // ... and so is its FAST, in the other candidate set
   h->la_valid = false;
+  if (pend && !(prefetched && may_defer && h->overlap)) {   // anything but the pipelined pattern: plain join first
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));
+    pend = false;
+  }
   if (prefetched) {
     std::swap(h->d_pyr, h->d_pyr_alt);
     DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
@@ -653,6 +665,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
     DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
+    if (pend) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_out, 0));   // ... except a deferred descriptor stage
     const bool la = h->env_lookahead && h->fa_stream && !after_fast;
     const int ns = h->cset ^ 1;
     if (la) {
@@ -719,6 +732,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipEventRecord(h->ev_pyr, st));
   }
   // 3. quad-tree
+  if (pend) DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));   // the deferred descriptor stage reads the lists the quad-tree rewrites
   h->timer.begin(DVS_STAGE_OCTREE, st);
   // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
   // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
@@ -761,6 +775,19 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_describe<2>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
     h->timer.end(st);
+  } else if (bst != st && may_defer && h->output_event && !sharded) {
+    // deferred: the descriptor stage follows the blur on the auxiliary stream and the main stream is NOT joined — the next call's
+    // FAST (vector-ALU bound, light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the
+    // caller's output event.
+    DVS_HIP(hipEventRecord(h->ev_oct, st));
+    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+    h->timer.begin(DVS_STAGE_DESCRIBE, bst);
+    hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, bst, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
+                       capacity, h->d_orient);
+    h->timer.end(bst);
+    DVS_HIP(hipEventRecord(h->ev_out, bst));
+    DVS_HIP(hipEventRecord(h->output_event, bst));
+    h->out_pending = true;
   } else {
     if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
     h->timer.begin(DVS_STAGE_DESCRIBE, st);
@@ -827,6 +854,8 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_oct, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_prefetch, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
@@ -864,6 +893,8 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_fast) (void)hipEventDestroy(h->ev_fast);
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
+  if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+  if (h->ev_oct) (void)hipEventDestroy(h->ev_oct);
   if (h->ev_prefetch) (void)hipEventDestroy(h->ev_prefetch);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -903,6 +934,7 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
+  if (h->out_pending) { DVS_HIP(hipStreamSynchronize(h->aux_stream)); h->out_pending = false; }   // a deferred descriptor stage
   DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
   if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));  // ... and so may its FAST
   return DVS_OK;
@@ -943,7 +975,7 @@ dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32
   ImgSrc src{d_imgs, (uint64_t)step, (uint64_t)frame_stride, h->d_pyr, ~0u, 0};
   const u8* next = h->next_hint;
   h->next_hint = nullptr;
-  return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out, next);
+  return enqueue_extract(h, src, nimg, d_kps, d_desc, capacity, d_n_out, next, true);
 }
 
 // ---- level-sharded extraction -----------------------------------------------------------------------------------
@@ -991,6 +1023,12 @@ dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int3
   }
   hipLaunchKernelGGL(k_merge_levels, dim3((Y.kpBlock + 255) / 256, nimg), dim3(256), 0, h->stream, Y, d_blocks, nimg, d_kps, d_desc, capacity, d_n_out);
   DVS_HIP(hipGetLastError());
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event) {
+  DVS_ARG(h);
+  h->output_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 

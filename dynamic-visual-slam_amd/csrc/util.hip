@@ -93,6 +93,31 @@ dvs_status dvs_stream_destroy(void* stream) {
   return DVS_OK;
 }
 
+dvs_status dvs_event_create(int32_t device, void** out_event) {
+  DVS_ARG(out_event);
+  *out_event = nullptr;
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipSetDevice(device));
+  hipEvent_t e = nullptr;
+  DVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out_event = e;
+  return DVS_OK;
+}
+dvs_status dvs_event_destroy(void* event) {
+  if (event) DVS_HIP(hipEventDestroy((hipEvent_t)event));
+  return DVS_OK;
+}
+dvs_status dvs_event_synchronize(void* event) {
+  DVS_ARG(event);
+  DVS_HIP(hipEventSynchronize((hipEvent_t)event));
+  return DVS_OK;
+}
+dvs_status dvs_stream_wait_event(void* stream, void* event) {
+  DVS_ARG(event);
+  DVS_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return DVS_OK;
+}
+
 dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap) {
   DVS_ARG(buf && cap > 0);
   buf[0] = 0;

@@ -76,8 +76,13 @@ def lib():
     L.dvs_stream_create.argtypes = [i32, i32, C.POINTER(vp)]
     L.dvs_stream_destroy.argtypes = [vp]
     L.dvs_stream_synchronize.argtypes = [vp]
+    L.dvs_event_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_event_destroy.argtypes = [vp]
+    L.dvs_event_synchronize.argtypes = [vp]
+    L.dvs_stream_wait_event.argtypes = [vp, vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_set_after_fast_event.argtypes = [vp, vp]
+    L.dvs_orb_set_output_event.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]
@@ -147,6 +152,13 @@ def stream_create(device=0, high_priority=False):
     """raw hipStream_t (int) created by the library (wrap with torch.cuda.ExternalStream when torch should use it)"""
     out = C.c_void_p()
     check(lib().dvs_stream_create(device, 1 if high_priority else 0, C.byref(out)))
+    return int(out.value)
+
+
+def event_create(device=0):
+    """raw hipEvent_t (int), timing disabled"""
+    out = C.c_void_p()
+    check(lib().dvs_event_create(device, C.byref(out)))
     return int(out.value)
 
 

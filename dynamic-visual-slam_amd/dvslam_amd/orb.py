@@ -105,6 +105,11 @@ class ORBextractor:
         beside this batch's descriptor stage and the match that follows; one-shot, results unchanged"""
         check(self._L.dvs_orb_hint_next_batch_device(self._h, d_next_imgs))
 
+    def set_output_event(self, hip_event):
+        """hipEvent_t (int, 0 to clear): deferred descriptor stage — outputs of a device-resident call are complete when this event
+        is (dvs_orb_set_output_event)"""
+        check(self._L.dvs_orb_set_output_event(self._h, hip_event or None))
+
     def set_after_fast_event(self, hip_event):
         """hipEvent_t (int, 0 to clear) recorded behind FAST by every following extract_batch_device (scheduling hook)"""
         check(self._L.dvs_orb_set_after_fast_event(self._h, hip_event or None))

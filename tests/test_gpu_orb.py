@@ -305,3 +305,70 @@ def test_level_sharded_extraction_equals_whole_frame_extraction(gpu, world, rows
     assert (n1 == n0).all() and n0.min() > 100
     for f in range(nimg):
         assert (k1[f, :n0[f]] == k0[f, :n0[f]]).all() and (de1[f, :n0[f]] == de0[f, :n0[f]]).all(), f
+
+
+def test_scheduling_hooks_leave_results_unchanged(gpu):
+    """dvs_orb_set_output_event (deferred descriptor stage: the next call's FAST runs beside it) and dvs_orb_set_after_fast_event
+    (a caller stream released behind FAST): a pipelined caller gets the same bytes as the plain calls, with the consumer — here the
+    match of the previous batch, on its own stream — ordered only by the two events."""
+    from dvslam_amd import ORBextractor, BFMatcher, _lib
+    L = _lib.lib()
+    rows, cols, nf, B, NBATCH = 480, 640, 800, 3, 5
+    frames = [np.stack([synth.make_frame(10 * b + i, cols=cols, rows=rows) for i in range(B)]) for b in range(NBATCH)]
+    d_img = [_lib.DeviceBuffer(f.nbytes).upload(f) for f in frames]
+    plain = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    cap = plain.capacity
+    mk = lambda: (_lib.DeviceBuffer(B * cap * 28), _lib.DeviceBuffer(B * cap * 32), _lib.DeviceBuffer(B * 4))
+    ref = []
+    for b in range(NBATCH):
+        k, d, n = mk()
+        plain.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr); plain.synchronize()
+        ref.append((k.download(np.uint8, B * cap * 28), d.download(np.uint8, B * cap * 32), n.download(np.int32, B)))
+    m0 = BFMatcher()
+    ridx = _lib.DeviceBuffer(B * cap * 4); rdist = _lib.DeviceBuffer(B * cap * 4)
+    # pipelined: outputs by event, match of batch b - 1 on its own stream behind batch b's FAST
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    mstream = _lib.stream_create(0)
+    mat = BFMatcher(stream=mstream)
+    ev_out = [_lib.event_create(0) for _ in range(NBATCH)]
+    ev_fast = _lib.event_create(0)
+    g.set_after_fast_event(ev_fast)
+    outs = [mk() for _ in range(NBATCH)]
+    idx = [_lib.DeviceBuffer(B * cap * 4) for _ in range(NBATCH)]; dist = [_lib.DeviceBuffer(B * cap * 4) for _ in range(NBATCH)]
+    for b in range(NBATCH):
+        k, d, n = outs[b]
+        g.set_output_event(ev_out[b])
+        if b + 1 < NBATCH:
+            g.hint_next_batch_device(d_img[b + 1].ptr)
+        g.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr)
+        if b >= 1:
+            assert L.dvs_stream_wait_event(mstream, ev_fast) == 0          # behind batch b's FAST
+            assert L.dvs_stream_wait_event(mstream, ev_out[b - 1]) == 0    # batch b - 1 complete (deferred descriptor stage)
+            pk = outs[b - 2] if b >= 2 else None
+            mat.match_sequence_device(outs[b - 1][1].ptr, outs[b - 1][2].ptr, cap, B, pk[1].ptr + (B - 1) * cap * 32 if pk else 0,
+                                      pk[2].ptr + (B - 1) * 4 if pk else 0, idx[b - 1].ptr, dist[b - 1].ptr)
+    g.synchronize(); _lib.stream_synchronize(mstream)
+    for b in range(NBATCH):
+        k, d, n = outs[b]
+        n1 = n.download(np.int32, B)
+        assert (n1 == ref[b][2]).all() and n1.min() > 100
+        k1 = k.download(np.uint8, B * cap * 28).reshape(B, cap, 28); d1 = d.download(np.uint8, B * cap * 32).reshape(B, cap, 32)
+        k0 = ref[b][0].reshape(B, cap, 28); d0 = ref[b][1].reshape(B, cap, 32)
+        for f in range(B):
+            assert (k1[f, :n1[f]] == k0[f, :n1[f]]).all() and (d1[f, :n1[f]] == d0[f, :n1[f]]).all(), (b, f)
+    for b in range(NBATCH - 1):   # matches of batches 0 .. NBATCH - 2 against the same jobs run serially
+        pk = outs[b - 1] if b >= 1 else None
+        m0.match_sequence_device(outs[b][1].ptr, outs[b][2].ptr, cap, B, pk[1].ptr + (B - 1) * cap * 32 if pk else 0,
+                                 pk[2].ptr + (B - 1) * 4 if pk else 0, ridx.ptr, rdist.ptr)
+        m0.synchronize()
+        n1 = outs[b][2].download(np.int32, B)
+        a = idx[b].download(np.int32, B * cap).reshape(B, cap); r = ridx.download(np.int32, B * cap).reshape(B, cap)
+        ad = dist[b].download(np.int32, B * cap).reshape(B, cap); rd = rdist.download(np.int32, B * cap).reshape(B, cap)
+        for f in range(B):
+            if b == 0 and f == 0:
+                continue                      # no predecessor: nothing is written for it
+            assert (a[f, :n1[f]] == r[f, :n1[f]]).all() and (ad[f, :n1[f]] == rd[f, :n1[f]]).all(), (b, f)
+    g.set_output_event(0); g.set_after_fast_event(0)
+    for e in ev_out + [ev_fast]:
+        L.dvs_event_destroy(e)
+    _lib.stream_destroy(mstream)
