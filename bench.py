@@ -556,7 +556,7 @@ def main():
             issue = {"kernel": dom, "valu_wave_insts_per_launch": int(insts), "achieved": round(rate, 1), "peak": nominal,
                      "unit": "G wave-instr/s", "frac": round(rate / nominal, 4),
                      "measured_class_rates_G_per_s": {"add/xor/max_i16 class": "780-950", "perm/pk16/dot/bcnt/min3/mad24 class": tj["valu_issue_peak_G_per_s"]},
-                     "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json; class rates: tools/ubench/valu_rate.hip, profiles/r01_valu_issue_rates.txt"}
+                     "source": "SQ_INSTS_VALU from profiles/pmc_traffic.json; class rates: tools/ubench/valu_rate.hip, profiles/r02_valu_issue_rates.txt"}
         except Exception:
             pass
         achieved = STAGE_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

@@ -197,7 +197,15 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict_
 #if defined(DVS_CHAIN_PRIO_LEVEL) && DVS_CHAIN_PRIO_LEVEL
   __builtin_amdgcn_s_setprio(DVS_CHAIN_PRIO_LEVEL);
 #endif
-  const int pair = blockIdx.y, qt = blockIdx.x;
+  // XCD-aware job mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, and with (x = query tile, y = pair) the
+  // tiles of one pair — which all stream the SAME train set — landed on 8 different L2s: 335 MB fetched per 64 pairs of 40 MB of
+  // distinct expanded descriptors (profiles/r02_pmc_summary.csv).  Re-deal the linear id so that pair p runs entirely on XCD p % 8.
+  int pair = blockIdx.y, qt = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int lid = blockIdx.x + gridDim.x * blockIdx.y, xcd = lid & 7, k = lid >> 3;
+    pair = xcd + 8 * (k / (int)gridDim.x);
+    qt = k % (int)gridDim.x;
+  }
   const int nq = min(max(nqArr[pair], 0), qStrideRows);
   const int nt = min(max(pair == 0 && nt0 ? *nt0 : ntArr[pair], 0), tStrideRows);
   if (qt * 128 * NQ >= nq) return;

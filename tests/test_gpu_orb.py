@@ -372,3 +372,34 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
     for e in ev_out + [ev_fast]:
         L.dvs_event_destroy(e)
     _lib.stream_destroy(mstream)
+
+
+@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "1"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}])
+@pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 500, 8), (720, 1280, 2000, 8), (360, 1000, 700, 6), (250, 332, 200, 4), (200, 136, 150, 3)])
+def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, nf, nl):
+    """the matrix-core blur (k_blur_mfma: int8 band products, LDS-staged) and the byte-aligned FAST tile origin are selected at
+    handle creation (environment); both must reproduce the oracle bit for bit — blurred levels, candidates and the final result —
+    including widths that are not a multiple of the 32-column strips / 128-column super-strips and rows not a multiple of 32"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        g, o = _pair(oracle, nf, nl, max_batch=2)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    frames = [synth.make_frame(t, cols=cols, rows=rows) for t in (2, 7)]
+    nout, kps, desc = g.extract_batch(frames)
+    for i, img in enumerate(frames):
+        n2, k2, d2 = o.extract(img)
+        _assert_same_result(int(nout[i]), kps[i, :nout[i]], desc[i, :nout[i]], n2, k2, d2)
+    n, k1, d1 = g(frames[1])
+    n2, k2, d2 = o.extract(frames[1])
+    for l in range(nl):
+        if len(o.level_keypoints(l)):
+            assert (g.level(l, blurred=True) == o.level(l, blurred=True)).all(), f"blurred level {l}"
+        assert len(o.candidates(l)) == len(g.candidates(l)) and (g.candidates(l) == o.candidates(l)).all(), f"candidates level {l}"
+    _assert_same_result(n, k1, d1, n2, k2, d2)
+    g.close()

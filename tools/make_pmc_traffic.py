@@ -8,7 +8,7 @@ src = sys.argv[1]
 rows = [r for r in csv.reader(l for l in open(src) if not l.startswith("#"))]
 hdr = rows[0]
 fi, wi, vi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE"), hdr.index("SQ_INSTS_VALU")
-stage = {"k_resize4": "pyramid", "k_fast_wave": "fast", "k_octree": "octree", "k_blur_stream": "blur", "k_describe": "describe", "k_match": "match"}
+stage = {"k_resize4": "pyramid", "k_fast_wave": "fast", "k_octree": "octree", "k_blur_stream": "blur", "k_describe": "describe", "k_match": "match", "k_expand_desc": "match"}
 by, vl = {}, {}
 for r in rows[1:]:
     for k, v in stage.items():
@@ -19,6 +19,6 @@ json.dump({"note": f"from {src}: HBM bytes per launch of 64 frames = (2 x FETCH_
                    "coalesced stream); valu_insts = SQ_INSTS_VALU (wave-level) per launch; pyramid = sum of the seven k_resize4 launches",
            "batch": 64, "bytes_per_launch": by, "valu_insts_per_launch": vl,
            "valu_issue_peak_G_per_s": 560.0,
-           "valu_issue_peak_note": "measured: profiles/r01_valu_issue_rates.txt (packed-16 / perm / dot4 / bcnt / min3 at 8 waves per SIMD)"},
+           "valu_issue_peak_note": "measured: profiles/r02_valu_issue_rates.txt (packed-16 / perm / dot4 / bcnt / min3 / mad24 at 8 waves per SIMD)"},
           open("profiles/pmc_traffic.json", "w"), indent=1)
 print(by, vl)
