@@ -297,10 +297,9 @@ def main():
                          "extracts batch i and matches batch i - 1 on a second stream that the extractor releases behind FAST "
                          "(dvs_orb_set_after_fast_event), so the matrix-core match runs beside the quad-tree / blur phase; every step "
                          "still runs one extraction and one match of 64 frames")
-    ap.add_argument("--defer", choices=("auto", "on", "off"), default="auto",
-                    help="deferred descriptor stage (dvs_orb_set_output_event): the next batch's FAST runs beside this batch's descriptor "
-                         "gathers.  Measured +3.5 .. +9 %% for 1-32 frames per step, -0.7 %% at 64 (the two stretch each other): auto = on up "
-                         "to 32 frames per step")
+    ap.add_argument("--defer", choices=("on", "off"), default="on",
+                    help="deferred descriptor stage (dvs_orb_set_output_event + dvs_orb_set_defer_outputs): the next batch's FAST runs beside "
+                         "this batch's descriptor gathers.  Measured +13 / +12 / +8.5 / +3.8 / +6.7 %% at 1 / 8 / 32 / 64 / 128 frames per step")
     ap.add_argument("--resident-batches", type=int, default=6,
                     help="distinct resident input batches the steps rotate over (6 x 64 x 0.92 MB of level 0 + 6 x 180 MB of pyramids and "
                          "blurred levels per pass: far beyond the 256 MB Infinity Cache)")
@@ -410,10 +409,15 @@ def main():
         ev_fast.record(ts)               # creates the hipEvent_t the library records behind FAST from now on
         orb.set_after_fast_event(ev_fast.cuda_event)
 
-    defer = bool((args.defer == "on" or (args.defer == "auto" and B <= 32)) and args.match_late and args.prefetch)
-    if defer:
+    defer = bool(args.defer == "on" and args.match_late and args.prefetch)
+    # cross-stream joins cost a barrier packet each (5-8 us when they sit between two dependent kernels of one queue): the library
+    # records the caller's output event itself (and gates its next prefetch on it) and takes the reuse guard onto the blur's
+    # stream, so that nothing but FAST follows the previous step's descriptor kernel on the main stream.  BENCH_HOPS=0: the plain
+    # stream-level statements of the same dependencies (A/B).
+    lib_events = os.environ.get("BENCH_HOPS", "1") != "0" and ms is not ts
+    if defer or lib_events:
         for e in P["ext_done"]:
-            e.record(ts)                 # creates the hipEvent_t handles the library records behind the descriptor stage
+            e.record(ts)                 # creates the hipEvent_t handles the library records where the outputs are complete
 
     def step():
         i = state["i"]; state["i"] += 1
@@ -442,17 +446,21 @@ def main():
             else:
                 prev_desc, prev_n = qd.data_ptr(), qn.data_ptr()
         if i >= NSETS and M is not T:
-            T.wait_event(P["match_done"][(i - NSETS + 1) % NSETS])   # the last reader of the set this step overwrites
+            guard = P["match_done"][(i - NSETS + 1) % NSETS]         # the last reader of the set this step overwrites
+            if lib_events:
+                P["orb"].set_reuse_guard_event(guard.cuda_event)
+            else:
+                T.wait_event(guard)
         with torch.cuda.stream(T):
             if args.prefetch:
                 # streaming: the next batch is already resident, so its pyramid is built beside this batch's FAST
                 # (every step still builds exactly one pyramid; the one of step 0 is built in-step)
                 P["orb"].hint_next_batch_device(nxt.data_ptr())
-            if defer:
-                P["orb"].set_output_event(P["ext_done"][s].cuda_event)   # recorded by the library when batch i's outputs are complete
+            if defer or lib_events:
+                P["orb"].set_output_event(P["ext_done"][s].cuda_event, defer=defer)   # recorded by the library: batch i's outputs complete
             P["orb"].extract_batch_device(img.data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][s].data_ptr(),
                                           P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
-            if not defer:
+            if not (defer or lib_events):
                 P["ext_done"][s].record(T)
         if j >= 0:
             if M is not T:
@@ -510,8 +518,8 @@ def main():
     orb.enable_stage_timing(True)
     with torch.cuda.stream(P["stream"]):
         for k in range(args.steps):
-            if defer:
-                orb.set_output_event(P["ext_done"][k % NSETS].cuda_event)
+            if defer or lib_events:
+                orb.set_output_event(P["ext_done"][k % NSETS].cuda_event, defer=defer)
             if args.prefetch:
                 orb.hint_next_batch_device(d_img[(k + 1) % NB].data_ptr())
             orb.extract_batch_device(d_img[k % NB].data_ptr(), B, rows, cols, cols, rows * cols, P["kps"][P["cur"]].data_ptr(),
@@ -520,7 +528,7 @@ def main():
     ov_ms, ov_calls = orb.stage_times()
     orb.enable_stage_timing(False)
     # (b) every kernel alone on the stream: the kernel's own duration, which the rooflines below are computed from
-    orb.set_output_event(0)
+    orb.set_output_event(0, defer=False)
     orb.set_overlap(False)
     orb.enable_stage_timing(True)
     with torch.cuda.stream(P["stream"]):

@@ -60,6 +60,12 @@ struct dvs_orb {
   hipEvent_t output_event = nullptr;       // caller's event: outputs complete (dvs_orb_set_output_event => deferred descriptor stage)
   hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // deferred mode: descriptor stage finished (auxiliary stream) / quad-tree finished
   bool out_pending = false;                // the previous call's descriptor stage is still only ordered on the auxiliary stream
+  hipEvent_t guard_event = nullptr;        // caller's event: outputs may only be overwritten behind it (dvs_orb_set_reuse_guard_event)
+  hipEvent_t ev_end = nullptr;             // end of the previous call (gate of the next call's prefetch chain: no extra record)
+  hipEvent_t gate_event = nullptr;         // = ev_end or the caller's output event, whichever the last call recorded at its end
+  bool defer_outputs = false;              // dvs_orb_set_defer_outputs
+  bool pf_joined = false;                  // the prefetched pyramid's completion already precedes the main stream (joined through the blur)
+  int env_hops = 1;                        // DVS_HOPS=0: round-2a placement of the cross-stream joins (A/B)
   hipEvent_t after_fast_event = nullptr;   // caller's event, recorded on the main stream behind FAST (dvs_orb_set_after_fast_event)
   const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
   int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
@@ -588,8 +594,10 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   if (prefetched) {
     std::swap(h->d_pyr, h->d_pyr_alt);
-    DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
+    // the previous call joined the chain through its blur (below): no barrier packet in front of FAST then
+    if (!h->pf_joined) DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
   }
+  h->pf_joined = false;
   if (la_hit) {
     h->cset ^= 1;
     DVS_HIP(hipStreamWaitEvent(st, h->ev_front, 0));
@@ -663,7 +671,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     ImgSrc nsrc = src;
     nsrc.img0 = next_img0;
     hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
-    DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
+    if (!after_fast && h->env_hops && h->gate_event) {
+      gate = h->gate_event;                // the previous call's end, recorded there: every reader of d_pyr_alt precedes it
+    } else {
+      DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
+    }
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
     if (pend) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_out, 0));   // ... except a deferred descriptor stage
     const bool la = h->env_lookahead && h->fa_stream && !after_fast;
@@ -695,6 +707,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     return DVS_OK;
   };
   if (!h->env_pf_after_fast) DVS_TRY(launch_prefetch(false));
+  // joins that only the descriptor stage needs ride on the blur's (auxiliary) stream, off the main stream's critical path, and are
+  // enqueued there BEFORE FAST so that their barrier packets are consumed while FAST runs: the caller's reuse guard (outputs are
+  // written by the descriptor stage, which waits for the blur) and the completion of the next batch's level chain (then the next
+  // call's FAST needs no barrier packet in front of it; the chain ends before FAST does)
+  if (h->overlap && h->aux_stream) {
+    if (h->guard_event) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->guard_event, 0)); h->guard_event = nullptr; }
+    if (h->env_hops && (h->env_hops > 1 || !(h->defer_outputs && h->output_event)) && h->pf_valid && !sharded && !h->env_pf_after_fast) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_prefetch, 0)); h->pf_joined = true; }
+  }
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap); nothing to do when it ran ahead
   if (!la_hit) {
     if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
@@ -726,10 +746,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
   // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
   hipStream_t bst = st;
-  if (h->after_fast_event) DVS_HIP(hipEventRecord(h->after_fast_event, st));
+  hipEvent_t ev_fastdone = h->ev_pyr;
+  if (h->after_fast_event) {
+    DVS_HIP(hipEventRecord(h->after_fast_event, st));
+    if (h->env_hops) ev_fastdone = h->after_fast_event;   // one record serves the caller and the blur's fork
+  }
   if (h->overlap) {
     bst = h->aux_stream;
-    DVS_HIP(hipEventRecord(h->ev_pyr, st));
+    if (ev_fastdone == h->ev_pyr) DVS_HIP(hipEventRecord(h->ev_pyr, st));
   }
   // 3. quad-tree
   if (pend) DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));   // the deferred descriptor stage reads the lists the quad-tree rewrites
@@ -744,7 +768,12 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
-  if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, h->ev_pyr, 0));
+  if (bst != st) {
+    DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
+  } else if (h->guard_event) {
+    DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
+  }
+  h->guard_event = nullptr;   // one-shot
   h->timer.begin(DVS_STAGE_BLUR, bst);
   // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
   // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
@@ -775,7 +804,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_describe<2>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
     h->timer.end(st);
-  } else if (bst != st && may_defer && h->output_event && !sharded) {
+  } else if (bst != st && may_defer && h->output_event && h->defer_outputs && !sharded) {
     // deferred: the descriptor stage follows the blur on the auxiliary stream and the main stream is NOT joined — the next call's
     // FAST (vector-ALU bound, light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the
     // caller's output event.
@@ -794,6 +823,12 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
     h->timer.end(st);
+  }
+  if (!h->out_pending) {   // end of the call on the main stream: the caller's output event, or our own — next call's prefetch gate
+    h->gate_event = (may_defer && h->output_event) ? h->output_event : h->ev_end;
+    DVS_HIP(hipEventRecord(h->gate_event, st));
+  } else {
+    h->gate_event = nullptr;   // deferred: the next call gates on ev_out
   }
   DVS_HIP(hipGetLastError());
   h->last_nimg = nimg;
@@ -840,6 +875,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e9 = getenv("DVS_FAST_BYTE_DMA")) h->fast_byte_dma = atoi(e9) ? probe_byte_dma(device, h->stream) : 0;
   if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
   if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
+  if (const char* eh = getenv("DVS_HOPS")) h->env_hops = atoi(eh);
   if (const char* e8 = getenv("DVS_BLUR_MFMA")) h->env_blur_mfma = atoi(e8);
   if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
   if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
@@ -855,6 +891,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_end, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_oct, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_prefetch, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming) != hipSuccess ||
@@ -894,6 +931,7 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->ev_fast) (void)hipEventDestroy(h->ev_fast);
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
   if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+  if (h->ev_end) (void)hipEventDestroy(h->ev_end);
   if (h->ev_oct) (void)hipEventDestroy(h->ev_oct);
   if (h->ev_prefetch) (void)hipEventDestroy(h->ev_prefetch);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
@@ -1029,6 +1067,18 @@ dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int3
 dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event) {
   DVS_ARG(h);
   h->output_event = (hipEvent_t)hip_event;
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on) {
+  DVS_ARG(h);
+  h->defer_outputs = on != 0;
+  return DVS_OK;
+}
+
+dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event) {
+  DVS_ARG(h);
+  h->guard_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 

@@ -112,6 +112,11 @@ dvs_status dvs_event_synchronize(void* event) {
   DVS_HIP(hipEventSynchronize((hipEvent_t)event));
   return DVS_OK;
 }
+dvs_status dvs_event_record(void* event, void* stream) {
+  DVS_ARG(event);
+  DVS_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return DVS_OK;
+}
 dvs_status dvs_stream_wait_event(void* stream, void* event) {
   DVS_ARG(event);
   DVS_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));

@@ -79,10 +79,13 @@ def lib():
     L.dvs_event_create.argtypes = [i32, C.POINTER(vp)]
     L.dvs_event_destroy.argtypes = [vp]
     L.dvs_event_synchronize.argtypes = [vp]
+    L.dvs_event_record.argtypes = [vp, vp]
     L.dvs_stream_wait_event.argtypes = [vp, vp]
     L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
     L.dvs_orb_set_after_fast_event.argtypes = [vp, vp]
     L.dvs_orb_set_output_event.argtypes = [vp, vp]
+    L.dvs_orb_set_defer_outputs.argtypes = [vp, i32]
+    L.dvs_orb_set_reuse_guard_event.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]

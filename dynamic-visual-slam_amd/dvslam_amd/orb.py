@@ -105,10 +105,16 @@ class ORBextractor:
         beside this batch's descriptor stage and the match that follows; one-shot, results unchanged"""
         check(self._L.dvs_orb_hint_next_batch_device(self._h, d_next_imgs))
 
-    def set_output_event(self, hip_event):
-        """hipEvent_t (int, 0 to clear): deferred descriptor stage — outputs of a device-resident call are complete when this event
-        is (dvs_orb_set_output_event)"""
+    def set_output_event(self, hip_event, defer=None):
+        """hipEvent_t (int, 0 to clear) recorded where a device-resident call's outputs are complete; defer=True/False also switches
+        the deferred descriptor stage (dvs_orb_set_defer_outputs)"""
         check(self._L.dvs_orb_set_output_event(self._h, hip_event or None))
+        if defer is not None:
+            check(self._L.dvs_orb_set_defer_outputs(self._h, int(bool(defer))))
+
+    def set_reuse_guard_event(self, hip_event):
+        """one-shot: the next device-resident call writes its outputs only behind this hipEvent_t"""
+        check(self._L.dvs_orb_set_reuse_guard_event(self._h, hip_event or None))
 
     def set_after_fast_event(self, hip_event):
         """hipEvent_t (int, 0 to clear) recorded behind FAST by every following extract_batch_device (scheduling hook)"""

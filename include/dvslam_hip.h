@@ -47,10 +47,11 @@ dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_s
 dvs_status dvs_stream_synchronize(void* stream);
 dvs_status dvs_stream_destroy(void* stream);
 /* hipEvent_t helpers for callers without a HIP toolchain of their own (the scheduling hooks dvs_orb_set_after_fast_event /
- * dvs_orb_set_output_event take any hipEvent_t): create (timing disabled), destroy, host wait, stream wait */
+ * dvs_orb_set_output_event take any hipEvent_t): create (timing disabled), destroy, host wait, record, stream wait */
 dvs_status dvs_event_create(int32_t device, void** out_event);
 dvs_status dvs_event_destroy(void* event);
 dvs_status dvs_event_synchronize(void* event);
+dvs_status dvs_event_record(void* event, void* stream);
 dvs_status dvs_stream_wait_event(void* stream, void* event);
 /* "gfx950" etc. for the given device, "" on error */
 dvs_status dvs_device_arch(int32_t device, char* buf, int32_t cap);
@@ -131,14 +132,20 @@ dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs
  * the PREVIOUS batch's match (BFMatcher call of frontend.cpp:1123) — makes its stream wait on it so that the work runs beside
  * that phase instead of beside FAST.  Results are unaffected. */
 dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event);
-/* Deferred outputs for a pipelined caller: while `hip_event` (a hipEvent_t of the caller, NULL to clear) is set, a device-resident
- * extraction whose pyramid was announced (dvs_orb_hint_next_batch_device) leaves its descriptor stage — fetch-bound gathers — on the
- * handle's auxiliary stream WITHOUT joining the main stream, and records the event behind it: keypoints, descriptors and counts of
- * that call are complete when the event is, not when the main stream reaches the end of the call.  The next call's FAST then starts
- * immediately and runs beside that descriptor stage; the library orders everything else (the next quad-tree, blur and prefetch wait
- * for it).  The caller orders its consumers on the event and must leave the call's level-0 images untouched until then.
- * dvs_orb_synchronize waits for a deferred stage too.  Results are unaffected. */
+/* Output event of a pipelined caller: while `hip_event` (a hipEvent_t of the caller, NULL to clear) is set, every device-resident
+ * extraction records it where its keypoints, descriptors and counts are complete (the library also uses it as the gate of the next
+ * call's prefetch chain, which saves a record of its own).  With dvs_orb_set_defer_outputs(h, 1) that point is NOT the end of the
+ * call on the main stream: the descriptor stage — fetch-bound gathers — stays on the handle's auxiliary stream without joining the
+ * main one, so that the next call's FAST starts immediately and runs beside it; the library orders everything else (the next
+ * quad-tree, blur and prefetch wait for it), the caller orders its consumers on the event and must leave the call's level-0 images
+ * untouched until then.  dvs_orb_synchronize waits for a deferred stage too.  Results are unaffected. */
 dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event);
+dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on);
+/* Reuse guard (one-shot, consumed by the next device-resident extraction): the call's OUTPUT buffers may still be read by work of
+ * the caller on another stream (the match of an earlier batch); the extraction writes them only behind `hip_event`.  Same effect as
+ * hipStreamWaitEvent on the main stream before the call, but the wait rides on the blur's stream, off the critical path in front of
+ * FAST (outputs are only written by the descriptor stage, which joins the blur). */
+dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event);
 
 /* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
  * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per

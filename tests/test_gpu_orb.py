@@ -332,12 +332,15 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
     mat = BFMatcher(stream=mstream)
     ev_out = [_lib.event_create(0) for _ in range(NBATCH)]
     ev_fast = _lib.event_create(0)
+    ev_match = [_lib.event_create(0) for _ in range(NBATCH)]
     g.set_after_fast_event(ev_fast)
     outs = [mk() for _ in range(NBATCH)]
     idx = [_lib.DeviceBuffer(B * cap * 4) for _ in range(NBATCH)]; dist = [_lib.DeviceBuffer(B * cap * 4) for _ in range(NBATCH)]
     for b in range(NBATCH):
         k, d, n = outs[b]
-        g.set_output_event(ev_out[b])
+        g.set_output_event(ev_out[b], defer=(b % 2 == 0))     # deferred and joined calls alternate
+        if b >= 2:
+            g.set_reuse_guard_event(ev_match[b - 2])              # (formally: the match that read the oldest outputs)
         if b + 1 < NBATCH:
             g.hint_next_batch_device(d_img[b + 1].ptr)
         g.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr)
@@ -347,6 +350,7 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
             pk = outs[b - 2] if b >= 2 else None
             mat.match_sequence_device(outs[b - 1][1].ptr, outs[b - 1][2].ptr, cap, B, pk[1].ptr + (B - 1) * cap * 32 if pk else 0,
                                       pk[2].ptr + (B - 1) * 4 if pk else 0, idx[b - 1].ptr, dist[b - 1].ptr)
+            assert L.dvs_event_record(ev_match[b - 1], mstream) == 0
     g.synchronize(); _lib.stream_synchronize(mstream)
     for b in range(NBATCH):
         k, d, n = outs[b]
@@ -368,8 +372,8 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
             if b == 0 and f == 0:
                 continue                      # no predecessor: nothing is written for it
             assert (a[f, :n1[f]] == r[f, :n1[f]]).all() and (ad[f, :n1[f]] == rd[f, :n1[f]]).all(), (b, f)
-    g.set_output_event(0); g.set_after_fast_event(0)
-    for e in ev_out + [ev_fast]:
+    g.set_output_event(0, defer=False); g.set_after_fast_event(0)
+    for e in ev_out + ev_match + [ev_fast]:
         L.dvs_event_destroy(e)
     _lib.stream_destroy(mstream)
 
