@@ -1170,6 +1170,15 @@ dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int3
   return read_packed(h, h->d_pts + (uint64_t)frame * h->geom.ptsPerFrame + h->geom.lv[level].ptsOff, cnt, xys);
 }
 
+dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64) {
+  DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  const LevelGeom& L = h->geom.lv[level];
+  DVS_HIP(hipMemcpy(out64, h->d_nodeof + ((L.ptsOff + L.ptsCap - 128) & ~1ull), 64 * 8, hipMemcpyDeviceToHost));
+  return DVS_OK;
+}
+
 dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
   DVS_ARG(h && xys && n && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
   DVS_HIP(hipSetDevice(h->device));

@@ -1274,6 +1274,13 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     return;
   }
   const LevelGeom& L = g->lv[level];
+  // diagnostics (DVS_DEBUG bit 1): thread 0 of frame 0 stamps the 100 MHz wall clock at phase boundaries into the unused tail of
+  // the level's global node-of-point block (dvs_test_octree_stamps)
+  unsigned long long* stamps = (unsigned long long*)(nodeOfAll + ((L.ptsOff + L.ptsCap - 128) & ~1ull));
+  int si = 0;
+  const bool stamping = (g->debug & 2) && tid == 0 && f == 0;
+#define QT_STAMP(id) do { if (stamping && si < 62) { stamps[1 + si] = ((unsigned long long)(id) << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFull); si++; stamps[0] = si; } } while (0)
+  QT_STAMP(1);
 
   QtShared sh;
   {
@@ -1299,13 +1306,20 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
 
   // ---- gather: candidate order = cells row-major, pixels row-major inside a cell -------------
   {
+    // cell offsets also live in LDS while they fit (the child-count array is dead until the roots exist): the gather below then has
+    // ONE global round trip per candidate instead of two dependent ones
+    int* coL = sh.childCnt;
+    const bool coLds = L.nCells <= 4 * nmax;
     int carry = 0;
     for (int b = 0; b < L.nCells; b += OCT_T) {
       const int c = b + tid;
       const int v = c < L.nCells ? cc[c] : 0;
       int tot;
       const int ex = block_excl_scan_rt(v, wsum, tot);
-      if (c < L.nCells) co[c] = carry + ex;
+      if (c < L.nCells) {
+        co[c] = carry + ex;
+        if (coLds) coL[c] = carry + ex;
+      }
       carry += tot;
     }
     if (tid == 0) { s_n = carry; candTotal[f * g->nlevels + level] = carry; }
@@ -1313,27 +1327,41 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     const bool inLds = s_n <= ptsLdsCap;
     if (inLds) { pts = ldsPts; nodeOf = ldsNodeOf; }
     // cell of candidate i: every cell stamps its index over its own slot range (cells hold a handful of candidates each, the
-    // stores are fire-and-forget), then each candidate is one independent lookup — instead of a serial per-cell copy chain
-    // (the first version) or a 10-step binary search over the offsets per candidate (the second).  The stamps live in the
-    // node-of-point array, which is not in use yet.
+    // stores are fire-and-forget), then each candidate is one independent lookup.  The stamps live in the node-of-point array,
+    // which is not in use yet.
     int* cellOf = inLds ? ldsNodeOf : nodeOf;
     const int total = s_n;
     for (int c = tid; c < L.nCells; c += OCT_T) {
-      const int b0 = co[c], cn = cc[c];
+      const int b0 = coLds ? coL[c] : co[c], cn = cc[c];
       for (int k = 0; k < cn; k++) cellOf[b0 + k] = c;
     }
     __syncthreads();
-    for (int i = tid; i < total; i += OCT_T) {
-      const int c = cellOf[i];
-      const uint32_t v = cnd[(uint64_t)c * L.cellCap + (i - co[c])];
-      gpts[i] = v;                      // kept in HBM too: dvs_orb_get_candidates reads it
-      if (inLds) ldsPts[i] = v;
+    // four candidates per thread and trip: their loads are independent, so the global latency is paid once per trip (the level-0
+    // workgroup walks ~6000 candidates with 256 threads: 24 dependent round trips before, 6 now)
+    for (int i0 = tid; i0 < total; i0 += 4 * OCT_T) {
+      int cidx[4], off[4];
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; cidx[u] = i < total ? cellOf[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) off[u] = coLds ? coL[cidx[u]] : co[cidx[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; v[u] = i < total ? cnd[(uint64_t)cidx[u] * L.cellCap + (i - off[u])] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * OCT_T;
+        if (i < total) {
+          gpts[i] = v[u];                 // kept in HBM too: dvs_orb_get_candidates reads it
+          if (inLds) ldsPts[i] = v[u];
+        }
+      }
     }
     __syncthreads();
   }
   const int n = s_n;
   const int N = L.N;
   int cur = 0;
+  QT_STAMP(2);
 
   // ---- roots (:559-601) ------------------------------------------------------------------------
   {
@@ -1373,12 +1401,14 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     __syncthreads();
   }
 
+  QT_STAMP(3);
   // ---- main loop ---------------------------------------------------------------------------------
   bool finish = (n == 0);
   while (!finish) {
     const int S = s_S;
     // full sweep: split every multi-point node (:622-681)
     qt_count_children(sh.nodes_(cur), S, sh.childCnt, pts, nodeOf, n);
+    QT_STAMP(4);
     int nExpandLocal = 0;
     {
       // children block: node k's children sit in front of the children of all earlier nodes
@@ -1420,7 +1450,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       __syncthreads();
       nUnsplit = s_c;
     }
+    QT_STAMP(5);
     qt_rebuild(sh, cur, S, T, pts, nodeOf, n, wsum);
+    QT_STAMP(6);
     cur ^= 1;
     int Snew = T + nUnsplit;
     if (tid == 0) s_S = Snew;
@@ -1430,6 +1462,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
 
     // ordered phase (:692-753)
     int m = qt_build_expand_list(sh, cur, T, wsum);
+    QT_STAMP(7);
     while (!finish) {
       const int Sb = s_S;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
@@ -1441,7 +1474,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       }
       for (int k = tid; k < Sb; k += OCT_T) sh.flag[k] = 0;
       __syncthreads();
+      QT_STAMP(8);
       if (!(g->debug & 1)) qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
+      QT_STAMP(9);
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
       if (tid == 0) s_c = 0;
@@ -1473,7 +1508,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
         sh.posArr[k] = Tm - sh.ecum[r];
       }
       __syncthreads();
+      QT_STAMP(10);
       qt_rebuild(sh, cur, Sb, Tm, pts, nodeOf, n, wsum);
+      QT_STAMP(11);
       cur ^= 1;
       const int Sn = Tm + (Sb - M);
       if (tid == 0) s_S = Sn;
@@ -1483,6 +1520,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     }
   }
 
+  QT_STAMP(12);
   // ---- best point per node (:757-776), list order = output order ----------------------------------
   const int S = (n == 0) ? 0 : s_S;
   QNode* nodes = sh.nodes_(cur);
@@ -1501,6 +1539,8 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     if (k < N + 4) outp[k] = pts[i];
   }
   if (tid == 0) lvlKpCount[f * g->nlevels + level] = min(S, N + 4);
+  QT_STAMP(13);
+#undef QT_STAMP
 }
 
 #undef OCT_T

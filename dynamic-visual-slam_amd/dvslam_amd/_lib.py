@@ -121,6 +121,7 @@ def lib():
     L.dvs_test_quartic_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
     L.dvs_test_p3p.argtypes = [vp, vp, vp]
     L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
+    L.dvs_test_octree_stamps.argtypes = [vp, i32, vp]
     L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):
         L.dvs_ba_create.argtypes = [i32, C.POINTER(vp)]
