@@ -1064,12 +1064,19 @@ __device__ __forceinline__ void qt_count_children(const QNode* nodes, int S, int
                                                   const int* nodeOf, int n) {
   for (int k = threadIdx.x; k < 4 * S; k += OCT_T) childCnt[k] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += OCT_T) {
-    const int k = nodeOf[i];
-    if (k >= 0) {
-      const uint32_t p = pts[i];
-      atomicAdd(&childCnt[4 * k + qt_quadrant(nodes[k], pt_x(p), pt_y(p))], 1);
-    }
+  // four points per thread and trip: the dependent LDS chain (node-of-point -> node -> counter) of one point is ~400 cycles of latency
+  // and a thread of the level-0 workgroup walks ~24 points; with the loads of four points issued together a trip costs one chain
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * OCT_T) {
+    int k[4];
+    uint32_t p[4];
+    QNode nd[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; k[u] = i < n ? nodeOf[i] : -1; p[u] = i < n ? pts[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) nd[u] = nodes[max(k[u], 0)];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k[u] >= 0) atomicAdd(&childCnt[4 * k[u] + qt_quadrant(nd[u], pt_x(p[u]), pt_y(p[u]))], 1);
   }
   __syncthreads();
 }
@@ -1109,17 +1116,31 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += OCT_T) {
-    const int k = nodeOf[i];
-    if (k < 0) continue;
-    const int pa = sh.posArr[k];
-    if (pa < 0) { nodeOf[i] = -(pa + 1); continue; }
-    const uint32_t p = pts[i];
-    const int q = qt_quadrant(old[k], pt_x(p), pt_y(p));
-    const int mask = qt_mask(sh.childCnt, k);
-    const int np = pa + __popc(mask >> (q + 1));
-    if (sh.childCnt[4 * k + q] == 1) { nw[np].pt = i; nodeOf[i] = -1; }
-    else nodeOf[i] = np;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * OCT_T) {   // four points per trip, loads first (see qt_count_children)
+    int k[4], pa[4], c4[4][4];
+    uint32_t p[4];
+    QNode nd[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; k[u] = i < n ? nodeOf[i] : -1; p[u] = i < n ? pts[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int kk = max(k[u], 0);
+      pa[u] = sh.posArr[kk];
+      nd[u] = old[kk];
+#pragma unroll
+      for (int q = 0; q < 4; q++) c4[u][q] = sh.childCnt[4 * kk + q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * OCT_T;
+      if (k[u] < 0) continue;
+      if (pa[u] < 0) { nodeOf[i] = -(pa[u] + 1); continue; }
+      const int q = qt_quadrant(nd[u], pt_x(p[u]), pt_y(p[u]));
+      const int mask = (c4[u][0] > 0 ? 1 : 0) | (c4[u][1] > 0 ? 2 : 0) | (c4[u][2] > 0 ? 4 : 0) | (c4[u][3] > 0 ? 8 : 0);
+      const int np = pa[u] + __popc(mask >> (q + 1));
+      if (c4[u][q] == 1) { nw[np].pt = i; nodeOf[i] = -1; }
+      else nodeOf[i] = np;
+    }
   }
   __syncthreads();
 }
@@ -1368,10 +1389,27 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     const int nIni = L.nIni;
     for (int k = tid; k < nIni; k += OCT_T) sh.childCnt[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += OCT_T) {
-      const int r = (int)__fdiv_rn((float)pt_x(pts[i]), L.hX);  // vpIniNodes[kp.pt.x/hX]
-      nodeOf[i] = r;  // root index for now
-      atomicAdd(&sh.childCnt[r], 1);
+    for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+      uint32_t p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; p[u] = i < n ? pts[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * OCT_T;
+        const bool v = i < n;
+        const int r = v ? (int)__fdiv_rn((float)pt_x(p[u]), L.hX) : -1;  // vpIniNodes[kp.pt.x/hX]
+        if (v) nodeOf[i] = r;  // root index for now
+        // there are only round(w / h) roots (2 at 16:9): thousands of atomics on two addresses serialise, so a wavefront counts
+        // its points per root with a ballot and adds once
+        if (nIni <= 4) {
+          for (int k = 0; k < nIni; k++) {
+            const unsigned long long b = __ballot(r == k);
+            if (lane_id() == 0 && b) atomicAdd(&sh.childCnt[k], __popcll(b));
+          }
+        } else if (v) {
+          atomicAdd(&sh.childCnt[r], 1);
+        }
+      }
     }
     __syncthreads();
     int carry = 0;
@@ -1393,10 +1431,22 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     }
     if (tid == 0) s_S = carry;
     __syncthreads();
-    for (int i = tid; i < n; i += OCT_T) {
-      const int pos = sh.posArr[nodeOf[i]];
-      if (sh.nodes_(0)[pos].cnt == 1) { sh.nodes_(0)[pos].pt = i; nodeOf[i] = -1; }
-      else nodeOf[i] = pos;
+    for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+      int r[4], pos[4], cnt[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; r[u] = i < n ? nodeOf[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) pos[u] = sh.posArr[r[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cnt[u] = sh.nodes_(0)[max(pos[u], 0)].cnt;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * OCT_T;
+        if (i < n) {
+          if (cnt[u] == 1) { sh.nodes_(0)[pos[u]].pt = i; nodeOf[i] = -1; }
+          else nodeOf[i] = pos[u];
+        }
+      }
     }
     __syncthreads();
   }
@@ -1527,9 +1577,14 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   int* best = sh.childCnt;
   for (int k = tid; k < S; k += OCT_T) best[k] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += OCT_T) {
-    const int k = nodeOf[i];
-    if (k >= 0) atomicMax((unsigned int*)&best[k], ((uint32_t)pt_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i));
+  for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+    int k[4];
+    uint32_t p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; k[u] = i < n ? nodeOf[i] : -1; p[u] = i < n ? pts[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k[u] >= 0) atomicMax((unsigned int*)&best[k[u]], ((uint32_t)pt_s(p[u]) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u * OCT_T)));
   }
   __syncthreads();
   uint32_t* outp = lvlKp + (uint64_t)f * g->kpBlock + L.kpOff;
