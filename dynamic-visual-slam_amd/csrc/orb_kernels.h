@@ -891,23 +891,21 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   wave_lds_fence();
   const int tmin = g->minTh, tini = g->iniTh;
   const unsigned long long ltmask = (1ull << lane) - 1ull;
-  // 2. rejection test, 4 pixels per lane
+  // 2. rejection test, 4 pixels per lane.  Lane = (row of the trip, dword column): the column group, its border mask and the
+  //    lane's offsets are fixed for the whole cell, a trip advances every lane by the same number of rows, so the loop carries no
+  //    index arithmetic (round 2a derived row and column from a flat index each trip: ~11 of its 122 instructions)
   const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
   const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
-  const int total = ng * ih;
-  const float invng = 1.0f / (float)ng;
-  // column masks of the first / last dword column of the interior: bit j = pixel j of the group is an interior column
-  const uint32_t cmFirst = (0xFu << (cx0 & 3)) & 0xFu, cmLast = 0xFu >> (3 - ((cx1 - 1) & 3));
+  const int rpt = 64 / ng;                    // rows per trip (ng <= 19 for cells up to 76 pixels)
+  const int rsub = (int)(((float)lane + 0.5f) * (1.0f / (float)ng)), gi = lane - rsub * ng;
+  // column mask of this lane's group: bit j = pixel j of the group is an interior column (first / last group only partly)
+  uint32_t cmLane = rsub < rpt ? 0xFu : 0u;
+  if (gi == 0) cmLane &= (0xFu << (cx0 & 3)) & 0xFu;
+  if (gi == ng - 1) cmLane &= 0xFu >> (3 - ((cx1 - 1) & 3));
   int nwork = 0;
-  const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
-  for (int i0 = 0; i0 < total; i0 += 64) {
-    const int idx = i0 + lane;
-    const bool valid = idx < total;
-    const int row = valid ? (int)(((float)idx + 0.5f) * invng) : 0;
-    const int gi = valid ? mad_i24(row, -ng, idx) : 0;  // idx - row * ng; 24-bit forms: v_mul_lo_u32 / v_mad_u64_u32 run at 1/4 rate
-    const int y = row + 3;
-    const int wcol = g0 + gi;  // word column
-    const uint32_t* rp = t32 + mad_i24(y, P / 4, wcol);
+  const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile) + mad_i24(rsub + 3, P / 4, g0 + gi);   // centre word of the lane's first row
+  int cbase = mad_i24(rsub, P, (g0 + gi) * 4 - 3);   // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left
+  for (int row0 = 0; row0 < ih; row0 += rpt, rp += rpt * (P / 4), cbase += rpt * P) {
     const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
     const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
     const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
@@ -939,19 +937,13 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
       sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
     }
-    // sign bits 15 / 31 of the two halves -> one 4-bit mask (bit j = pixel j passes), gated by the interior-column mask
+    // sign bits 15 / 31 of the two halves -> one 4-bit mask (bit j = pixel j passes), gated by the lane's column mask and the
+    // cell's last row
     uint32_t m4 = ((sgn[0] >> 15) & 0x00010001u) | ((sgn[1] >> 13) & 0x00040004u);  // bits 0, 16 | 2, 18
-    m4 = (m4 | (m4 >> 15)) & 0xFu;
-    uint32_t cm = valid ? 0xFu : 0u;
-    cm &= gi == 0 ? cmFirst : 0xFu;
-    cm &= gi == ng - 1 ? cmLast : 0xFu;
-    m4 &= cm;
+    m4 = (m4 | (m4 >> 15)) & (row0 + rsub < ih ? cmLane : 0u);
     const int cnt = __popc(m4);
     const int incl = wave_incl_scan_dpp(cnt);
     int pos = nwork + incl - cnt;
-    // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left of them: the score stage then addresses every
-    // ring sample with a non-negative immediate
-    const int cbase = mad_i24(row, P, wcol * 4 - 3);   // (y - 3) * P + x - 3
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (m4 & (1u << j)) work[pos++] = (uint16_t)(cbase + j);
