@@ -660,19 +660,40 @@ __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
 }
 
+// publish the status record to the host's pinned copy (read after the stream synchronises: no D2H copy command), and — last kernel of
+// a trial step — re-arm the device record for the next one (was a one-thread launch of its own)
+__device__ __forceinline__ void lm_publish(const LmStatus* st, LmStatus* host) {
+  *host = *st;
+  __threadfence_system();
+}
+
 __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __restrict__ part, const double* __restrict__ cost,
-                                                  LmStatus* __restrict__ st) {
+                                                  LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
   __shared__ double sm[256];
   double sn = 0.0, xn = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) { sn += part[2 * i]; xn += part[2 * i + 1]; }
   const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
-  if (threadIdx.x == 0) { st->sn = a; st->xn = b; st->cand_cost = *cost; }
+  if (threadIdx.x == 0) {
+    st->sn = a; st->xn = b; st->cand_cost = *cost;
+    lm_publish(st, host);
+    st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0;
+  }
+}
+
+// the accepted candidate becomes the point of the next iteration (one launch instead of three copy commands)
+__global__ __launch_bounds__(256) void k_lm_accept(int K, int L, const double* __restrict__ q, const double* __restrict__ t,
+                                                   const double* __restrict__ X, double* __restrict__ q0, double* __restrict__ t0,
+                                                   double* __restrict__ X0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 4 * K) q0[i] = q[i];
+  if (i < 3 * K) t0[i] = t[i];
+  if (i < 3 * L) X0[i] = X[i];
 }
 
 // Ceres' gradient max-norm: |x - Plus(x, -g)|_inf over the active blocks, and the cost of the accepted point
 __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __restrict__ q0, const double* __restrict__ g,
                                                  const unsigned char* __restrict__ active, const double* __restrict__ cost,
-                                                 LmStatus* __restrict__ st) {
+                                                 LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
   __shared__ double sm[256];
   const int tid = threadIdx.x;
   double m = 0.0;
@@ -688,7 +709,7 @@ __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __r
   sm[tid] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
-  if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; }
+  if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; lm_publish(st, host); }
 }
 
 __global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; }
@@ -1267,14 +1288,13 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
   DVS_HIP(hipMemcpyAsync(h->d_X0, h->d_X, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
   LmStatus* S = h->h_status;
-  auto fetch_status = [&]() -> dvs_status {
-    DVS_HIP(hipMemcpyAsync(S, h->d_status, sizeof(LmStatus), hipMemcpyDeviceToHost, st));
+  auto fetch_status = [&]() -> dvs_status {   // the last kernel wrote the record into the pinned host copy (lm_publish)
     DVS_HIP(hipStreamSynchronize(st));
     return DVS_OK;
   };
   auto evaluate_full = [&]() -> dvs_status {  // Jacobian blocks, gradient, cost of the point in the evaluation buffers
     DVS_TRY(enqueue_eval(h, 1 | 2, true));
-    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status);
+    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, S);
     return fetch_status();
   };
   hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
@@ -1294,7 +1314,6 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     if (gmax <= gtol) { summary->termination = 0; break; }
     if (radius < 1e-32) { summary->termination = 0; break; }
     iteration++;
-    hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
     hipLaunchKernelGGL(k_lm_landmarks, dim3((L + K + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_W, h->d_lmStart, h->d_lmObs,
                        h->d_cam, h->d_scale, h->d_diag, h->d_active, radius, reuse_diagonal ? 0 : 1, h->d_Vinv, h->d_Ws, h->d_Y, h->d_status);
     hipLaunchKernelGGL(k_lm_observations, dim3((R + 255) / 256), dim3(256), 0, st, K, R, h->d_W, h->d_cam, h->d_lm, h->d_scale, h->d_active, h->d_Vinv,
@@ -1309,7 +1328,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,
                        h->d_q, h->d_t, h->d_X, h->d_normPart);
     DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
-    hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, h->d_status);
+    hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, h->d_status, S);
     DVS_HIP(hipGetLastError());
     DVS_TRY(fetch_status());
     const bool valid = S->ok && S->finite && S->model_change > 0.0;
@@ -1326,9 +1345,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     const double rel = cost_change / S->model_change;
     h->log(radius, rel > 1e-3 ? 1 : 2, cost_change, S->model_change, rel, S->cand_cost);
     if (rel > 1e-3) {
-      DVS_HIP(hipMemcpyAsync(h->d_q0, h->d_q, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
-      DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
-      DVS_HIP(hipMemcpyAsync(h->d_X0, h->d_X, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_lm_accept, dim3((std::max(4 * K, 3 * L) + 255) / 256), dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0);
       DVS_TRY(evaluate_full());
       x_cost = S->x_cost; gmax = S->gmax;
       summary->num_successful_steps++;
