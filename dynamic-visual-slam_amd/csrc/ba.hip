@@ -570,37 +570,54 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   }
 }
 
-// landmark steps by back-substitution (already negated), and each landmark's share of step.g and step^T H step
+// landmark steps by back-substitution (already negated), and each landmark's share of step.g and step^T H step.
+// Four lanes per landmark (three of them carry one coordinate m each): the kernel is a latency chain of ~10 observations x 2 passes
+// per landmark over 2000 landmarks, i.e. 8 workgroups with a thread per landmark (24 us); with a lane per coordinate it is 32
+// workgroups and a third of the loads per lane.  The quad exchanges b and the step by DPP-width shuffles.
 __global__ __launch_bounds__(256) void k_lm_backsub(int K, int L, const double* __restrict__ Hll, const double* __restrict__ g,
                                                     const int* __restrict__ lmStart, const int* __restrict__ lmObs,
                                                     const int* __restrict__ cam, const double* __restrict__ scale,
                                                     const unsigned char* __restrict__ active, const double* __restrict__ Vinv,
                                                     const double* __restrict__ Ws, double* __restrict__ step,
                                                     double* __restrict__ lmPart, LmStatus* __restrict__ st) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= L) return;
-  const int j0 = 6 * K + 3 * l;
-  double sg = 0.0, sHs = 0.0;
-  if (!active[j0]) {
-    for (int a = 0; a < 3; a++) step[j0 + a] = 0.0;
-  } else {
-    double b[3] = {g[j0] * scale[j0], g[j0 + 1] * scale[j0 + 1], g[j0 + 2] * scale[j0 + 2]};
-    for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int l = t >> 2, m = t & 3;
+  const bool on = l < L && m < 3;
+  const int lc = min(l, L - 1), mc = min(m, 2);
+  const int j0 = 6 * K + 3 * lc;
+  const bool act = active[j0] != 0;
+  const int e0 = lmStart[lc], e1 = lmStart[lc + 1];
+  double bm = g[j0 + mc] * scale[j0 + mc];
+  if (act)
+    for (int e = e0; e < e1; e++) {
       const int p = lmObs[e], c = cam[p];
-      for (int m = 0; m < 3; m++) for (int a = 0; a < 6; a++) b[m] -= Ws[18 * (size_t)p + 3 * a + m] * step[6 * c + a];
+      for (int a = 0; a < 6; a++) bm -= Ws[18 * (size_t)p + 3 * a + mc] * step[6 * c + a];
     }
-    const double* Vi = Vinv + 9 * (size_t)l;
-    double sl[3];
-    for (int a = 0; a < 3; a++) sl[a] = -(Vi[3 * a] * b[0] + Vi[3 * a + 1] * b[1] + Vi[3 * a + 2] * b[2]);
-    if (!(isfinite(sl[0]) && isfinite(sl[1]) && isfinite(sl[2]))) st->finite = 0;
-    for (int a = 0; a < 3; a++) { step[j0 + a] = sl[a]; sg += sl[a] * g[j0 + a] * scale[j0 + a]; }
-    for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) sHs += sl[a] * scale[j0 + a] * Hll[9 * (size_t)l + 3 * a + bb] * scale[j0 + bb] * sl[bb];
-    for (int e = lmStart[l]; e < lmStart[l + 1]; e++) {  // cross terms 2 step_c^T W step_l with the NEGATED camera step
+  const int base = (int)(threadIdx.x & 63) & ~3;
+  const double b0 = __shfl(bm, base), b1 = __shfl(bm, base + 1), b2 = __shfl(bm, base + 2);
+  const double* Vi = Vinv + 9 * (size_t)lc;
+  const double slm = act ? -(Vi[3 * mc] * b0 + Vi[3 * mc + 1] * b1 + Vi[3 * mc + 2] * b2) : 0.0;
+  if (on && act && !isfinite(slm)) st->finite = 0;
+  if (on) step[j0 + m] = slm;
+  const double s0 = __shfl(slm, base), s1 = __shfl(slm, base + 1), s2 = __shfl(slm, base + 2);
+  // this lane's terms: coordinate m of step.g, row m of step^T H_ll step, column m of the cross terms 2 step_c^T W step_l
+  double sg = 0.0, sHs = 0.0;
+  if (act) {
+    sg = slm * g[j0 + mc] * scale[j0 + mc];
+    sHs = slm * scale[j0 + mc] * (Hll[9 * (size_t)lc + 3 * mc] * scale[j0] * s0 + Hll[9 * (size_t)lc + 3 * mc + 1] * scale[j0 + 1] * s1 +
+                                  Hll[9 * (size_t)lc + 3 * mc + 2] * scale[j0 + 2] * s2);
+    for (int e = e0; e < e1; e++) {  // with the NEGATED camera step
       const int p = lmObs[e], c = cam[p];
-      for (int a = 0; a < 6; a++) for (int bb = 0; bb < 3; bb++) sHs += 2.0 * (-step[6 * c + a]) * Ws[18 * (size_t)p + 3 * a + bb] * sl[bb];
+      double w = 0.0;
+      for (int a = 0; a < 6; a++) w += (-step[6 * c + a]) * Ws[18 * (size_t)p + 3 * a + mc];
+      sHs += 2.0 * w * slm;
     }
   }
-  lmPart[2 * (size_t)l] = sg; lmPart[2 * (size_t)l + 1] = sHs;
+  if (m == 3) { sg = 0.0; sHs = 0.0; }
+  // quad sums in a fixed order (m = 0, 1, 2)
+  const double g0 = __shfl(sg, base), g1 = __shfl(sg, base + 1), g2 = __shfl(sg, base + 2);
+  const double h0 = __shfl(sHs, base), h1 = __shfl(sHs, base + 1), h2 = __shfl(sHs, base + 2);
+  if (l < L && m == 0) { lmPart[2 * (size_t)l] = (g0 + g1) + g2; lmPart[2 * (size_t)l + 1] = (h0 + h1) + h2; }
 }
 
 // negate the camera steps, add the camera terms, reduce: model_cost_change = -(step.g + step^T H step / 2)
@@ -1322,7 +1339,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), (2 * (size_t)n * n + n) * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
-    hipLaunchKernelGGL(k_lm_backsub, dim3((L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
+    hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_model, dim3(1), dim3(256), 0, st, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,
