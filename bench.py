@@ -426,25 +426,6 @@ def main():
         T, M, X = P["stream"], P["mstream"], P["xstream"]
         j = i - lag                      # the batch matched in this step
         sj = j % NSETS
-        prev_desc = prev_n = 0
-        if j > 0:
-            sp = (j - 1) % NSETS
-            qd, qn = P["desc"][sp][B - 1], P["n"][sp][B - 1:B]   # last frame of the batch before it (this rank's)
-            if collective:
-                # the one exchange step: every rank's last-frame block, this rank needs its predecessor's.  It depends only on
-                # that batch's extraction, so it runs on a side stream beside this step's and is joined before the match
-                X.wait_event(P["ext_done"][sp])
-                if comm is not None:
-                    prev_desc, prev_n = comm.exchange_boundary(X.cuda_stream, qd.data_ptr(), qn.data_ptr(), cap)
-                    P["xdone"].record(X)
-                else:
-                    with torch.cuda.stream(X):
-                        bd, bn = dvdist.exchange_boundary(qd, qn, cap)
-                        P["xdone"].record(X)
-                    P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
-                    prev_desc, prev_n = bd.data_ptr(), bn.data_ptr()
-            else:
-                prev_desc, prev_n = qd.data_ptr(), qn.data_ptr()
         if i >= NSETS and M is not T:
             guard = P["match_done"][(i - NSETS + 1) % NSETS]         # the last reader of the set this step overwrites
             if lib_events:
@@ -462,12 +443,31 @@ def main():
                                           P["desc"][s].data_ptr(), cap, P["n"][s].data_ptr())
             if not (defer or lib_events):
                 P["ext_done"][s].record(T)
+        prev_desc = prev_n = 0
+        if j >= 0 and collective:
+            # the one exchange step, once per global batch: every rank's LAST frame of batch j; a rank's first frame is matched
+            # against the frame before it in the global order — the previous rank's last frame of the same batch, or (rank 0) the
+            # last rank's of the batch before.  It depends only on batch j's extraction and is joined before the match.
+            qd, qn = P["desc"][sj][B - 1], P["n"][sj][B - 1:B]
+            X.wait_event(P["ext_done"][sj])
+            if comm is not None:
+                prev_desc, prev_n = comm.exchange_boundary(X.cuda_stream, qd.data_ptr(), qn.data_ptr(), cap)
+                P["xdone"].record(X)
+            else:
+                with torch.cuda.stream(X):
+                    bd, bn = dvdist.exchange_boundary(qd, qn, cap)
+                    P["xdone"].record(X)
+                P["prev"] = (bd, bn)     # keep the gathered block alive until the match has read it
+                prev_desc, prev_n = (bd.data_ptr(), bn.data_ptr()) if bd is not None else (0, 0)
+        elif j > 0:
+            sp = (j - 1) % NSETS         # one GPU: the previous batch's last frame, read in place
+            prev_desc, prev_n = P["desc"][sp][B - 1].data_ptr(), P["n"][sp][B - 1:B].data_ptr()
         if j >= 0:
             if M is not T:
                 M.wait_event(P["ext_done"][sj])
                 if lag:
                     M.wait_event(ev_fast)    # recorded behind this step's FAST by the extraction just enqueued
-            if j > 0 and collective:
+            if collective:
                 M.wait_event(P["xdone"])
             P["mat"].match_sequence_device(P["desc"][sj].data_ptr(), P["n"][sj].data_ptr(), cap, B, prev_desc, prev_n,
                                            P["idx"].data_ptr(), P["dist"].data_ptr())
@@ -499,7 +499,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # the pipelined match against the same job enqueued serially (outside the timed region): guards the event dependencies
     match_check = None; nj = None
-    if not collective and state["i"] >= 3:
+    if world == 1 and state["i"] >= 3:   # (under the launcher with one rank this also checks the block that came back from RCCL)
         jl = state["i"] - 1 - lag
         sj, sp = jl % NSETS, (jl - 1) % NSETS
         idx2 = torch.empty_like(P["idx"]); dist2 = torch.empty_like(P["dist"])

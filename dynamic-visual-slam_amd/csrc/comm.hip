@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(256) k_pack_boundary(const uint4* __restrict__
 struct dvs_comm {
   int device = 0, rank = 0, world = 1;
   NcclComm comm = nullptr;
-  uint8_t* gather[2] = {nullptr, nullptr};  // [world][block] twice: step i's match may still read one while step i+1 gathers
+  uint8_t* gather[3] = {nullptr, nullptr, nullptr};  // [world][block] x 3: a call's result points into this call's and the previous
+                                                     // call's buffer, and stays valid while the next call gathers into the third
+  long calls = 0;
   size_t block = 0;
   int turn = 0;
 };
@@ -144,14 +146,16 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   DVS_ARG(((uintptr_t)d_desc_last) % 16 == 0);
   DVS_HIP(hipSetDevice(c->device));
   const size_t blk = dvs_boundary_block_bytes(cap);
-  if (c->block != blk) {  // (re)allocate the two gather buffers once per capacity: nothing is allocated per step
+  if (c->block != blk) {  // (re)allocate the three gather buffers once per capacity: nothing is allocated per step
     DVS_HIP(hipDeviceSynchronize());
     for (uint8_t*& p : c->gather) { if (p) DVS_HIP(hipFree(p)); p = nullptr; }
     for (uint8_t*& p : c->gather) DVS_HIP(hipMalloc((void**)&p, blk * (size_t)c->world));
-    c->block = blk;
+    c->block = blk; c->calls = 0; c->turn = 0;
   }
   uint8_t* g = c->gather[c->turn];
-  c->turn ^= 1;
+  const uint8_t* gprev = c->calls > 0 ? c->gather[(c->turn + 2) % 3] : nullptr;
+  c->turn = (c->turn + 1) % 3;
+  c->calls++;
   hipStream_t st = (hipStream_t)stream;
   uint8_t* mine = g + (size_t)c->rank * blk;
   const int rows16 = cap * 2, blk16 = (int)(blk / 16);
@@ -159,9 +163,11 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   DVS_HIP(hipGetLastError());
   // in place: this rank's block already sits at its slot of the receive buffer
   DVS_NCCL(g_rccl.AllGather(mine, g, blk, kNcclUint8, c->comm, st));
-  const int prev = (c->rank + c->world - 1) % c->world;  // the last rank's block of the previous global batch wraps to rank 0
-  *d_prev_desc = g + (size_t)prev * blk;
-  *d_prev_n = (const int32_t*)(g + (size_t)prev * blk + (size_t)cap * 32);
+  // predecessor of this rank's FIRST frame of the batch: the previous rank's last frame of the SAME batch — or, for rank 0, the
+  // last rank's last frame of the PREVIOUS batch (the previous call's gather; nothing on the first call)
+  const uint8_t* pb = c->rank > 0 ? g + (size_t)(c->rank - 1) * blk : (gprev ? gprev + (size_t)(c->world - 1) * blk : nullptr);
+  *d_prev_desc = pb;
+  *d_prev_n = pb ? (const int32_t*)(pb + (size_t)cap * 32) : nullptr;
   return DVS_OK;
 }
 

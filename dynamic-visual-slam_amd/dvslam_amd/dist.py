@@ -1,8 +1,9 @@
 """Multi-GPU sharding of the frontend path: frames are sharded contiguously over the
 ranks (rank r owns frames [r*B, (r+1)*B) of every global batch), extraction needs no communication,
 and the ONE exchange step is the boundary descriptor block: the match job (t, t-1) with t = r*B needs
-the descriptors of frame r*B - 1, which the previous rank produced.  One all-gather of the fixed-size
-block {descriptors[cap x 32], n} per step.
+the descriptors of frame r*B - 1, which the previous rank produced as the last frame of the SAME batch (rank 0:
+the last rank's last frame of the batch before).  One all-gather of the fixed-size block {descriptors[cap x 32], n}
+per global batch; the result for rank 0 comes from the previous call's gather.
 
 Two implementations of the same block layout:
 * `Comm` — the product path: dvs_comm_* / dvs_exchange_boundary of the C-ABI (RCCL ncclAllGather over xGMI on the
@@ -60,37 +61,44 @@ def unpack_boundary(block: torch.Tensor, cap: int):
 
 
 class BoundaryExchanger:
-    """torch.distributed form of the exchange step with everything preallocated: the gather buffer [world][block] twice (a
-    step's match may still read one while the next step gathers into the other); this rank packs straight into its slot."""
+    """torch.distributed form of the exchange step with everything preallocated: the gather buffer [world][block] three times (a
+    call's result points into this call's and the previous call's buffer and stays valid while the next call gathers into the
+    third); this rank packs straight into its slot.  Same contract as dvs_exchange_boundary: called once per global batch with
+    this rank's last frame, returns the predecessor of this rank's FIRST frame — rank r >= 1: rank r - 1's block of this call;
+    rank 0: the last rank's block of the previous call, (None, None) on the first call."""
 
     def __init__(self, cap: int, device, group=None):
         self.cap, self.group = cap, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.blk = _block_bytes(cap)
-        self.bufs = [torch.zeros(self.world * self.blk, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.bufs = [torch.zeros(self.world * self.blk, dtype=torch.uint8, device=device) for _ in range(3)]
         self.turn = 0
+        self.calls = 0
 
     def __call__(self, desc_last: torch.Tensor, n_last: torch.Tensor):
         out = self.bufs[self.turn]
-        self.turn ^= 1
+        prev_out = self.bufs[(self.turn + 2) % 3] if self.calls > 0 else None
+        self.turn = (self.turn + 1) % 3
+        self.calls += 1
         mine = out[self.rank * self.blk:(self.rank + 1) * self.blk]
         pack_boundary(desc_last, n_last, mine)
-        if self.world > 1 or (dist.is_initialized() and os.environ.get("DVS_FORCE_COLLECTIVE") == "1"):
+        if self.world > 1:
             dist.all_gather_into_tensor(out, mine, group=self.group)
-        prev = (self.rank - 1) % self.world
-        return unpack_boundary(out[prev * self.blk:(prev + 1) * self.blk], self.cap)
+        if self.rank > 0:
+            return unpack_boundary(out[(self.rank - 1) * self.blk:self.rank * self.blk], self.cap)
+        if prev_out is None:
+            return None, None
+        return unpack_boundary(prev_out[(self.world - 1) * self.blk:self.world * self.blk], self.cap)
 
 
 _exchangers = {}
 
 
 def exchange_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, cap: int, group=None):
-    """all-gather every rank's last-frame block; return (desc, n) of the PREVIOUS rank (the last rank's
-    block of the previous global batch wraps around to rank 0, like a streaming sequence would)."""
+    """one call per global batch with this rank's last frame; returns (desc, n) of the frame BEFORE this rank's first frame of the
+    batch in the global order (see BoundaryExchanger), (None, None) where the sequence starts"""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and not (dist.is_initialized() and os.environ.get("DVS_FORCE_COLLECTIVE") == "1"):
-        return desc_last, n_last.reshape(-1)[0]   # one rank: the predecessor is the caller's own last frame, in place
     key = (cap, str(desc_last.device), id(group), world)
     if key not in _exchangers:
         _exchangers[key] = BoundaryExchanger(cap, desc_last.device, group)
@@ -120,10 +128,11 @@ class Comm:
         return int(self._L.dvs_comm_rccl_version())
 
     def exchange_boundary(self, stream: int, d_desc_last: int, d_n_last: int, cap: int):
-        """-> (device pointer of the predecessor's descriptors, device pointer of its count); asynchronous on `stream`"""
+        """one call per global batch with this rank's last frame -> (device pointer of the descriptors, of the count) of the frame
+        before this rank's first frame in the global order, (0, 0) where the sequence starts; asynchronous on `stream`"""
         pd, pn = C.c_void_p(), C.c_void_p()
         self._check(self._L.dvs_exchange_boundary(self.h, stream, d_desc_last, d_n_last, cap, C.byref(pd), C.byref(pn)))
-        return pd.value, pn.value
+        return pd.value or 0, pn.value or 0
 
     def all_gather(self, stream: int, d_send: int, d_recv: int, nbytes: int):
         self._check(self._L.dvs_comm_all_gather(self.h, stream, d_send, d_recv, nbytes))

@@ -226,10 +226,12 @@ int32_t dvs_comm_world(const dvs_comm* c);
 int32_t dvs_comm_rccl_version(void);  /* ncclGetVersion code, 0 if RCCL is unavailable */
 /* bytes of one rank's boundary block {descriptors[cap x 32], int32 n, padding to 64 B} */
 size_t dvs_boundary_block_bytes(int32_t cap);
-/* The exchange step.  Packs {d_desc_last (cap rows of 32 B, 16-byte aligned), *d_n_last} into this rank's slot of a gather
- * buffer owned by the communicator (two buffers used alternately, allocated once per capacity), all-gathers in place on
- * `stream`, and returns device pointers to the PREDECESSOR rank's descriptors / count (rank 0's predecessor is the last
- * rank: the previous global batch's last frame), valid until the call after next.  Asynchronous. */
+/* The exchange step, called once per GLOBAL BATCH with this rank's LAST frame of the batch.  Packs {d_desc_last (cap rows of 32 B,
+ * 16-byte aligned), *d_n_last} into this rank's slot of a gather buffer owned by the communicator (three buffers used in turn,
+ * allocated once per capacity), all-gathers in place on `stream`, and returns device pointers to the predecessor of this rank's
+ * FIRST frame of the same batch in the global frame order: rank r >= 1 gets rank r - 1's block of this call, rank 0 gets the last
+ * rank's block of the PREVIOUS call (both NULL on the first call: the sequence starts there).  The pointers stay valid until the
+ * call after next.  Asynchronous. */
 dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_desc_last, const int32_t* d_n_last, int32_t cap,
                                  const uint8_t** d_prev_desc, const int32_t** d_prev_n);
 /* plain all-gather of bytes_per_rank bytes per rank (level-sharded extraction gathers its per-level blocks with it) */

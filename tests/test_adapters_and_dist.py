@@ -95,13 +95,26 @@ assert list(dvdist.shard_range(world, rank, 8)) == list(range(rank * 8, rank * 8
 desc = torch.full((cap, 32), 10 + rank, dtype=torch.uint8)
 desc[5, 7] = 200 + rank
 n = torch.tensor(1900 + rank, dtype=torch.int32)
+# one call per global batch with this rank's LAST frame; the result is the frame before this rank's FIRST frame in the global order
 d, m = dvdist.exchange_boundary(desc, n, cap)
-prev = (rank - 1) % world
-assert int(m) == 1900 + prev, (rank, int(m))
-assert int(d[0, 0]) == 10 + prev and int(d[5, 7]) == 200 + prev and d.shape == (cap, 32)
-# second round with different payloads: no stale data
+if rank == 0:
+    assert d is None and m is None                     # the sequence starts here
+else:
+    assert int(m) == 1900 + rank - 1 and int(d[0, 0]) == 10 + rank - 1 and int(d[5, 7]) == 200 + rank - 1 and d.shape == (cap, 32)
+# second batch with different payloads: rank r >= 1 sees rank r - 1's block of THIS batch, rank 0 the last rank's of the FIRST batch
 d2, m2 = dvdist.exchange_boundary(desc + 1, n + 7, cap)
-assert int(m2) == 1907 + prev and int(d2[0, 0]) == 11 + prev
+if rank == 0:
+    assert int(m2) == 1900 + world - 1 and int(d2[0, 0]) == 10 + world - 1 and int(d2[5, 7]) == 200 + world - 1
+else:
+    assert int(m2) == 1907 + rank - 1 and int(d2[0, 0]) == 11 + rank - 1
+# third batch: rank 0 now sees the second batch's last block; the first batch's result is still intact (three buffers)
+d3, m3 = dvdist.exchange_boundary(desc + 2, n + 9, cap)
+if rank == 0:
+    assert int(m3) == 1907 + world - 1 and int(d3[0, 0]) == 11 + world - 1
+    assert int(m2) == 1900 + world - 1 and int(d2[0, 0]) == 10 + world - 1
+else:
+    assert int(m3) == 1909 + rank - 1 and int(d3[0, 0]) == 12 + rank - 1
+    assert int(m2) == 1907 + rank - 1 and int(d2[0, 0]) == 11 + rank - 1
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -122,12 +135,14 @@ def test_boundary_exchange_two_gloo_ranks(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
-def test_single_rank_exchange_is_identity():
+def test_single_rank_exchange_returns_the_previous_batch():
     import torch
     from dvslam_amd import dist as dvdist
     desc = torch.arange(64 * 32, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(64, 32)
     d, n = dvdist.exchange_boundary(desc, torch.tensor(17, dtype=torch.int32), 64)
-    assert int(n) == 17 and torch.equal(d, desc)
+    assert d is None and n is None                                     # first batch: no predecessor
+    d, n = dvdist.exchange_boundary(desc + 1, torch.tensor(18, dtype=torch.int32), 64)
+    assert int(n) == 17 and torch.equal(d, desc)                       # one rank: its own last frame of the batch before
 
 
 def test_level_shards_cover_every_level_once():
@@ -182,7 +197,7 @@ def test_comm_c_abi_refuses_without_gpu(hiplib):
 @pytest.mark.gpu
 def test_comm_exchange_single_rank_on_gpu(gpu, hiplib):
     """world = 1 RCCL communicator through the C-ABI: the exchange packs {descriptors, n}, all-gathers in place and hands back
-    the predecessor's (= own) block; two calls alternate between the two gather buffers"""
+    the predecessor's block — with one rank its own last frame of the batch before; the gather buffers are used in turn"""
     import ctypes as C
     from dvslam_amd import _lib
     from dvslam_amd import dist as dvdist
@@ -192,16 +207,21 @@ def test_comm_exchange_single_rank_on_gpu(gpu, hiplib):
     rng = np.random.default_rng(5)
     st = _lib.stream_create(0)
     seen = []
-    for rnd in range(3):
+    last = None
+    for rnd in range(4):
         desc = rng.integers(0, 256, size=(cap, 32), dtype=np.uint8)
         n = np.array([1900 + rnd], np.int32)
         d_desc = _lib.DeviceBuffer(desc.nbytes).upload(desc); d_n = _lib.DeviceBuffer(4).upload(n)
         pd, pn = comm.exchange_boundary(st, d_desc.ptr, d_n.ptr, cap)
-        got = np.empty((cap, 32), np.uint8); gn = np.empty(1, np.int32)
         _lib.stream_synchronize(st)   # the exchange is asynchronous on `st`, a non-blocking stream
-        _lib.check(hiplib.dvs_memcpy_d2h(0, got.ctypes.data, pd, got.nbytes)); _lib.check(hiplib.dvs_memcpy_d2h(0, gn.ctypes.data, pn, 4))
-        assert (got == desc).all() and gn[0] == 1900 + rnd
+        if rnd == 0:
+            assert pd == 0 and pn == 0, "first batch: no predecessor"
+        else:   # one rank: the predecessor of its first frame is its own last frame of the batch before
+            got = np.empty((cap, 32), np.uint8); gn = np.empty(1, np.int32)
+            _lib.check(hiplib.dvs_memcpy_d2h(0, got.ctypes.data, pd, got.nbytes)); _lib.check(hiplib.dvs_memcpy_d2h(0, gn.ctypes.data, pn, 4))
+            assert (got == last[0]).all() and gn[0] == last[1]
+        last = (desc, 1900 + rnd)
         seen.append(pd)
-    assert seen[0] != seen[1] and seen[0] == seen[2], "two gather buffers used alternately"
+    assert seen[1] != seen[2] and seen[1] != 0, "gather buffers used in turn"
     comm.close()
     _lib.stream_destroy(st)
