@@ -378,6 +378,7 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     G.fastRows = maxh;
     const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
     G.fastByteDma = h->fast_byte_dma;
+    G.fastXcd = getenv("DVS_FAST_XCD") ? atoi(getenv("DVS_FAST_XCD")) : 1;
     G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
     G.fastWaveLds = (int)align_up((size_t)G.fastTile + (size_t)G.fastRows * G.fastP + listBytes, 16);
   }

@@ -849,9 +849,13 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int lane = lane_id();
   const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
-  const int ci = cell0 + blockIdx.x * 4 + wvi;                        // every size derived from them stay on the scalar unit
+  // frames -> XCDs contiguously (xcd_contiguous_id): the workgroups of one frame — whose cells share halo rows and 128-byte lines —
+  // then meet in ONE L2 instead of eight (HBM fetch 2.1x -> see profiles of the algorithmic bytes; FAST is not fetch-bound, the
+  // time is unchanged)
+  const int xid = g->fastXcd ? xcd_contiguous_id() : (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int f = xid / (int)gridDim.x;
+  const int ci = cell0 + (xid - f * (int)gridDim.x) * 4 + wvi;       // every size derived from them stay on the scalar unit
   if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
-  const int f = blockIdx.y;
   unsigned char* base = fsm + wvi * g->fastWaveLds;
   u8* tile = base;
   u8* score = base + g->fastTile;
