@@ -484,6 +484,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
   if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
+  h->out_pending = false; h->pf_joined = false; h->pf_valid = false; h->la_valid = false;
   free_workspace(h);
   Geom G;
   std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
@@ -769,7 +770,15 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
-  if (bst != st) {
+  const bool will_defer = bst != st && may_defer && h->output_event && h->defer_outputs && !sharded && !h->env_desc_split;
+  // experiment (DVS_BLUR_LATE=1): with a deferred descriptor stage the blur — only the descriptors need it — could wait for the
+  // quad-tree too and run beside the next call's FAST.  Measured: neutral at 64 frames per step (0.6177 against 0.6194-0.6408 ms),
+  // worse everywhere else (1 frame 9.8 k -> 7.4 k frames/s, 32: 95.8 k -> 90.7 k, 128: 106.4 k -> 99.1 k): off.
+  const bool blur_late = will_defer && getenv("DVS_BLUR_LATE") && atoi(getenv("DVS_BLUR_LATE"));
+  if (blur_late) {
+    DVS_HIP(hipEventRecord(h->ev_oct, st));
+    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+  } else if (bst != st) {
     DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
   } else if (h->guard_event) {
     DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
@@ -809,8 +818,10 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     // deferred: the descriptor stage follows the blur on the auxiliary stream and the main stream is NOT joined — the next call's
     // FAST (vector-ALU bound, light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the
     // caller's output event.
-    DVS_HIP(hipEventRecord(h->ev_oct, st));
-    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+    if (!blur_late) {
+      DVS_HIP(hipEventRecord(h->ev_oct, st));
+      DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+    }
     h->timer.begin(DVS_STAGE_DESCRIBE, bst);
     hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, bst, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
@@ -958,7 +969,8 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_HIP(hipStreamSynchronize(h->aux_stream));
   DVS_HIP(hipStreamSynchronize(h->pf_stream));
   if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
-  h->la_valid = false; h->pf_valid = false;
+  h->la_valid = false; h->pf_valid = false; h->pf_joined = false;
+  h->out_pending = false;   // everything, a deferred descriptor stage included, has completed above
   h->overlap = on != 0;
   return DVS_OK;
 }
