@@ -419,7 +419,7 @@ def main():
         for e in P["ext_done"]:
             e.record(ts)                 # creates the hipEvent_t handles the library records where the outputs are complete
 
-    def step():
+    def step_torch():
         i = state["i"]; state["i"] += 1
         s = i % NSETS
         img = d_img[i % NB]; nxt = d_img[(i + 1) % NB]
@@ -473,6 +473,56 @@ def main():
                                            P["idx"].data_ptr(), P["dist"].data_ptr())
             P["match_done"][sj].record(M)
         P["cur"] = s
+
+    # everything a step needs as plain integers, prepared once: at 1-2 frames per step the host's enqueue time (torch tensor indexing,
+    # data_ptr(), stream context managers: ~0.1 ms per step) was what the GPU waited for
+    L_ = dvslam_amd.lib()
+    ptr = dict(img=[d_img[k].data_ptr() for k in range(NB)],
+               kps=[t.data_ptr() for t in P["kps"]], desc=[t.data_ptr() for t in P["desc"]], n=[t.data_ptr() for t in P["n"]],
+               last_desc=[t[B - 1].data_ptr() for t in P["desc"]], last_n=[t[B - 1:B].data_ptr() for t in P["n"]],
+               idx=P["idx"].data_ptr(), dist=P["dist"].data_ptr())
+    T_, M_, X_ = P["stream"].cuda_stream, P["mstream"].cuda_stream, P["xstream"].cuda_stream
+    raw = lib_events and not args.torch_exchange     # library events / waits by handle (torch events only on the fallback paths)
+    if raw:
+        for e in P["match_done"]:
+            e.record(P["mstream"])
+        evh = dict(ext=[e.cuda_event for e in P["ext_done"]], md=[e.cuda_event for e in P["match_done"]], fast=ev_fast.cuda_event if ev_fast else 0)
+        P["xdone"].record(P["xstream"])
+        evh["x"] = P["xdone"].cuda_event
+    orb_h, mat_ = P["orb"], P["mat"]
+
+    def step_raw():
+        i = state["i"]; state["i"] += 1
+        s = i % NSETS
+        j = i - lag
+        sj = j % NSETS
+        if i >= NSETS:
+            orb_h.set_reuse_guard_event(evh["md"][(i - NSETS + 1) % NSETS])   # the last reader of the set this step overwrites
+        if args.prefetch:
+            orb_h.hint_next_batch_device(ptr["img"][(i + 1) % NB])
+        orb_h.set_output_event(evh["ext"][s], defer=None)
+        orb_h.extract_batch_device(ptr["img"][i % NB], B, rows, cols, cols, rows * cols, ptr["kps"][s], ptr["desc"][s], cap, ptr["n"][s])
+        prev_desc = prev_n = 0
+        if j >= 0 and collective:
+            L_.dvs_stream_wait_event(X_, evh["ext"][sj])
+            prev_desc, prev_n = comm.exchange_boundary(X_, ptr["last_desc"][sj], ptr["last_n"][sj], cap)
+            L_.dvs_event_record(evh["x"], X_)
+        elif j > 0:
+            sp = (j - 1) % NSETS
+            prev_desc, prev_n = ptr["last_desc"][sp], ptr["last_n"][sp]
+        if j >= 0:
+            L_.dvs_stream_wait_event(M_, evh["ext"][sj])
+            if lag:
+                L_.dvs_stream_wait_event(M_, evh["fast"])
+            if collective and X_ != M_:
+                L_.dvs_stream_wait_event(M_, evh["x"])
+            mat_.match_sequence_device(ptr["desc"][sj], ptr["n"][sj], cap, B, prev_desc, prev_n, ptr["idx"], ptr["dist"])
+            L_.dvs_event_record(evh["md"][sj], M_)
+        P["cur"] = s
+
+    if raw:
+        orb_h.set_output_event(evh["ext"][0], defer=defer)
+    step = step_raw if (raw and comm is not None or raw and not collective) else step_torch
 
     def sync_all():
         P["orb"].synchronize()
