@@ -96,6 +96,12 @@ struct dvs_orb {
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
   u8* d_desc = nullptr;
   int* d_nout = nullptr;
+  // experiment: the single-frame host path as ONE hipGraph (H2D of the staged frame, every kernel of the two streams,
+  // the three D2H copies), captured once per resolution and replayed per frame.  Bit-identical, not faster: off by default.
+  u8* h_img = nullptr;             // pinned staging of the caller's frame (rows x cols, tight)
+  hipGraphExec_t g_exec = nullptr;
+  int g_rows = 0, g_cols = 0;
+  int env_graph = 0;               // DVS_GRAPH=1: replay a captured graph (measured: no faster on ROCm 7.2 — 640x480 0.224 vs 0.171 ms, 720p 0.229 vs 0.236)
   dvs_keypoint* h_kps = nullptr;   // pinned
   u8* h_desc = nullptr;
   int* h_nout = nullptr;
@@ -116,6 +122,8 @@ void free_workspace(dvs_orb* h) {
                   h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
+  if (h->h_img) { (void)hipHostFree(h->h_img); h->h_img = nullptr; }
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
@@ -890,6 +898,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
   if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
   if (const char* eh = getenv("DVS_HOPS")) h->env_hops = atoi(eh);
+  if (const char* eg = getenv("DVS_GRAPH")) h->env_graph = atoi(eg);
   if (const char* e8 = getenv("DVS_BLUR_MFMA")) h->env_blur_mfma = atoi(e8);
   if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
   if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
@@ -1120,6 +1129,48 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
   DVS_TRY(ensure_workspace(h, rows, cols));
   const Geom& G = h->geom;
   const int cap = G.outCap;
+  if (nimg == 1 && h->env_graph && h->overlap && !h->timer.on && !h->out_pending) {
+    // one frame: replay the captured graph of exactly this call (same buffers every time: the frame goes through pinned staging)
+    if (!h->h_img) DVS_HIP(hipHostMalloc((void**)&h->h_img, (size_t)rows * cols));
+    for (int r = 0; r < rows; r++) memcpy(h->h_img + (size_t)r * cols, imgs[0] + (size_t)r * step, (size_t)cols);
+    if (!h->g_exec || h->g_rows != rows || h->g_cols != cols) {
+      if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
+      DVS_HIP(hipStreamSynchronize(h->stream));
+      h->pf_valid = false; h->la_valid = false; h->pf_joined = false;
+      hipGraph_t graph = nullptr;
+      dvs_status rc = DVS_OK;
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        hipError_t e = hipMemcpy2DAsync(h->d_pyr + G.lv[0].off, G.lv[0].pitch, h->h_img, cols, cols, rows, hipMemcpyHostToDevice, h->stream);
+        ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr, ~0u, 0};
+        if (e == hipSuccess) rc = enqueue_extract(h, src, 1, h->d_kps, h->d_desc, cap, h->d_nout);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->h_nout, h->d_nout, 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream);
+        const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
+        h->gate_event = nullptr;   // the call's end event was recorded inside the capture: not waitable outside it
+        if (e == hipSuccess && ee == hipSuccess && rc == DVS_OK && graph && hipGraphInstantiate(&h->g_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          h->g_rows = rows; h->g_cols = cols;
+        } else {
+          h->g_exec = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+      if (!h->g_exec) h->env_graph = 0;   // capture is not available here: plain launches from now on
+    }
+    if (h->g_exec) {
+      DVS_HIP(hipGraphLaunch(h->g_exec, h->stream));
+      DVS_HIP(hipStreamSynchronize(h->stream));
+      h->last_nimg = 1;
+      h->gate_event = nullptr;
+      const int n = h->h_nout[0];
+      if (n > capacity) { set_error("frame 0: %d keypoints > capacity %d", n, capacity); return DVS_ERR_CAPACITY; }
+      n_out[0] = n;
+      memcpy(kps, h->h_kps, (size_t)n * sizeof(dvs_keypoint));
+      memcpy(desc, h->h_desc, (size_t)n * 32);
+      return DVS_OK;
+    }
+  }
   for (int b0 = 0; b0 < nimg; b0 += h->max_batch) {
     const int nb = std::min(h->max_batch, nimg - b0);
     // level 0 staged into the frame's pyramid block (the reference copies it too: copyMakeBorder, :1189)
@@ -1184,6 +1235,8 @@ dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int3
   if (cnt > cap) return DVS_ERR_CAPACITY;
   return read_packed(h, h->d_pts + (uint64_t)frame * h->geom.ptsPerFrame + h->geom.lv[level].ptsOff, cnt, xys);
 }
+
+int32_t dvs_test_graph_active(const dvs_orb* h) { return h && h->g_exec ? 1 : 0; }
 
 dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64) {
   DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels);
