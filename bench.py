@@ -360,7 +360,7 @@ def main():
     # (measured: an unused fourth stream in the extractor handle, 0.74 -> 0.93 ms)
     need_x = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ) or os.environ.get("DVS_FORCE_COLLECTIVE") == "1"
     ts = torch.cuda.ExternalStream(orb.get_stream(), device=dev)
-    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev) if (args.match_stream or args.match_late) else ts   # match
+    ms = torch.cuda.ExternalStream(dvslam_amd.stream_create(local, int(os.environ.get("BENCH_M_PRIO", "0"))), device=dev) if (args.match_stream or args.match_late) else ts   # match
     # boundary exchange: with the pipelined match it shares the match stream (the match is its only consumer and a fifth hardware
     # queue cost 0.28 ms per step under the launcher); the serial schedule gives it a stream of its own beside the extraction
     xs = (ms if args.match_late else torch.cuda.ExternalStream(dvslam_amd.stream_create(local), device=dev)) if need_x else ts
@@ -562,6 +562,23 @@ def main():
         match_check = "identical to the serial match of the same batch" if same else "MISMATCH"
         if not same:
             print("[bench] WARNING: the pipelined match differs from the same job enqueued serially", file=sys.stderr, flush=True)
+    if os.environ.get("DVS_DEBUG") and int(os.environ["DVS_DEBUG"]) & 4:   # diagnostics: when did the quad-tree workgroups of the last step run
+        import numpy as np
+        sync_all()
+        st_, en_ = [], []
+        for f in range(B):
+            for l in range(8):
+                o = np.zeros(64, np.uint64)
+                dvslam_amd.lib().dvs_test_octree_stamps_frame(orb._h, f, l, o.ctypes.data)
+                c = int(o[0])
+                if c >= 2:
+                    st_.append((int(o[1]) & 0xFFFFFFFFFFFFFF, l, f)); en_.append((int(o[c]) & 0xFFFFFFFFFFFFFF, l, f))
+        t0 = min(x[0] for x in st_)
+        per_level = {l: (max((x[0] - t0) / 100 for x in st_ if x[1] == l), max((x[0] - t0) / 100 for x in en_ if x[1] == l)) for l in range(8)}
+        print("[bench] quad-tree workgroups of the last step: latest start / latest end per level (us after the first start):",
+              {l: (round(a, 1), round(b, 1)) for l, (a, b) in per_level.items()}, file=sys.stderr, flush=True)
+        late = sorted(((x[0] - t0) / 100 for x in st_), reverse=True)[:10]
+        print("[bench] ten latest starts:", [round(x, 1) for x in late], file=sys.stderr, flush=True)
     # per-kernel durations: K more steps on ONE pipeline with hipEvents around every stage launch (the events cost ~10 us
     # of stream time per stage, so they stay out of the whole-job timing above)
     # (a) the same schedule as the timed region (overlap + pyramid prefetch), events on the streams the kernels run on: what a

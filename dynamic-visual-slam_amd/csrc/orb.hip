@@ -774,7 +774,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // slots 512-thread workgroups hold cost those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 and
   // 384 threads: 0.729 / 0.690).  DVS_OCT_T=512 keeps 512 with the per-level grading of oct_threads().
   const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
-  hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+  hipLaunchKernelGGL(k_octree, dim3(nimg, G.nlevels), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
                      h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
   h->timer.end(st);
   // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
@@ -880,7 +880,14 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (ksum > 257) { delete h; set_error("gauss_kernel sum %d would overflow the Q8.8 row buffer", ksum); return DVS_ERR_ARG; }
   h->device = device;
   h->max_batch = params->max_batch > 0 ? params->max_batch : 1;
-  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  hipError_t e;
+  {
+    int plo = 0, phi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+    const char* mp = getenv("DVS_MAIN_PRIO");
+    const int v = mp ? atoi(mp) : 0;
+    e = hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, v > 0 ? phi : (v < 0 ? plo : 0));
+  }
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
   // diagnostics, read once: DVS_NO_OVERLAP=1 every stage alone on the stream; DVS_CASCADE=1 / 0 all-levels-in-one-launch pyramid
@@ -902,10 +909,15 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e8 = getenv("DVS_BLUR_MFMA")) h->env_blur_mfma = atoi(e8);
   if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
   if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
-  int prio_lo = 0, prio_hi = 0;  // the auxiliary stream carries the short latency-bound launches: give it dispatch priority
+  int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+  auto env_prio = [&](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return v > 0 ? prio_hi : (v < 0 ? prio_lo : 0); };
+  // the auxiliary stream carries the blur (and a deferred descriptor stage): LOWEST dispatch priority, so that the quad-tree
+  // workgroups launched at the same moment on the main stream all become resident first — with the blur's workgroups dispatched
+  // ahead of them some quad-tree workgroups started 90 us late and the kernel took 170 us instead of 110 (64 frames per step:
+  // 0.628 -> 0.592 ms, neutral below 64; DVS_AUX_PRIO=1 restores round 1's highest priority)
+  if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, env_prio("DVS_AUX_PRIO", -1)) != hipSuccess ||
+      hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, env_prio("DVS_PF_PRIO", 1)) != hipSuccess ||
       (h->env_lookahead && create_fa_stream(&h->fa_stream, prio_lo, prio_hi) != hipSuccess) ||
       hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
@@ -1237,6 +1249,14 @@ dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int3
 }
 
 int32_t dvs_test_graph_active(const dvs_orb* h) { return h && h->g_exec ? 1 : 0; }
+
+dvs_status dvs_test_octree_stamps_frame(dvs_orb* h, int32_t frame, int32_t level, uint64_t* out64) {
+  DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels && frame >= 0 && frame < h->max_batch);
+  DVS_HIP(hipSetDevice(h->device));
+  const LevelGeom& L = h->geom.lv[level];
+  DVS_HIP(hipMemcpy(out64, h->d_nodeof + (uint64_t)frame * h->geom.ptsPerFrame + ((L.ptsOff + L.ptsCap - 128) & ~1ull), 64 * 8, hipMemcpyDeviceToHost));
+  return DVS_OK;
+}
 
 dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64) {
   DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels);

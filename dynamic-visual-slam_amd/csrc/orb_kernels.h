@@ -134,7 +134,7 @@ constexpr int kOctTMax = 512;  // few frames: nothing competes for the wave slot
 __device__ __forceinline__ int oct_threads() {
   const int bd = (int)blockDim.x;
   if (gridDim.x * gridDim.y <= 256 || bd < 512) return bd;
-  const int l = (int)blockIdx.x;
+  const int l = (int)blockIdx.y;   // grid = (frames, levels)
   return l < 2 ? 512 : (l < 5 ? 256 : 128);
 }
 // exclusive scan over oct_threads() (multiple of 64, <= kOctTMax) threads; wsum = kOctTMax / 64 + 1 ints
@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   __shared__ int s_S, s_n, s_T, s_nexp, s_c;
   __shared__ SortShared s_sort;
   const int tid = threadIdx.x;
-  const int level = blockIdx.x, f = blockIdx.y;
+  // grid = (frames, levels): the linear workgroup id is frame + frames x level, so the level-0 workgroups — the long ones — are
+  // dispatched first and dealt round-robin over the XCDs, eight per XCD.  With (levels, frames) the id was level + 8 x frame and
+  // XCD l received all 64 workgroups of level l: XCD 0 the 64 long ones, two per CU.
+  const int level = blockIdx.y, f = blockIdx.x;
   if (tid >= OCT_T) return;  // wavefronts this level does not use leave before the first barrier
   if (!((levelMask >> level) & 1u)) {  // a level another rank owns: no keypoints from here
     if (tid == 0) { lvlKpCount[f * g->nlevels + level] = 0; candTotal[f * g->nlevels + level] = 0; }
@@ -1293,9 +1296,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   const LevelGeom& L = g->lv[level];
   // diagnostics (DVS_DEBUG bit 1): thread 0 of frame 0 stamps the 100 MHz wall clock at phase boundaries into the unused tail of
   // the level's global node-of-point block (dvs_test_octree_stamps)
-  unsigned long long* stamps = (unsigned long long*)(nodeOfAll + ((L.ptsOff + L.ptsCap - 128) & ~1ull));
+  unsigned long long* stamps = (unsigned long long*)(nodeOfAll + (uint64_t)((g->debug & 4) ? f : 0) * g->ptsPerFrame + ((L.ptsOff + L.ptsCap - 128) & ~1ull));
   int si = 0;
-  const bool stamping = (g->debug & 2) && tid == 0 && f == 0;
+  const bool stamping = (g->debug & 2) && tid == 0 && (f == 0 || (g->debug & 4));   // bit 2: every frame stamps (into its own block)
 #define QT_STAMP(id) do { if (stamping && si < 62) { stamps[1 + si] = ((unsigned long long)(id) << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFull); si++; stamps[0] = si; } } while (0)
   QT_STAMP(1);
 

@@ -72,10 +72,10 @@ dvs_status dvs_stream_create(int32_t device, int32_t high_priority, void** out_s
   DVS_TRY(dvs::check_device(device));
   DVS_HIP(hipSetDevice(device));
   hipStream_t s = nullptr;
-  if (high_priority) {
+  if (high_priority) {   // > 0: highest dispatch priority, < 0: lowest
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    DVS_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    DVS_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority > 0 ? hi : lo));
   } else {
     DVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   }

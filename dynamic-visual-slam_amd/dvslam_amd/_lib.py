@@ -122,6 +122,7 @@ def lib():
     L.dvs_test_p3p.argtypes = [vp, vp, vp]
     L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
     L.dvs_test_octree_stamps.argtypes = [vp, i32, vp]
+    L.dvs_test_octree_stamps_frame.argtypes = [vp, i32, i32, vp]
     L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):
         L.dvs_ba_create.argtypes = [i32, C.POINTER(vp)]
@@ -155,7 +156,7 @@ def device_count():
 def stream_create(device=0, high_priority=False):
     """raw hipStream_t (int) created by the library (wrap with torch.cuda.ExternalStream when torch should use it)"""
     out = C.c_void_p()
-    check(lib().dvs_stream_create(device, 1 if high_priority else 0, C.byref(out)))
+    check(lib().dvs_stream_create(device, int(high_priority), C.byref(out)))   # True / 1: highest, -1: lowest, False / 0: default
     return int(out.value)
 
 

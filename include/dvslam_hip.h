@@ -416,6 +416,7 @@ int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48);
 /* diagnostics: with DVS_DEBUG bit 1 set at handle creation the quad-tree workgroup of (frame 0, level) stamps the 100 MHz wall clock at
  * its phase boundaries; out64[0] = count, out64[1 + i] = id << 56 | ticks (tools/exp_octree_phases.py) */
 dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64);
+dvs_status dvs_test_octree_stamps_frame(dvs_orb* h, int32_t frame, int32_t level, uint64_t* out64);   /* DVS_DEBUG bit 2: every frame stamps */
 /* diagnostics: 1 while the handle replays a captured hipGraph for single-frame host calls (dvs_orb_extract) */
 int32_t dvs_test_graph_active(const dvs_orb* h);
 dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
