@@ -91,6 +91,9 @@ struct dvs_orb {
   bool pf_valid = false;
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
+  uint32_t* d_lvlkp2[2] = {nullptr, nullptr};   // level keypoint lists, two sets: a deferred descriptor stage still reads one while the
+  int* d_lvlcount2[2] = {nullptr, nullptr};     // next call's quad-tree writes the other (no wait on the main stream in front of it)
+  int lset = 0;
   float4* d_orient = nullptr;  // per keypoint slot: (angle, cos, sin, -) between the two halves of the descriptor stage
   int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
@@ -119,8 +122,8 @@ void free_workspace(dvs_orb* h) {
   if (h->d_cellcount2[1]) (void)hipFree(h->d_cellcount2[1]);
   h->d_cand2[0] = h->d_cand2[1] = nullptr; h->d_cellcount2[0] = h->d_cellcount2[1] = nullptr; h->la_valid = false;
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp, h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
-                  h->d_lvlcount, h->d_kps, h->d_desc, h->d_nout};
+                  h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp2[0], h->d_lvlkp2[1], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_lvlcount2[0], h->d_lvlcount2[1], h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
   if (h->h_img) { (void)hipHostFree(h->h_img); h->h_img = nullptr; }
@@ -131,6 +134,7 @@ void free_workspace(dvs_orb* h) {
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
+  h->d_lvlkp2[0] = h->d_lvlkp2[1] = nullptr; h->d_lvlcount2[0] = h->d_lvlcount2[1] = nullptr;
   h->d_pyr_alt = nullptr; h->d_orient = nullptr; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
@@ -526,8 +530,11 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   h->d_cellcount2[0] = h->d_cellcount; h->d_cellcount2[1] = nullptr;
   DVS_HIP(hipMalloc((void**)&h->d_celloff, B * G.totalCells * 4));
   DVS_HIP(hipMalloc((void**)&h->d_candtotal, B * G.nlevels * 4));
-  DVS_HIP(hipMalloc((void**)&h->d_lvlcount, B * G.nlevels * 4));
-  DVS_HIP(hipMalloc((void**)&h->d_lvlkp, B * (size_t)G.kpBlock * 4));
+  for (int k = 0; k < 2; k++) {
+    DVS_HIP(hipMalloc((void**)&h->d_lvlcount2[k], B * G.nlevels * 4));
+    DVS_HIP(hipMalloc((void**)&h->d_lvlkp2[k], B * (size_t)G.kpBlock * 4));
+  }
+  h->lset = 0; h->d_lvlcount = h->d_lvlcount2[0]; h->d_lvlkp = h->d_lvlkp2[0];
   DVS_HIP(hipMalloc((void**)&h->d_orient, B * (size_t)G.kpBlock * sizeof(float4)));
   DVS_HIP(hipMalloc((void**)&h->d_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
   DVS_HIP(hipMalloc((void**)&h->d_desc, B * (size_t)G.outCap * 32));
@@ -765,8 +772,10 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     bst = h->aux_stream;
     if (ev_fastdone == h->ev_pyr) DVS_HIP(hipEventRecord(h->ev_pyr, st));
   }
-  // 3. quad-tree
-  if (pend) DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));   // the deferred descriptor stage reads the lists the quad-tree rewrites
+  // 3. quad-tree.  A deferred descriptor stage of the previous call still reads that call's level keypoint lists: this call takes the
+  //    other set instead of waiting for it (the set before that is free: its reader precedes the prefetch chain this call's FAST
+  //    waited for)
+  if (pend) { h->lset ^= 1; h->d_lvlkp = h->d_lvlkp2[h->lset]; h->d_lvlcount = h->d_lvlcount2[h->lset]; }
   h->timer.begin(DVS_STAGE_OCTREE, st);
   // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
   // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
