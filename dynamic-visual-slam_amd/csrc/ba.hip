@@ -40,14 +40,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // flags: 1 = store residuals/Jacobians (local, loss-corrected), 2 = store W, 4 = store raw functor outputs
-__global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restrict__ chunks, int flags,
+__device__ __forceinline__ void ba_eval_body(const int bid, BaDev P, const BaChunk* __restrict__ chunks, int flags,
                                                  double* __restrict__ res, double* __restrict__ Jp, double* __restrict__ Jl,
                                                  double* __restrict__ W, double* __restrict__ partial,
                                                  double* __restrict__ rawRes, double* __restrict__ rawJq,
                                                  double* __restrict__ rawJt, double* __restrict__ rawJX) {
   __shared__ double wred[4][28];
   __shared__ double stage[256 * 12];  // 24 KB: store staging (see below)
-  const BaChunk ch = chunks[blockIdx.x];
+  const BaChunk ch = chunks[bid];
   const int tid = threadIdx.x;
   const int c = ch.cam;
   const bool act = tid < ch.count;
@@ -235,10 +235,18 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
     if ((lane & 1) == 0 && k < 28) wred[w][k] = tot;
   }
   __syncthreads();
-  if (tid < 28) partial[(size_t)blockIdx.x * 28 + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
+  if (tid < 28) partial[(size_t)bid * 28 + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
 }
 
-__global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
+__global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restrict__ chunks, int flags,
+                                                 double* __restrict__ res, double* __restrict__ Jp, double* __restrict__ Jl,
+                                                 double* __restrict__ W, double* __restrict__ partial,
+                                                 double* __restrict__ rawRes, double* __restrict__ rawJq,
+                                                 double* __restrict__ rawJt, double* __restrict__ rawJX) {
+  ba_eval_body((int)blockIdx.x, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
+}
+
+__device__ __forceinline__ void ba_reduce_body(const int bid, const int nReduce, BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
                                                    const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
                                                    const int* __restrict__ lmObs, const double* __restrict__ res,
                                                    const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
@@ -246,9 +254,9 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
                                                    double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
                                                    int* __restrict__ ticketCounter) {
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x < lmBlocks) {
+  if ((int)bid < lmBlocks) {
     if (!withLm) return;
-    const int l = blockIdx.x * 256 + tid;
+    const int l = bid * 256 + tid;
     if (l >= L) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
     if (!P.lm_fixed[l]) {
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
     return;
   }
   // camera fold: 8 cameras per workgroup, thread (c, k) sums the camera's chunk partials in chunk order (k = 27: cost)
-  const int cb = (int)blockIdx.x - lmBlocks;
+  const int cb = (int)bid - lmBlocks;
   const int c = cb * 8 + (tid >> 5), k = tid & 31;
   // costOnly (a trust-region candidate's cost, flags == 0): fold only the cost column — H_pp and g keep the ACCEPTED point's
   // values, which the next trial step needs again if this candidate is rejected
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int nCamBlocks = (int)gridDim.x - lmBlocks;
+    const int nCamBlocks = nReduce - lmBlocks;
     const int ticket = __hip_atomic_fetch_add(ticketCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = ticket == nCamBlocks - 1 ? 1 : 0;
     if (s_last) {
@@ -340,6 +348,16 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
   }
 }
 
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
+                                                   const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
+                                                   const int* __restrict__ lmObs, const double* __restrict__ res,
+                                                   const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
+                                                   int withLm, int costOnly, double* __restrict__ Hpp, double* __restrict__ Hll,
+                                                   double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
+                                                   int* __restrict__ ticketCounter) {
+  ba_reduce_body((int)blockIdx.x, (int)gridDim.x, P, K, L, nChunks, chunks, camChunkStart, lmStart, lmObs, res, Jl, partial, lmBlocks, withLm, costOnly, Hpp, Hll, g, cost, costCam, ticketCounter);
+}
+
 
 // =============================================================================================================================
 // Device-resident Levenberg-Marquardt step: the linear algebra of dvs_ba_solve — Jacobi scaling, LM
@@ -347,6 +365,43 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
 // change and the candidate point — as kernels over the buffers k_ba_eval / k_ba_reduce leave in HBM.  The host keeps only the
 // trust-region decisions and reads one 64-byte status record per trial step.  All reductions run in a fixed order.
 // =============================================================================================================================
+// Experiment (opt-in DVS_BA_FUSED=1): one window's evaluation and reduction in ONE launch, separated by a grid-wide
+// barrier.  Measured on MI355X: 17.3 us per evaluation against 13.0 us for the two dependent launches (LM 1.73 vs 1.64 ms) — the
+// barrier (arrival atomics, s_sleep polling, the slowest workgroup) costs more than the second launch.  Results identical.  All workgroups are resident at once (the host only takes
+// this path for <= 512 workgroups of <= 27 KB LDS on 256 CUs); thread 0 of every workgroup arrives at a monotonic counter and spins
+// with s_sleep until `target` arrivals are in.  The spin is bounded: after ~1 s it gives up and raises *err (the results are then
+// invalid and the host falls back to the two launches) — a wave never waits for ever.
+__global__ __launch_bounds__(256) void k_ba_fused(BaDev P, const BaChunk* __restrict__ chunks, int flags, double* __restrict__ res,
+                                                  double* __restrict__ Jp, double* __restrict__ Jl, double* __restrict__ W,
+                                                  double* __restrict__ partial, double* __restrict__ rawRes, double* __restrict__ rawJq,
+                                                  double* __restrict__ rawJt, double* __restrict__ rawJX, int K, int L, int nChunks,
+                                                  const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
+                                                  const int* __restrict__ lmObs, int lmBlocks, int nReduce, int withLm, int costOnly,
+                                                  double* __restrict__ Hpp, double* __restrict__ Hll, double* __restrict__ g,
+                                                  double* __restrict__ cost, double* __restrict__ costCam, int* __restrict__ ticketCounter,
+                                                  unsigned* __restrict__ gbar, unsigned target, int* __restrict__ err) {
+  __shared__ int s_timeout;
+  const int bid = (int)blockIdx.x;
+  if (bid < nChunks) ba_eval_body(bid, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0, to = 0;
+    while ((int)(__hip_atomic_load(gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 20)) { to = 1; break; }
+    }
+    if (to) { *err = 1; if (bid == 0) *cost = __builtin_nan(""); }   // the caller sees an invalid cost and the host stops using this path
+    s_timeout = to;
+  }
+  __syncthreads();
+  if (s_timeout) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (bid < nReduce) ba_reduce_body(bid, nReduce, P, K, L, nChunks, chunks, camChunkStart, lmStart, lmObs, res, Jl, partial, lmBlocks, withLm, costOnly, Hpp, Hll, g,
+                                    cost, costCam, ticketCounter);
+}
+
 struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; };
 
 __device__ __forceinline__ double block_sum_fixed(double v, double* sm) {  // 256 threads, fixed tree
@@ -752,6 +807,9 @@ struct dvs_ba {
   double *d_res = nullptr, *d_Jp = nullptr, *d_Jl = nullptr, *d_W = nullptr, *d_partial = nullptr;
   double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr, *d_costCam = nullptr;
   int* d_ticket = nullptr;
+  unsigned* d_gbar = nullptr;      // [0] grid-barrier arrivals (monotonic), [1] timeout flag of k_ba_fused
+  unsigned gbar_total = 0;
+  int fused = 0;                   // DVS_BA_FUSED=1: one launch with a grid barrier — measured SLOWER (17.3 vs 13.0 us per evaluation)
   double *d_raw = nullptr;  // R*(2+8+6+6)
   // device LM (dvs_ba_solve_device): accepted point, scaling, LM diagonal, step, per-landmark inverses, scaled W, Y = W V^-1,
   // reduced system, observation-of-(landmark, camera) table
@@ -805,6 +863,17 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
   if (h->R == 0) return DVS_OK;
   const BaDev P = dev_view(h);
   double* raw = h->d_raw;
+  const int nReduce = h->lmBlocks + (h->K + 7) / 8;
+  if (h->fused && h->d_gbar && std::max(h->nChunks, nReduce) <= 512) {
+    const int nb = std::max(h->nChunks, nReduce);
+    h->gbar_total += (unsigned)nb;
+    hipLaunchKernelGGL(k_ba_fused, dim3(nb), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, raw,
+                       raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr, raw ? raw + 16 * (size_t)h->R : nullptr,
+                       h->K, h->L, h->nChunks, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->lmBlocks, nReduce, withLm ? 1 : 0, flags == 0 ? 1 : 0,
+                       h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_costCam, h->d_ticket, h->d_gbar, h->gbar_total, (int*)(h->d_gbar + 1));
+    DVS_HIP(hipGetLastError());
+    return DVS_OK;
+  }
   hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
                      h->d_partial, raw, raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr,
                      raw ? raw + 16 * (size_t)h->R : nullptr);
@@ -886,6 +955,7 @@ void dvs_ba_destroy(dvs_ba* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   ba_free(h);
+  if (h->d_gbar) (void)hipFree(h->d_gbar);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -969,6 +1039,8 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
   DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
   DVS_HIP(hipMalloc((void**)&h->d_costCam, (size_t)std::max(K, 1) * 8)); DVS_HIP(hipMemset(h->d_costCam, 0, (size_t)std::max(K, 1) * 8));
   DVS_HIP(hipMalloc((void**)&h->d_ticket, 4)); DVS_HIP(hipMemset(h->d_ticket, 0, 4));
+  if (!h->d_gbar) { DVS_HIP(hipMalloc((void**)&h->d_gbar, 8)); DVS_HIP(hipMemset(h->d_gbar, 0, 8)); h->gbar_total = 0; }
+  if (const char* ef = getenv("DVS_BA_FUSED")) h->fused = atoi(ef);
   DVS_HIP(hipStreamSynchronize(nullptr));  // the memsets above run on the null stream; the handle's stream is non-blocking
   return DVS_OK;
 }
