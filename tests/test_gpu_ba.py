@@ -2,6 +2,7 @@
 (Ceres autodiff restated with dual numbers).  Tolerances (floating point, stated per assertion):
 residuals bit-exact (same operation order, no FMA), analytic vs autodiff Jacobians and all reductions
 1e-12 relative to the largest magnitude, LM final cost 1e-6 relative."""
+import os
 import numpy as np
 import pytest
 from dvslam_amd import synth
@@ -205,3 +206,29 @@ def test_device_and_host_schur_agree_through_rejections(gpu):
     ta, tb = a.trace(), b.trace()
     assert len(ta) == len(tb) and (ta[:, 1] == tb[:, 1]).all() and np.allclose(ta[:, 0], tb[:, 0], rtol=1e-9, atol=0)
     assert np.allclose(ta[:, 5], tb[:, 5], rtol=1e-2, atol=0) and abs(sa.final_cost - sb.final_cost) <= 1e-6 * sa.final_cost
+
+
+def test_one_launch_evaluation_with_grid_barrier_is_identical(gpu):
+    """k_ba_fused (DVS_BA_FUSED=1: evaluation, bounded grid-wide barrier, reduction in one launch — an experiment kept opt-in because it
+    measured slower) must give bit-identical cost, gradient and Hessian blocks to the two dependent launches, and the same LM solve."""
+    import dvslam_amd
+    P = synth.make_ba_problem(K=6, L=400, seed=11)
+    outs = []
+    for fused in ("0", "1"):
+        old = os.environ.get("DVS_BA_FUSED")
+        os.environ["DVS_BA_FUSED"] = fused
+        try:
+            g = dvslam_amd.BAProblem(P)
+        finally:
+            if old is None:
+                os.environ.pop("DVS_BA_FUSED", None)
+            else:
+                os.environ["DVS_BA_FUSED"] = old
+        c, r, jp, jl, grad = g.evaluate()
+        hpp, hll, w, g2, c2 = g.normal_equations()
+        s = g.solve_device(20)
+        outs.append((c, c2, s.final_cost, s.num_iterations, r, jp, jl, grad, hpp, hll, w, g2))
+    a, b = outs
+    assert a[:4] == b[:4]
+    for x, y in zip(a[4:], b[4:]):
+        assert np.array_equal(x, y)
