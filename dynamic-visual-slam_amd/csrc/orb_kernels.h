@@ -1748,15 +1748,17 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
 #pragma unroll
         for (int j = 0; j < 4; j++) { ring[kk][j] = hprev[j] | (hc[j] << 16); hprev[j] = hc[j]; }
         if (k >= 6 && outl) {
-          uint32_t o = 0;
+          uint32_t acc[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            uint32_t acc = mad_u24(hc[j], kv[6], 32768u);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 2) % 7][j]), k01, acc, false);  // rows k-6, k-5
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 4) % 7][j]), k23, acc, false);  // rows k-4, k-3
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 6) % 7][j]), k45, acc, false);  // rows k-2, k-1
-            o |= ((acc >> 16) & 0xffu) << (8 * j);
+            acc[j] = mad_u24(hc[j], kv[6], 32768u);
+            acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 2) % 7][j]), k01, acc[j], false);  // rows k-6, k-5
+            acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 4) % 7][j]), k23, acc[j], false);  // rows k-4, k-3
+            acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 6) % 7][j]), k45, acc[j], false);  // rows k-2, k-1
           }
+          // byte 2 of each Q16.16 sum is the output pixel: three byte permutes gather the four of them (were four extracts + four inserts)
+          const uint32_t o = __builtin_amdgcn_perm(__builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u), __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u),
+                                                   0x05040100u);
           u8* orow = dst + (uint32_t)((s.y0 + k - 6) * L.pitch + x);
           *reinterpret_cast<uint32_t*>(orow) = o;  // the blurred block has the padded pitch too: a tail word may spill into it
         }
