@@ -1689,6 +1689,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const int xmax = s.level == 0 ? W - 4 : ((W + 8) & ~3) - 4;  // last loadable word start (levels >= 1: padded width)
   const int xl = min(max(x, 0), xmax);
   const bool left_edge = x == 0, right_edge = s.level == 0 && x + 4 == W;
+  const bool strip_left = s.x0 == 0, strip_right = s.level == 0 && s.x0 + s.w >= W;   // wave-uniform
   const uint32_t w0 = (uint32_t)g->gk[0] | ((uint32_t)g->gk[1] << 8) | ((uint32_t)g->gk[2] << 16) | ((uint32_t)g->gk[3] << 24);
   const uint32_t w1 = (uint32_t)g->gk[4] | ((uint32_t)g->gk[5] << 8) | ((uint32_t)g->gk[6] << 16);
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
@@ -1731,8 +1732,9 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
         uint32_t left = __builtin_amdgcn_update_dpp(0u, own, 0x138, 0xf, 0xf, false);
         uint32_t right = __builtin_amdgcn_update_dpp(0u, own, 0x130, 0xf, 0xf, false);
         // px -3,-2,-1 = px 3,2,1 ; px W,W+1,W+2 = px W-2,W-3,W-4
-        if (left_edge) left = ((own >> 24) << 8) | (((own >> 16) & 0xffu) << 16) | (((own >> 8) & 0xffu) << 24);
-        if (right_edge) right = ((own >> 16) & 0xffu) | (((own >> 8) & 0xffu) << 8) | ((own & 0xffu) << 16);
+        // (only strips that touch a border compute the mirrored words at all: a wave-uniform branch, four strips in five skip it)
+        if (strip_left) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0102030cu); left = left_edge ? m : left; }
+        if (strip_right) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0c000102u); right = right_edge ? m : right; }
         // px x+j: bytes x+j-3 .. x+j  = window offset j+1 ; bytes x+j+1 .. x+j+4 = window offset j+5
         const uint32_t a0 = __builtin_amdgcn_alignbyte(own, left, 1), a1 = __builtin_amdgcn_alignbyte(own, left, 2),
                        a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
