@@ -1690,8 +1690,12 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   const int xl = min(max(x, 0), xmax);
   const bool left_edge = x == 0, right_edge = s.level == 0 && x + 4 == W;
   const bool strip_left = s.x0 == 0, strip_right = s.level == 0 && s.x0 + s.w >= W;   // wave-uniform
-  const uint32_t w0 = (uint32_t)g->gk[0] | ((uint32_t)g->gk[1] << 8) | ((uint32_t)g->gk[2] << 16) | ((uint32_t)g->gk[3] << 24);
-  const uint32_t w1 = (uint32_t)g->gk[4] | ((uint32_t)g->gk[5] << 8) | ((uint32_t)g->gk[6] << 16);
+  const uint32_t q0 = (uint32_t)g->gk[0], q1 = (uint32_t)g->gk[1], q2 = (uint32_t)g->gk[2], q3 = (uint32_t)g->gk[3], q4 = (uint32_t)g->gk[4],
+                 q5 = (uint32_t)g->gk[5], q6 = (uint32_t)g->gk[6];
+  const uint32_t wL0 = q0 << 8 | q1 << 16 | q2 << 24, wO0 = q3 | q4 << 8 | q5 << 16 | q6 << 24;
+  const uint32_t wL1 = q0 << 16 | q1 << 24, wO1 = q2 | q3 << 8 | q4 << 16 | q5 << 24, wR1 = q6;
+  const uint32_t wL2 = q0 << 24, wO2 = q1 | q2 << 8 | q3 << 16 | q4 << 24, wR2 = q5 | q6 << 8;
+  const uint32_t wO3 = q0 | q1 << 8 | q2 << 16 | q3 << 24, wR3 = q4 | q5 << 8 | q6 << 16;
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
                           (uint32_t)g->gk[4], (uint32_t)g->gk[5], (uint32_t)g->gk[6]};
   const int rows = min(kBlurBand, H - s.y0);
@@ -1735,16 +1739,14 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
         // (only strips that touch a border compute the mirrored words at all: a wave-uniform branch, four strips in five skip it)
         if (strip_left) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0102030cu); left = left_edge ? m : left; }
         if (strip_right) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0c000102u); right = right_edge ? m : right; }
-        // px x+j: bytes x+j-3 .. x+j  = window offset j+1 ; bytes x+j+1 .. x+j+4 = window offset j+5
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(own, left, 1), a1 = __builtin_amdgcn_alignbyte(own, left, 2),
-                       a2 = __builtin_amdgcn_alignbyte(own, left, 3), a3 = own;
-        const uint32_t b0 = __builtin_amdgcn_alignbyte(right, own, 1), b1 = __builtin_amdgcn_alignbyte(right, own, 2),
-                       b2 = __builtin_amdgcn_alignbyte(right, own, 3), b3 = right;
+        // px x+j takes bytes x+j-3 .. x+j+3 of the 12-byte window (left | own | right): instead of shifting the DATA to a common
+        // alignment (six v_alignbyte per row) the WEIGHTS are kept in the ten alignments the four pixels need (scalar constants):
+        // 2 + 3 + 3 + 2 v_dot4_u32_u8
         uint32_t hc[4];
-        hc[0] = __builtin_amdgcn_udot4(b0, w1, __builtin_amdgcn_udot4(a0, w0, 0u, false), false);
-        hc[1] = __builtin_amdgcn_udot4(b1, w1, __builtin_amdgcn_udot4(a1, w0, 0u, false), false);
-        hc[2] = __builtin_amdgcn_udot4(b2, w1, __builtin_amdgcn_udot4(a2, w0, 0u, false), false);
-        hc[3] = __builtin_amdgcn_udot4(b3, w1, __builtin_amdgcn_udot4(a3, w0, 0u, false), false);
+        hc[0] = __builtin_amdgcn_udot4(own, wO0, __builtin_amdgcn_udot4(left, wL0, 0u, false), false);
+        hc[1] = __builtin_amdgcn_udot4(right, wR1, __builtin_amdgcn_udot4(own, wO1, __builtin_amdgcn_udot4(left, wL1, 0u, false), false), false);
+        hc[2] = __builtin_amdgcn_udot4(right, wR2, __builtin_amdgcn_udot4(own, wO2, __builtin_amdgcn_udot4(left, wL2, 0u, false), false), false);
+        hc[3] = __builtin_amdgcn_udot4(right, wR3, __builtin_amdgcn_udot4(own, wO3, 0u, false), false);
         // ring slot kk holds the PAIR (row k-1, row k) of horizontal sums as two u16 halves: the 7-tap column filter is then
         // three v_dot2_u32_u16 on the pairs formed at rows k-5, k-3, k-1 plus one multiply-add for row k
 #pragma unroll
