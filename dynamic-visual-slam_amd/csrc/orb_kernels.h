@@ -914,25 +914,25 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
     const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
     const uint32_t Lp2 = rp[2 * (P / 4) - 1], Op2 = rp[2 * (P / 4)], Rp2 = rp[2 * (P / 4) + 1];
-    const uint32_t s4 = __builtin_amdgcn_alignbyte(R0, O0, 3);    // ring 4  ( 3, 0)
-    const uint32_t s12 = __builtin_amdgcn_alignbyte(O0, L0, 1);   // ring 12 (-3, 0)
-    const uint32_t s2 = __builtin_amdgcn_alignbyte(Rp2, Op2, 2);  // ring 2  ( 2, 2)
-    const uint32_t s14 = __builtin_amdgcn_alignbyte(Op2, Lp2, 2); // ring 14 (-2, 2)
-    const uint32_t s6 = __builtin_amdgcn_alignbyte(Rm2, Om2, 2);  // ring 6  ( 2,-2)
-    const uint32_t s10 = __builtin_amdgcn_alignbyte(Om2, Lm2, 2); // ring 10 (-2,-2)
     // packed 16-bit evaluation, two pixels per instruction: with r_k the raw ring samples,
     //   all four opposite pairs hold a darker sample   <=>  max_pairs(min(r_k, r_k+8)) < v - t
     //   all four opposite pairs hold a brighter sample <=>  min_pairs(max(r_k, r_k+8)) > v + t
+    // A ring sample of the pixel pair (2 hh, 2 hh + 1) is two bytes of the eight bytes (hi : lo) of two neighbouring words: ONE byte
+    // permute moves them into the 16-bit halves (round 2a shifted the words first — six v_alignbyte per trip — and unpacked then)
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    auto lo2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); };
-    auto hi2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); };
     const s16x2 T2 = {(short)tmin, (short)tmin};
     uint32_t sgn[2];
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
-      auto un = [&](uint32_t w) -> s16x2 { return hh ? hi2(w) : lo2(w); };
-      const s16x2 v2 = un(O0);
-      const s16x2 r0 = un(Op3), r8 = un(Om3), r4 = un(s4), r12 = un(s12), r2 = un(s2), r10 = un(s10), r6 = un(s6), r14 = un(s14);
+      auto pick = [&](uint32_t hi, uint32_t lo, int shift) -> s16x2 {   // bytes shift + 2 hh, shift + 2 hh + 1 of (hi : lo)
+        const uint32_t sel = (uint32_t)(shift + 2 * hh) | 0x0c00u | ((uint32_t)(shift + 2 * hh + 1) << 16) | 0x0c000000u;
+        return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, sel));
+      };
+      const s16x2 v2 = pick(0u, O0, 0);
+      const s16x2 r0 = pick(0u, Op3, 0), r8 = pick(0u, Om3, 0);
+      const s16x2 r4 = pick(R0, O0, 3), r12 = pick(O0, L0, 1);             // ring 4 ( 3, 0), ring 12 (-3, 0)
+      const s16x2 r2 = pick(Rp2, Op2, 2), r14 = pick(Op2, Lp2, 2);         // ring 2 ( 2, 2), ring 14 (-2, 2)
+      const s16x2 r6 = pick(Rm2, Om2, 2), r10 = pick(Om2, Lm2, 2);         // ring 6 ( 2,-2), ring 10 (-2,-2)
       const s16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
                                                  __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
       const s16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
