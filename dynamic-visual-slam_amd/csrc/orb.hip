@@ -520,7 +520,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   if (G.pyrLds > 0) DVS_HIP(hipFuncSetAttribute((const void*)k_pyr_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G.pyrLds));
   DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
   DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
-  DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes));
+  DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes + 256));   // + slack: k_resize4 reads whole 12-byte windows at a row's end
   DVS_HIP(hipMalloc((void**)&h->d_blur, B * G.frameBytes));
   DVS_HIP(hipMalloc((void**)&h->d_cand, B * G.candPerFrame * 4));
   h->d_cand2[0] = h->d_cand; h->d_cand2[1] = nullptr; h->cset = 0; h->la_valid = false;
@@ -580,7 +580,8 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
     if (aligned && D.gtab >= 0)
       hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
                          sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
-                         h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
+                         h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab,
+                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off ? nimg - 1 : -1);   // caller's buffer: no slack behind its last row
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
@@ -684,7 +685,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // candidate set): gated on that call's last kernel (ev_back of the previous call; it precedes this point of `st` anyway).
   auto launch_prefetch = [&](bool after_fast) -> dvs_status {
     if (!(next_img0 && h->overlap && G.nlevels >= 2)) return DVS_OK;
-    if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes));
+    if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes + 256));
     ImgSrc nsrc = src;
     nsrc.img0 = next_img0;
     hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;

@@ -201,7 +201,7 @@ constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x 
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
-                                                 const int* __restrict__ beta) {
+                                                 const int* __restrict__ beta, int guardFrame) {
   // (raising these waves' issue priority over the FAST waves they run beside, s_setprio, was measured: 3 % slower overall)
   const int gx = blockIdx.x * 64 + threadIdx.x;
   const int x4 = gx * 4;
@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
   // uniform frame bases + 32-bit per-lane offsets (a level is far smaller than 4 GB): no 64-bit vector multiply-adds
   const u8* s = src + (uint64_t)f * sfs;
   u8* d = dst + (uint64_t)f * dfs;
-  const bool fastw = t.base + 12 <= sw;
+  // the 12-byte windows of a row's last group run up to 11 bytes past the row: harmless everywhere (the bytes past the last tap carry
+  // zero weights, and what follows a row is the next row, the next level or the allocation's slack) except behind the LAST row of
+  // the LAST frame of a caller's buffer (guardFrame).  Round 2a sent every row-end lane — and with it its whole wavefront, one in
+  // five at level 1, one in two at level 7 — through the bytewise path.
+  const bool tailLane = t.base + 12 > sw;
   uint32_t w0[kResizeRows][3], w1[kResizeRows][3];
   int bb[kResizeRows];
 #pragma unroll
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
     const u8* p0 = s + (uint32_t)(r0 * sp + t.base);
     const u8* p1 = s + (uint32_t)(r1 * sp + t.base);
+    const bool fastw = !(tailLane && f == guardFrame && r1 == sh - 1);
     if (fastw) {
       const uint2 a = *reinterpret_cast<const uint2*>(p0);
       const uint2 c = *reinterpret_cast<const uint2*>(p1);
