@@ -3,10 +3,11 @@ run() { name=$1; shift; envs=""; while [ "$1" != "--" ] && [ -n "$1" ]; do envs=
 import json
 d=json.loads(open('gpurun_out/sw/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/sw/$name.err; }
 run base X=1 --
-run mfmablur DVS_BLUR_MFMA=1 --
 run oct512 DVS_OCT_T=512 --
-run oct384 DVS_OCT_T=384 --
-run oct128 DVS_OCT_T=128 --
+run auxhi DVS_AUX_PRIO=1 --
+run nodefer X=1 -- --defer off
+run pflo DVS_PF_PRIO=-1 --
+run mainhi DVS_MAIN_PRIO=1 --
 run base2 X=1 --
-run bytedma DVS_FAST_BYTE_DMA=1 --
-run nomfmamatch DVS_MATCH_MFMA=0 --
+run b128 X=1 -- --batch 128
+run b32 X=1 -- --batch 32
