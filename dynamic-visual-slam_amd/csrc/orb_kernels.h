@@ -1693,14 +1693,26 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   // buffer) are byte permutations of the edge lane's own word.  No branches, no byte gathers in the row loop.
   const int xmax = s.level == 0 ? W - 4 : ((W + 8) & ~3) - 4;  // last loadable word start (levels >= 1: padded width)
   const int xl = min(max(x, 0), xmax);
-  const bool left_edge = x == 0, right_edge = s.level == 0 && x + 4 == W;
-  const bool strip_left = s.x0 == 0, strip_right = s.level == 0 && s.x0 + s.w >= W;   // wave-uniform
   const uint32_t q0 = (uint32_t)g->gk[0], q1 = (uint32_t)g->gk[1], q2 = (uint32_t)g->gk[2], q3 = (uint32_t)g->gk[3], q4 = (uint32_t)g->gk[4],
                  q5 = (uint32_t)g->gk[5], q6 = (uint32_t)g->gk[6];
-  const uint32_t wL0 = q0 << 8 | q1 << 16 | q2 << 24, wO0 = q3 | q4 << 8 | q5 << 16 | q6 << 24;
-  const uint32_t wL1 = q0 << 16 | q1 << 24, wO1 = q2 | q3 << 8 | q4 << 16 | q5 << 24, wR1 = q6;
-  const uint32_t wL2 = q0 << 24, wO2 = q1 | q2 << 8 | q3 << 16 | q4 << 24, wR2 = q5 | q6 << 8;
-  const uint32_t wO3 = q0 | q1 << 8 | q2 << 16 | q3 << 24, wR3 = q4 | q5 << 8 | q6 << 16;
+  // BORDER_REFLECT_101 in the columns is folded into the WEIGHTS of the one lane that holds a border word (per-lane registers, set
+  // once): px -3, -2, -1 = px 3, 2, 1 add their taps to the own word's bytes and the left word gets weight 0; likewise px W, W + 1,
+  // W + 2 = px W - 2, W - 3, W - 4 at the right border of level 0 (levels >= 1 read the mirrored columns k_resize4 wrote).  Sums of
+  // two Q8 weights stay below 256.  (Round 2a built the mirrored neighbour word per row: two permutes and two selects.)
+  uint32_t wL0 = q0 << 8 | q1 << 16 | q2 << 24, wO0 = q3 | q4 << 8 | q5 << 16 | q6 << 24;
+  uint32_t wL1 = q0 << 16 | q1 << 24, wO1 = q2 | q3 << 8 | q4 << 16 | q5 << 24, wR1 = q6;
+  uint32_t wL2 = q0 << 24, wO2 = q1 | q2 << 8 | q3 << 16 | q4 << 24, wR2 = q5 | q6 << 8;
+  uint32_t wO3 = q0 | q1 << 8 | q2 << 16 | q3 << 24, wR3 = q4 | q5 << 8 | q6 << 16;
+  if (x == 0) {
+    wL0 = 0; wO0 = q3 | (q2 + q4) << 8 | (q1 + q5) << 16 | (q0 + q6) << 24;
+    wL1 = 0; wO1 = q2 | (q1 + q3) << 8 | (q0 + q4) << 16 | q5 << 24;
+    wL2 = 0; wO2 = q1 | (q0 + q2) << 8 | q3 << 16 | q4 << 24;
+  }
+  if (s.level == 0 && x + 4 == W) {
+    wR1 = 0; wO1 = q2 | q3 << 8 | (q4 + q6) << 16 | q5 << 24;
+    wR2 = 0; wO2 = q1 | (q2 + q6) << 8 | (q3 + q5) << 16 | q4 << 24;
+    wR3 = 0; wO3 = (q0 + q6) | (q1 + q5) << 8 | (q2 + q4) << 16 | q3 << 24;
+  }
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
                           (uint32_t)g->gk[4], (uint32_t)g->gk[5], (uint32_t)g->gk[6]};
   const int rows = min(kBlurBand, H - s.y0);
@@ -1741,9 +1753,6 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
         uint32_t left = __builtin_amdgcn_update_dpp(0u, own, 0x138, 0xf, 0xf, false);
         uint32_t right = __builtin_amdgcn_update_dpp(0u, own, 0x130, 0xf, 0xf, false);
         // px -3,-2,-1 = px 3,2,1 ; px W,W+1,W+2 = px W-2,W-3,W-4
-        // (only strips that touch a border compute the mirrored words at all: a wave-uniform branch, four strips in five skip it)
-        if (strip_left) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0102030cu); left = left_edge ? m : left; }
-        if (strip_right) { const uint32_t m = __builtin_amdgcn_perm(0u, own, 0x0c000102u); right = right_edge ? m : right; }
         // px x+j takes bytes x+j-3 .. x+j+3 of the 12-byte window (left | own | right): instead of shifting the DATA to a common
         // alignment (six v_alignbyte per row) the WEIGHTS are kept in the ten alignments the four pixels need (scalar constants):
         // 2 + 3 + 3 + 2 v_dot4_u32_u8
