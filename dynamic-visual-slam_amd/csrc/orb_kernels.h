@@ -135,7 +135,11 @@ __device__ __forceinline__ int oct_threads() {
   const int bd = (int)blockDim.x;
   if (gridDim.x * gridDim.y <= 256 || bd < 512) return bd;
   const int l = (int)blockIdx.y;   // grid = (frames, levels)
+#ifdef DVS_OCT_GRADE_L0
+  return l < 1 ? 512 : 256;
+#else
   return l < 2 ? 512 : (l < 5 ? 256 : 128);
+#endif
 }
 // exclusive scan over oct_threads() (multiple of 64, <= kOctTMax) threads; wsum = kOctTMax / 64 + 1 ints
 __device__ __forceinline__ int block_excl_scan_rt(int v, int* wsum, int& total) {
