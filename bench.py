@@ -354,7 +354,7 @@ def main():
     # same job ran anywhere between 48 k and 72 k frames/s depending on GPU_MAX_HW_QUEUES (kernels alone on the GPU took
     # 1.3-2.5x longer); like this it is 71 k for 4, 6, 8 and 12 queues.
     NP = 1
-    NSETS = 3
+    NSETS = int(os.environ.get("BENCH_NSETS", "4"))   # output sets: set i % NSETS is overwritten by step i + NSETS; its last reader is match i + 1
     orb = dvslam_amd.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local, max_batch=B)
     # streams are created only when used: every HIP stream is a hardware queue, and one idle queue too many cost 0.2 ms per step
     # (measured: an unused fourth stream in the extractor handle, 0.74 -> 0.93 ms)
@@ -490,6 +490,7 @@ def main():
         P["xdone"].record(P["xstream"])
         evh["x"] = P["xdone"].cuda_event
     orb_h, mat_ = P["orb"], P["mat"]
+    skip_match = os.environ.get("BENCH_NO_MATCH") == "1"   # diagnostics only: the extraction pipeline alone (the line is then NOT the metric)
 
     def step_raw():
         i = state["i"]; state["i"] += 1
@@ -516,7 +517,8 @@ def main():
                 L_.dvs_stream_wait_event(M_, evh["fast"])
             if collective and X_ != M_:
                 L_.dvs_stream_wait_event(M_, evh["x"])
-            mat_.match_sequence_device(ptr["desc"][sj], ptr["n"][sj], cap, B, prev_desc, prev_n, ptr["idx"], ptr["dist"])
+            if not skip_match:
+                mat_.match_sequence_device(ptr["desc"][sj], ptr["n"][sj], cap, B, prev_desc, prev_n, ptr["idx"], ptr["dist"])
             L_.dvs_event_record(evh["md"][sj], M_)
         P["cur"] = s
 

@@ -32,6 +32,8 @@ struct dvs_orb {
   hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr;
   hipEvent_t ev_desc = nullptr, ev_prefetch = nullptr;  // descriptor stage reached / next batch's pyramid complete
+  hipEvent_t ev_pf2[2] = {nullptr, nullptr};   // ev_prefetch alternates between these: this call may still wait for its own chain
+  int pf_idx = 0;                               // after it has launched (and recorded) the next batch's
   hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete
   bool overlap = true;
   int max_batch = 1;
@@ -57,6 +59,9 @@ struct dvs_orb {
   // cross-batch software pipeline (dvs_orb_hint_next_batch_device): the NEXT batch's pyramid is built into d_pyr_alt on the
   // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
   u8* d_pyr_alt = nullptr;
+  u8* d_pyr_3rd = nullptr;         // deferred descriptor stages: the pyramid of the batch before is still being read while the next one is built
+  hipEvent_t ev_outs[2] = {nullptr, nullptr};   // the last two deferred descriptor stages (ev_out points at the latest)
+  int out_gen = 0;
   hipEvent_t output_event = nullptr;       // caller's event: outputs complete (dvs_orb_set_output_event => deferred descriptor stage)
   hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // deferred mode: descriptor stage finished (auxiliary stream) / quad-tree finished
   bool out_pending = false;                // the previous call's descriptor stage is still only ordered on the auxiliary stream
@@ -122,7 +127,7 @@ void free_workspace(dvs_orb* h) {
   if (h->d_cellcount2[1]) (void)hipFree(h->d_cellcount2[1]);
   h->d_cand2[0] = h->d_cand2[1] = nullptr; h->d_cellcount2[0] = h->d_cellcount2[1] = nullptr; h->la_valid = false;
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_pyr_alt, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp2[0], h->d_lvlkp2[1], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_pyr_alt, h->d_pyr_3rd, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp2[0], h->d_lvlkp2[1], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount2[0], h->d_lvlcount2[1], h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
@@ -135,7 +140,7 @@ void free_workspace(dvs_orb* h) {
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
   h->d_lvlkp2[0] = h->d_lvlkp2[1] = nullptr; h->d_lvlcount2[0] = h->d_lvlcount2[1] = nullptr;
-  h->d_pyr_alt = nullptr; h->d_orient = nullptr; h->pf_valid = false; h->next_hint = nullptr;
+  h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->out_gen = 0; h->d_orient = nullptr; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
   h->rows = h->cols = 0;
@@ -388,7 +393,8 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     for (const Cell& c : cells) { maxw = std::max<int>(maxw, c.cw); maxh = std::max<int>(maxh, c.ch); }
     G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
     G.fastRows = maxh;
-    const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
+    int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
+    if (const char* el = getenv("DVS_FAST_LIST")) listBytes = atoi(el);   // EXPERIMENT ONLY (occupancy probe): no overflow handling
     G.fastByteDma = h->fast_byte_dma;
     G.fastXcd = getenv("DVS_FAST_XCD") ? atoi(getenv("DVS_FAST_XCD")) : 1;
     G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
@@ -581,7 +587,7 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
       hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
                          sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab,
-                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off ? nimg - 1 : -1);   // caller's buffer: no slack behind its last row
+                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off ? nimg - 1 : -1);   // caller's buffer: no slack behind its last row
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);
@@ -610,12 +616,18 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));
     pend = false;
   }
+  // experiment (DVS_FAST_SPLIT=1): a prefetched pyramid is only needed from level 1 on, so FAST could start on level 0 (52 % of its
+  // cells) at once with the wait for the chain in front of the rest.  Measured: 0.544-0.551 ms per step against 0.524-0.533 with
+  // one FAST launch behind the wait — off.
+  hipEvent_t my_pf = nullptr;
   if (prefetched) {
     std::swap(h->d_pyr, h->d_pyr_alt);
-    // the previous call joined the chain through its blur (below): no barrier packet in front of FAST then
-    if (!h->pf_joined) DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
+    // (non-deferred calls: the previous call joined the chain through its blur, below — no barrier packet at all then)
+    if (!h->pf_joined) my_pf = h->ev_prefetch;
   }
   h->pf_joined = false;
+  const bool fast_split = my_pf && h->geom.nlevels >= 2 && getenv("DVS_FAST_SPLIT") && atoi(getenv("DVS_FAST_SPLIT"));
+  if (my_pf && !fast_split) DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));
   if (la_hit) {
     h->cset ^= 1;
     DVS_HIP(hipStreamWaitEvent(st, h->ev_front, 0));
@@ -689,13 +701,22 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     ImgSrc nsrc = src;
     nsrc.img0 = next_img0;
     hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
-    if (!after_fast && h->env_hops && h->gate_event) {
+    if (pend && !after_fast && !h->env_lookahead && !(getenv("DVS_PYR_TRIPLE") && !atoi(getenv("DVS_PYR_TRIPLE")))) {
+      // the previous call's descriptor stage is still reading that batch's pyramid (d_pyr_alt after the swap above): build into a
+      // THIRD buffer instead of waiting for it — the chain then runs beside FAST from the start, as without deferral (when it waited,
+      // it ended after FAST and became the critical path as soon as FAST got faster).  The third buffer held the pyramid of two
+      // batches ago; its last reader is that batch's descriptor stage, whose event is the only gate (nothing on the main stream).
+      if (!h->d_pyr_3rd) DVS_HIP(hipMalloc((void**)&h->d_pyr_3rd, (size_t)h->max_batch * G.frameBytes + 256));
+      std::swap(h->d_pyr_alt, h->d_pyr_3rd);
+      if (h->out_gen >= 2) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_outs[h->out_gen & 1], 0));
+      gate = nullptr;
+    } else if (!after_fast && h->env_hops && h->gate_event) {
       gate = h->gate_event;                // the previous call's end, recorded there: every reader of d_pyr_alt precedes it
     } else {
       DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
     }
-    DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
-    if (pend) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_out, 0));   // ... except a deferred descriptor stage
+    if (gate) DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
+    if (pend && gate) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_out, 0));   // ... except a deferred descriptor stage
     const bool la = h->env_lookahead && h->fa_stream && !after_fast;
     const int ns = h->cset ^ 1;
     if (la) {
@@ -712,6 +733,8 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
     DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
     h->timer.end(h->pf_stream);
+    h->pf_idx ^= 1;
+    h->ev_prefetch = h->ev_pf2[h->pf_idx];
     DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
     if (la) {
       DVS_HIP(hipStreamWaitEvent(h->fa_stream, h->ev_prefetch, 0));
@@ -730,10 +753,15 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // written by the descriptor stage, which waits for the blur) and the completion of the next batch's level chain (then the next
   // call's FAST needs no barrier packet in front of it; the chain ends before FAST does)
   if (h->overlap && h->aux_stream) {
-    if (h->guard_event) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->guard_event, 0)); h->guard_event = nullptr; }
+    // (with a deferred descriptor stage the guard is waited for right in front of that stage instead — see below — so that a slow
+    // reader of the output buffers does not hold up the blur as well)
+    const bool guard_late = may_defer && h->output_event && h->defer_outputs && !sharded && !h->env_desc_split;
+    if (h->guard_event && !guard_late) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->guard_event, 0)); h->guard_event = nullptr; }
     if (h->env_hops && (h->env_hops > 1 || !(h->defer_outputs && h->output_event)) && h->pf_valid && !sharded && !h->env_pf_after_fast) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_prefetch, 0)); h->pf_joined = true; }
   }
   // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap); nothing to do when it ran ahead
+  bool split_here = fast_split && !la_hit && !ov && !sharded;
+  if (fast_split && !split_here) DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));   // any other FAST schedule: the chain first
   if (!la_hit) {
     if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
       int tail = G.nlevels;  // first level of the merged tail: levels whose cells are < 1/16 of all cells each
@@ -755,7 +783,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
       h->timer.end(st);
     } else {
       h->timer.begin(DVS_STAGE_FAST, st);
-      launch_fast(src, st, h->cset, 0, G.totalCells);
+      if (split_here) {
+        launch_fast(src, st, h->cset, 0, G.lv[0].nCells);                 // level 0 reads the caller's frames only
+        DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));                         // this batch's level chain
+        launch_fast(src, st, h->cset, G.lv[0].nCells, G.totalCells);
+      } else {
+        launch_fast(src, st, h->cset, 0, G.totalCells);
+      }
       h->timer.end(st);
     }
   }
@@ -801,6 +835,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   } else if (h->guard_event) {
     DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
   }
+  hipEvent_t late_guard = (bst != st) ? h->guard_event : nullptr;   // still set only in the deferred case (guard_late above)
   h->guard_event = nullptr;   // one-shot
   h->timer.begin(DVS_STAGE_BLUR, bst);
   // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
@@ -840,10 +875,13 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
       DVS_HIP(hipEventRecord(h->ev_oct, st));
       DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
     }
+    if (late_guard) DVS_HIP(hipStreamWaitEvent(bst, late_guard, 0));   // the caller's readers of the output buffers
     h->timer.begin(DVS_STAGE_DESCRIBE, bst);
     hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, bst, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
                        capacity, h->d_orient);
     h->timer.end(bst);
+    h->ev_out = h->ev_outs[h->out_gen & 1];
+    h->out_gen++;
     DVS_HIP(hipEventRecord(h->ev_out, bst));
     DVS_HIP(hipEventRecord(h->output_event, bst));
     h->out_pending = true;
@@ -935,10 +973,12 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_outs[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_outs[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_end, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_oct, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_prefetch, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pf2[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pf2[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
     dvs_orb_destroy(h);
@@ -975,10 +1015,10 @@ void dvs_orb_destroy(dvs_orb* h) {
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_fast) (void)hipEventDestroy(h->ev_fast);
   if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
-  if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+  for (hipEvent_t e : h->ev_outs) if (e) (void)hipEventDestroy(e);
   if (h->ev_end) (void)hipEventDestroy(h->ev_end);
   if (h->ev_oct) (void)hipEventDestroy(h->ev_oct);
-  if (h->ev_prefetch) (void)hipEventDestroy(h->ev_prefetch);
+  for (hipEvent_t e : h->ev_pf2) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
