@@ -566,21 +566,24 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
 }
 
 // Dense Cholesky + two triangular solves of the n x n reduced system, one workgroup, everything in LDS.
-// Right-looking: at column j the scaled column l_ij = a_ij / sqrt(a_jj) is written to a second array, then the threads subtract
-// l_ij l_kj from the trailing lower triangle — element (i, k) thus receives the subtractions j = 0, 1, ... in the same order as
-// the host routine's dot products (chol_solve), i.e. the factor is bit-identical to it (two barriers per column).  Forward substitution is column-oriented in the
-// host's order too; the backward one applies its updates from the last unknown down (a different association: rounding-level).
-// Writes the (not yet negated) camera steps.
+// Right-looking on the matrix AUGMENTED by the right-hand side as row n: at column j the scaled column l_ij = a_ij / sqrt(a_jj) is
+// written to a second array, then the threads subtract l_ij l_kj from the trailing lower triangle — element (i, k) thus receives the
+// subtractions j = 0, 1, ... in the same order as the host routine's dot products (chol_solve), i.e. the factor is bit-identical to
+// it (two barriers per column; every thread scaling the entries it needs itself saves one of them and costs more in redundant f64
+// divisions: 72 us against 58).
+// Row n undergoes exactly the host's forward substitution (y_j = (b_j - sum_k l_jk y_k) / l_jj, same order), so L y = b costs nothing
+// extra.  The backward substitution applies its updates from the last unknown down (a different association from the host's:
+// rounding-level) — for n <= 64 in the registers of one wavefront (x_j broadcast by readlane, the factor's row prefetched: no LDS
+// round trip and no barrier on the chain of n dependent steps).  Writes the (not yet negated) camera steps.
 __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
                                                  const double* __restrict__ rhs, double* __restrict__ step, LmStatus* __restrict__ st) {
   extern __shared__ double lds[];
-  double* A = lds;                       // working lower triangle (row-major n x n)
-  double* Lm = lds + (size_t)n * n;      // the factor
-  double* b = Lm + (size_t)n * n;
+  double* A = lds;                             // working lower triangle, row-major (n + 1) x n: row n = the right-hand side
+  double* Lm = lds + (size_t)(n + 1) * n;      // the factor, same shape: row n = y
   __shared__ int bad;
   const int tid = threadIdx.x;
   for (int i = tid; i < n * n; i += 256) A[i] = S[i];
-  for (int i = tid; i < n; i += 256) b[i] = rhs[i];
+  for (int i = tid; i < n; i += 256) A[(size_t)n * n + i] = rhs[i];
   for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
@@ -589,31 +592,44 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
     const double ajj = A[(size_t)j * n + j];
     if (!(ajj > 0)) { if (tid == 0) bad = 1; break; }  // uniform: every thread reads the same a_jj
     const double d = sqrt(ajj);
-    const int m = n - j - 1;             // rows / columns j+1 .. n-1 of the trailing block
+    const int m = n - j;                 // rows j+1 .. n (the right-hand side included) of the trailing block; columns j+1 .. n-1
     if (tid == 0) Lm[(size_t)j * n + j] = d;
     for (int i = tid; i < m; i += 256) Lm[(size_t)(j + 1 + i) * n + j] = A[(size_t)(j + 1 + i) * n + j] / d;
     __syncthreads();
-    // trailing update over the lower triangle (i >= k > j): 16 x 16 thread tiling, no index arithmetic beyond the strides
+    // trailing update over the lower triangle (i >= k > j) and the right-hand side row: 16 x 16 thread tiling, no index arithmetic
+    // beyond the strides
     for (int i = ty; i < m; i += 16) {
       const double li = Lm[(size_t)(j + 1 + i) * n + j];
-      for (int k = tx; k <= i; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
+      const int kmax = min(i, m - 2);    // the right-hand side row has no diagonal element
+      for (int k = tx; k <= kmax; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
     }
     __syncthreads();
   }
   __syncthreads();
   if (bad) { if (tid == 0) st->ok = 0; return; }
-  // the two triangular solves are chains of n short steps: one wavefront, wave-level fences instead of workgroup barriers
-  if (tid < 64) {
-    const int lane = tid;
-    // forward: L y = b, column by column (row i receives its subtractions in the order k = 0 .. i-1, like the host loop)
-    for (int j = 0; j < n; j++) {
-      const double yj = b[j] / Lm[(size_t)j * n + j];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-      if (lane == 0) b[j] = yj;
-      for (int i = j + 1 + lane; i < n; i += 64) b[i] -= Lm[(size_t)i * n + j] * yj;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  if (tid >= 64) return;
+  const int lane = tid;
+  const double* y = Lm + (size_t)n * n;
+  if (n <= 64) {
+    // backward: L^T x = y with x in registers (lane i holds unknown i)
+    const int li = min(lane, n - 1);
+    double bi = y[li];
+    double lrow = Lm[(size_t)(n - 1) * n + li], dj = Lm[(size_t)(n - 1) * n + (n - 1)];
+    for (int j = n - 1; j >= 0; j--) {
+      const double lcur = lrow, dcur = dj;
+      if (j > 0) { lrow = Lm[(size_t)(j - 1) * n + min(li, j - 1)]; dj = Lm[(size_t)(j - 1) * n + (j - 1)]; }   // next step's row, off the chain
+      const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(bi) & 0xffffffffll), j);
+      const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(bi) >> 32), j);
+      const double xj = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) / dcur;
+      if (lane == j) bi = xj;
+      else if (lane < j) bi -= lcur * xj;
     }
-    // backward: L^T x = y
+    if (lane < n) step[6 * slotCam[lane / 6] + lane % 6] = bi;
+  } else {
+    // the same chain through LDS for larger systems: wave-level fences instead of workgroup barriers
+    double* b = A;                       // the working triangle is dead: reuse its first row
+    for (int i = lane; i < n; i += 64) b[i] = y[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     for (int j = n - 1; j >= 0; j--) {
       const double xj = b[j] / Lm[(size_t)j * n + j];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -1367,7 +1383,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
     DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
     DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
-    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 96 * 96 + 96) * 8));
+    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
   }
   DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
   DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
@@ -1410,7 +1426,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
-    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), (2 * (size_t)n * n + n) * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
+    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_model, dim3(1), dim3(256), 0, st, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step, h->d_lmPart, h->d_status);
