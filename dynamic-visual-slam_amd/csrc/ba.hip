@@ -587,28 +587,50 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
+  // Look-ahead: the first wavefront is the panel — at step j it applies column j's update to column j + 1 only, takes the square
+  // root of the new pivot and scales that column (the chain of dependent f64 sqrt / divide the factorisation is bound by) — while the
+  // other three subtract l_ij l_kj from the rest of the trailing triangle.  One barrier per column.
+  const int wave = tid >> 6, lane = tid & 63;
+  auto bcast = [](double v, int src) -> double {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  // scale column c from the values a0 (row c + lane) / a1 (row c + lane + 64); lane 0 holds the pivot
+  auto panel = [&](int c, double a0, double a1) {
+    const double piv = bcast(a0, 0);
+    if (!(piv > 0) && lane == 0) bad = 1;   // the factorisation runs on (NaNs from here): no flag to poll on the chain of columns
+    const double d = sqrt(piv);
+    if (lane == 0) Lm[(size_t)c * n + c] = d;
+    else if (c + lane <= n) Lm[(size_t)(c + lane) * n + c] = a0 / d;
+    if (c + 64 <= n && c + lane + 64 <= n) Lm[(size_t)(c + lane + 64) * n + c] = a1 / d;
+  };
+  if (wave == 0) panel(0, A[(size_t)min(lane, n) * n], A[(size_t)min(lane + 64, n) * n]);
+  __syncthreads();
+  const int t3 = tid - 64, ty = t3 >> 4, tx = t3 & 15;   // waves 1..3: 12 x 16 tiling of the trailing block
   for (int j = 0; j < n; j++) {
-    const double ajj = A[(size_t)j * n + j];
-    if (!(ajj > 0)) { if (tid == 0) bad = 1; break; }  // uniform: every thread reads the same a_jj
-    const double d = sqrt(ajj);
     const int m = n - j;                 // rows j+1 .. n (the right-hand side included) of the trailing block; columns j+1 .. n-1
-    if (tid == 0) Lm[(size_t)j * n + j] = d;
-    for (int i = tid; i < m; i += 256) Lm[(size_t)(j + 1 + i) * n + j] = A[(size_t)(j + 1 + i) * n + j] / d;
-    __syncthreads();
-    // trailing update over the lower triangle (i >= k > j) and the right-hand side row: 16 x 16 thread tiling, no index arithmetic
-    // beyond the strides
-    for (int i = ty; i < m; i += 16) {
-      const double li = Lm[(size_t)(j + 1 + i) * n + j];
-      const int kmax = min(i, m - 2);    // the right-hand side row has no diagonal element
-      for (int k = tx; k <= kmax; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
+    if (wave == 0) {
+      const int c = j + 1;
+      if (c < n) {
+        const double lc = Lm[(size_t)c * n + j];
+        const int r0 = min(c + lane, n), r1 = min(c + lane + 64, n);
+        double a1 = 0.0;
+        if (c + 64 <= n) a1 = A[(size_t)r1 * n + c] - Lm[(size_t)r1 * n + j] * lc;
+        panel(c, A[(size_t)r0 * n + c] - Lm[(size_t)r0 * n + j] * lc, a1);
+      }
+    } else {
+      for (int i = 1 + ty; i < m; i += 12) {
+        const double li = Lm[(size_t)(j + 1 + i) * n + j];
+        const int kmax = min(i, m - 2);  // the right-hand side row has no diagonal element
+        for (int k = 1 + tx; k <= kmax; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
+      }
     }
     __syncthreads();
   }
   __syncthreads();
   if (bad) { if (tid == 0) st->ok = 0; return; }
   if (tid >= 64) return;
-  const int lane = tid;
   const double* y = Lm + (size_t)n * n;
   if (n <= 64) {
     // backward: L^T x = y with x in registers (lane i holds unknown i)
