@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
 // Right-looking on the matrix AUGMENTED by the right-hand side as row n: at column j the scaled column l_ij = a_ij / sqrt(a_jj) is
 // written to a second array, then the threads subtract l_ij l_kj from the trailing lower triangle — element (i, k) thus receives the
 // subtractions j = 0, 1, ... in the same order as the host routine's dot products (chol_solve), i.e. the factor is bit-identical to
-// it (two barriers per column; every thread scaling the entries it needs itself saves one of them and costs more in redundant f64
-// divisions: 72 us against 58).
+// it (one barrier per column, see the look-ahead below; every thread scaling the entries it needs itself, the other way to save
+// the second barrier, costs more in redundant f64 divisions: 72 us against 58).
 // Row n undergoes exactly the host's forward substitution (y_j = (b_j - sum_k l_jk y_k) / l_jj, same order), so L y = b costs nothing
 // extra.  The backward substitution applies its updates from the last unknown down (a different association from the host's:
 // rounding-level) — for n <= 64 in the registers of one wavefront (x_j broadcast by readlane, the factor's row prefetched: no LDS
