@@ -507,18 +507,23 @@ __device__ __forceinline__ int butterfly32_index(int lane) {
   return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
 }
 
-// reduced camera system, one workgroup per 6x6 block (ci, ck):  S = (H_pp + D/radius) - sum_l Y_l,ci W_l,ck^T,  rhs likewise
+// reduced camera system, kSchurSplit workgroups per 6x6 block (ci, ck) of the lower triangle:  S = (H_pp + D/radius) - sum_l Y_l,ci W_l,ck^T,
+// rhs likewise.  A thread's landmarks are a chain of dependent loads (observation slots, then 36 doubles); with one workgroup per
+// block that was 8 landmarks = 24 us on 81 CUs.  Split s sums the landmarks l = 256 s + thread (mod 256 kSchurSplit) and writes its
+// total into S + (s + 1) n^2 / rhs + (s + 1) n; split 0 also writes the H_pp part into S / rhs; k_lm_chol adds them up in split order.
+constexpr int kSchurSplit = 4;
 __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int* __restrict__ slotCam, const int* __restrict__ obsOf,
                                                   const unsigned char* __restrict__ active, const double* __restrict__ Hpp,
                                                   const double* __restrict__ g, const double* __restrict__ scale,
                                                   const double* __restrict__ diag, double radius, const double* __restrict__ Ws,
                                                   const double* __restrict__ Y, double* __restrict__ S, double* __restrict__ rhs) {
-  const int ci = blockIdx.x, ck = blockIdx.y;
+  const int ci = blockIdx.x, ck = blockIdx.y, sp = blockIdx.z;
+  if (ck > ci) return;                   // the factorisation reads the lower triangle only
   const int cI = slotCam[ci], cK = slotCam[ck];
   double acc[36], r[6];
   for (int k = 0; k < 36; k++) acc[k] = 0.0;
   for (int k = 0; k < 6; k++) r[k] = 0.0;
-  for (int l = threadIdx.x; l < L; l += 256) {
+  for (int l = 256 * sp + threadIdx.x; l < L; l += 256 * kSchurSplit) {
     const int j0 = 6 * K + 3 * l;
     if (!active[j0]) continue;
     const int e = obsOf[(size_t)l * K + cI], f = obsOf[(size_t)l * K + cK];
@@ -549,19 +554,23 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
     if ((lane & 1) == 0) { wtot[wv][k] = t0; if (k < 10) wtot[wv][32 + k] = t1; }
   }
   __syncthreads();
+  double* Sp = S + (size_t)(sp + 1) * n * n;
+  double* rp = rhs + (size_t)(sp + 1) * n;
   if (threadIdx.x < 36) {
     const int k = threadIdx.x, a = k / 6, b = k - 6 * a;
-    const double tot = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
-    double v = 0.0;
-    if (ci == ck) {
-      v = Hpp[36 * (size_t)cI + 6 * a + b] * scale[6 * cI + a] * scale[6 * cI + b];
-      if (a == b) v += diag[6 * cI + a] / radius;
+    Sp[(size_t)(6 * ci + a) * n + 6 * ck + b] = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
+    if (sp == 0) {
+      double v = 0.0;
+      if (ci == ck) {
+        v = Hpp[36 * (size_t)cI + 6 * a + b] * scale[6 * cI + a] * scale[6 * cI + b];
+        if (a == b) v += diag[6 * cI + a] / radius;
+      }
+      S[(size_t)(6 * ci + a) * n + 6 * ck + b] = v;
     }
-    S[(size_t)(6 * ci + a) * n + 6 * ck + b] = v - tot;
   } else if (ci == ck && threadIdx.x < 42) {
     const int a = threadIdx.x - 36, k = 36 + a;
-    const double tot = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
-    rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a] - tot;
+    rp[6 * ci + a] = ((wtot[0][k] + wtot[1][k]) + wtot[2][k]) + wtot[3][k];
+    if (sp == 0) rhs[6 * ci + a] = g[6 * cI + a] * scale[6 * cI + a];
   }
 }
 
@@ -582,8 +591,30 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   double* Lm = lds + (size_t)(n + 1) * n;      // the factor, same shape: row n = y
   __shared__ int bad;
   const int tid = threadIdx.x;
-  for (int i = tid; i < n * n; i += 256) A[i] = S[i];
-  for (int i = tid; i < n; i += 256) A[(size_t)n * n + i] = rhs[i];
+  // the system from k_lm_schur's pieces: the H_pp part minus the kSchurSplit landmark sums in split order (block lower triangle)
+#pragma unroll 4
+  for (int r = tid >> 6; r < n; r += 4) {            // a wavefront per row: no index division, the loads of four rows in flight together
+    const int cend = 6 * (r / 6) + 6;
+    for (int c = tid & 63; c < n; c += 64) {
+      const int i = r * n + c;
+      double v = 0.0;
+      if (c < cend) {
+        double p[kSchurSplit];
+#pragma unroll
+        for (int sp = 0; sp < kSchurSplit; sp++) p[sp] = S[(size_t)(sp + 1) * n * n + i];
+        double tot = p[0];
+#pragma unroll
+        for (int sp = 1; sp < kSchurSplit; sp++) tot += p[sp];
+        v = S[i] - tot;
+      }
+      A[i] = v;
+    }
+  }
+  for (int i = tid; i < n; i += 256) {
+    double tot = rhs[n + i];
+    for (int sp = 1; sp < kSchurSplit; sp++) tot += rhs[(size_t)(sp + 1) * n + i];
+    A[(size_t)n * n + i] = rhs[i] - tot;
+  }
   for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
@@ -1399,7 +1430,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_HIP(hipMalloc((void**)&h->d_scale, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_diag, (size_t)NT * 8));
     DVS_HIP(hipMalloc((void**)&h->d_step, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_Vinv, (size_t)std::max(L, 1) * 72));
     DVS_HIP(hipMalloc((void**)&h->d_Ws, Rz * 144)); DVS_HIP(hipMalloc((void**)&h->d_Y, Rz * 144));
-    DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, 96 * 8));
+    DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)(1 + kSchurSplit) * 96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, (1 + kSchurSplit) * 96 * 8));
     DVS_HIP(hipMalloc((void**)&h->d_lmPart, (size_t)std::max(L, 1) * 16));
     DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
     DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
@@ -1446,7 +1477,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     hipLaunchKernelGGL(k_lm_observations, dim3((R + 255) / 256), dim3(256), 0, st, K, R, h->d_W, h->d_cam, h->d_lm, h->d_scale, h->d_active, h->d_Vinv,
                        h->d_Ws, h->d_Y);
     reuse_diagonal = true;
-    hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
+    hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc, kSchurSplit), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
