@@ -868,6 +868,8 @@ struct dvs_ba {
   std::vector<int> cam, lm, perm;         // camera-sorted observation arrays, perm[p] = original index
   std::vector<int> lmStart, lmObs;
   std::vector<unsigned char> pose_fixed, lm_fixed;
+  bool lm_ready = false;   // dvs_ba_solve_device: structure tables built and uploaded
+  int lm_nc = 0;           // ... free cameras
   // device
   double *d_q = nullptr, *d_t = nullptr, *d_X = nullptr, *d_uv = nullptr;
   int *d_cam = nullptr, *d_lm = nullptr, *d_camChunkStart = nullptr, *d_lmStart = nullptr, *d_lmObs = nullptr;
@@ -907,6 +909,7 @@ void ba_free(dvs_ba* h) {
   if (h->h_status) (void)hipHostFree(h->h_status);
   h->d_q0 = h->d_t0 = h->d_X0 = h->d_scale = h->d_diag = h->d_step = h->d_Vinv = h->d_Ws = h->d_Y = h->d_S = h->d_rhs = h->d_lmPart = h->d_normPart = nullptr;
   h->d_obsOf = h->d_slotCam = nullptr; h->d_active = nullptr; h->d_status = nullptr; h->h_status = nullptr;
+  h->lm_ready = false;
   h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
   h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
   h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr; h->d_ticket = nullptr;
@@ -1402,49 +1405,56 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   DVS_HIP(hipSetDevice(h->device));
   const int K = h->K, L = h->L, R = h->R, NT = 6 * K + 3 * L;
   if (R == 0) { set_error("no observations"); return DVS_ERR_ARG; }
-  // active blocks, camera slots, observation table
-  std::vector<unsigned char> lmUsed(L, 0), camUsed(K, 0), active(NT, 0);
-  for (int p = 0; p < R; p++) { lmUsed[h->lm[p]] = 1; camUsed[h->cam[p]] = 1; }
-  std::vector<int> slotCam;
-  for (int c = 0; c < K; c++) if (!h->pose_fixed[c] && camUsed[c]) { slotCam.push_back(c); for (int a = 0; a < 6; a++) active[6 * c + a] = 1; }
-  for (int l = 0; l < L; l++) if (!h->lm_fixed[l] && lmUsed[l]) for (int a = 0; a < 3; a++) active[6 * K + 3 * l + a] = 1;
-  const int nc = (int)slotCam.size(), n = 6 * nc;
-  if (K > 64 || nc > 16 || nc == 0) {
-    set_error("dvs_ba_solve_device handles sliding windows (<= 64 cameras, 1..16 of them free); this problem has %d / %d", K, nc);
-    return DVS_ERR_UNSUPPORTED;
-  }
-  std::vector<int> obsOf((size_t)L * K, -1);
-  for (int l = 0; l < L; l++)
-    for (int e = h->lmStart[l]; e < h->lmStart[l + 1]; e++) {
-      const int p = h->lmObs[e];
-      int& slot = obsOf[(size_t)l * K + h->cam[p]];
-      if (slot >= 0) { set_error("landmark %d is observed twice in camera %d: use dvs_ba_solve", l, h->cam[p]); return DVS_ERR_UNSUPPORTED; }
-      slot = p;
+  // active blocks, camera slots, observation table: fixed for the life of the handle (the observation structure and the fixed flags
+  // are set at creation), built and uploaded by the first solve
+  if (!h->lm_ready) {
+    std::vector<unsigned char> lmUsed(L, 0), camUsed(K, 0), active(NT, 0);
+    for (int p = 0; p < R; p++) { lmUsed[h->lm[p]] = 1; camUsed[h->cam[p]] = 1; }
+    std::vector<int> slotCam;
+    for (int c = 0; c < K; c++) if (!h->pose_fixed[c] && camUsed[c]) { slotCam.push_back(c); for (int a = 0; a < 6; a++) active[6 * c + a] = 1; }
+    for (int l = 0; l < L; l++) if (!h->lm_fixed[l] && lmUsed[l]) for (int a = 0; a < 3; a++) active[6 * K + 3 * l + a] = 1;
+    const int nc = (int)slotCam.size();
+    if (K > 64 || nc > 16 || nc == 0) {
+      set_error("dvs_ba_solve_device handles sliding windows (<= 64 cameras, 1..16 of them free); this problem has %d / %d", K, nc);
+      return DVS_ERR_UNSUPPORTED;
     }
+    std::vector<int> obsOf((size_t)L * K, -1);
+    for (int l = 0; l < L; l++)
+      for (int e = h->lmStart[l]; e < h->lmStart[l + 1]; e++) {
+        const int p = h->lmObs[e];
+        int& slot = obsOf[(size_t)l * K + h->cam[p]];
+        if (slot >= 0) { set_error("landmark %d is observed twice in camera %d: use dvs_ba_solve", l, h->cam[p]); return DVS_ERR_UNSUPPORTED; }
+        slot = p;
+      }
+    hipStream_t st = h->stream;
+    if (!h->d_status) {
+      const size_t Rz = std::max(R, 1);
+      DVS_HIP(hipMalloc((void**)&h->d_q0, (size_t)std::max(K, 1) * 32)); DVS_HIP(hipMalloc((void**)&h->d_t0, (size_t)std::max(K, 1) * 24));
+      DVS_HIP(hipMalloc((void**)&h->d_X0, (size_t)std::max(L, 1) * 24));
+      DVS_HIP(hipMalloc((void**)&h->d_scale, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_diag, (size_t)NT * 8));
+      DVS_HIP(hipMalloc((void**)&h->d_step, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_Vinv, (size_t)std::max(L, 1) * 72));
+      DVS_HIP(hipMalloc((void**)&h->d_Ws, Rz * 144)); DVS_HIP(hipMalloc((void**)&h->d_Y, Rz * 144));
+      DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)(1 + kSchurSplit) * 96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, (1 + kSchurSplit) * 96 * 8));
+      DVS_HIP(hipMalloc((void**)&h->d_lmPart, (size_t)std::max(L, 1) * 16));
+      DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
+      DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
+      DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
+      DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
+      DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
+    }
+    DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
+    DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+    DVS_HIP(hipMemcpyAsync(h->d_active, active.data(), (size_t)NT, hipMemcpyHostToDevice, st));
+    DVS_HIP(hipStreamSynchronize(st));   // the host vectors go out of scope
+    h->lm_nc = nc;
+    h->lm_ready = true;
+  }
+  const int nc = h->lm_nc, n = 6 * nc;
   h->trace.clear();
   hipStream_t st = h->stream;
-  if (!h->d_status) {
-    const size_t Rz = std::max(R, 1);
-    DVS_HIP(hipMalloc((void**)&h->d_q0, (size_t)std::max(K, 1) * 32)); DVS_HIP(hipMalloc((void**)&h->d_t0, (size_t)std::max(K, 1) * 24));
-    DVS_HIP(hipMalloc((void**)&h->d_X0, (size_t)std::max(L, 1) * 24));
-    DVS_HIP(hipMalloc((void**)&h->d_scale, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_diag, (size_t)NT * 8));
-    DVS_HIP(hipMalloc((void**)&h->d_step, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_Vinv, (size_t)std::max(L, 1) * 72));
-    DVS_HIP(hipMalloc((void**)&h->d_Ws, Rz * 144)); DVS_HIP(hipMalloc((void**)&h->d_Y, Rz * 144));
-    DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)(1 + kSchurSplit) * 96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, (1 + kSchurSplit) * 96 * 8));
-    DVS_HIP(hipMalloc((void**)&h->d_lmPart, (size_t)std::max(L, 1) * 16));
-    DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
-    DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
-    DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
-    DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
-    DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
-  }
-  DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_active, active.data(), (size_t)NT, hipMemcpyHostToDevice, st));
   DVS_TRY(upload_params(h, h->q, h->t, h->X));
-  DVS_HIP(hipMemcpyAsync(h->d_q0, h->d_q, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_t0, h->d_t, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_X0, h->d_X, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+  const dim3 copyGrid((std::max(4 * K, 3 * L) + 255) / 256);   // one launch instead of three copy commands
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0);
   LmStatus* S = h->h_status;
   auto fetch_status = [&]() -> dvs_status {   // the last kernel wrote the record into the pinned host copy (lm_publish)
     DVS_HIP(hipStreamSynchronize(st));
@@ -1518,9 +1528,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   summary->num_iterations = iteration;
   summary->final_cost = min_cost;
   // the accepted point becomes the problem's parameters (host mirror and evaluation buffers)
-  DVS_HIP(hipMemcpyAsync(h->d_q, h->d_q0, (size_t)K * 32, hipMemcpyDeviceToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_t, h->d_t0, (size_t)K * 24, hipMemcpyDeviceToDevice, st));
-  DVS_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_q, h->d_t, h->d_X);
   DVS_HIP(hipMemcpyAsync(h->q.data(), h->d_q0, (size_t)K * 32, hipMemcpyDeviceToHost, st));
   DVS_HIP(hipMemcpyAsync(h->t.data(), h->d_t0, (size_t)K * 24, hipMemcpyDeviceToHost, st));
   DVS_HIP(hipMemcpyAsync(h->X.data(), h->d_X0, (size_t)L * 24, hipMemcpyDeviceToHost, st));
