@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <chrono>
 #include <vector>
 #include "common.h"
 
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k_ba_fused(BaDev P, const BaChunk* __rest
                                     cost, costCam, ticketCounter);
 }
 
-struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; };
+struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; int seq, pad; };   // seq: number of this publication
 
 __device__ __forceinline__ double block_sum_fixed(double v, double* sm) {  // 256 threads, fixed tree
   const int tid = threadIdx.x;
@@ -803,8 +804,15 @@ __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double
 
 // publish the status record to the host's pinned copy (read after the stream synchronises: no D2H copy command), and — last kernel of
 // a trial step — re-arm the device record for the next one (was a one-thread launch of its own)
-__device__ __forceinline__ void lm_publish(const LmStatus* st, LmStatus* host) {
-  *host = *st;
+// the record first, its sequence number after a system-scope fence: the host polls the number (dvs_ba_solve_device) instead of
+// waiting for the stream
+__device__ __forceinline__ void lm_publish(LmStatus* st, LmStatus* host) {
+  const int seq = st->seq + 1;
+  st->seq = seq;
+  host->ok = st->ok; host->finite = st->finite; host->model_change = st->model_change; host->sn = st->sn; host->xn = st->xn;
+  host->cand_cost = st->cand_cost; host->gmax = st->gmax; host->x_cost = st->x_cost;
+  __threadfence_system();
+  *reinterpret_cast<volatile int*>(&host->seq) = seq;
   __threadfence_system();
 }
 
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __r
   if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; lm_publish(st, host); }
 }
 
-__global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; }
+__global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; st->seq = 0; }
 
 }  // namespace dvs
 
@@ -890,6 +898,7 @@ struct dvs_ba {
   unsigned char* d_active = nullptr;
   dvs::LmStatus* d_status = nullptr;
   dvs::LmStatus* h_status = nullptr;  // pinned
+  double* h_out = nullptr;            // pinned staging of the solved parameters (q, t, X)
   std::vector<double> trace;          // dvs_ba_get_trace: 6 doubles per trust-region iteration of the last solve
   void log(double radius, int kind, double dc, double dm, double rel, double cand) {
     const double row[6] = {radius, (double)kind, dc, dm, rel, cand};
@@ -907,6 +916,8 @@ void ba_free(dvs_ba* h) {
                  h->d_normPart, h->d_obsOf, h->d_slotCam, h->d_active, h->d_status};
   for (void* p : lmp) if (p) (void)hipFree(p);
   if (h->h_status) (void)hipHostFree(h->h_status);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  h->h_out = nullptr;
   h->d_q0 = h->d_t0 = h->d_X0 = h->d_scale = h->d_diag = h->d_step = h->d_Vinv = h->d_Ws = h->d_Y = h->d_S = h->d_rhs = h->d_lmPart = h->d_normPart = nullptr;
   h->d_obsOf = h->d_slotCam = nullptr; h->d_active = nullptr; h->d_status = nullptr; h->h_status = nullptr;
   h->lm_ready = false;
@@ -1440,6 +1451,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
       DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
       DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
       DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
+      DVS_HIP(hipHostMalloc((void**)&h->h_out, ((size_t)7 * std::max(K, 1) + 3 * (size_t)std::max(L, 1)) * 8));
       DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
     }
     DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
@@ -1452,11 +1464,36 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   const int nc = h->lm_nc, n = 6 * nc;
   h->trace.clear();
   hipStream_t st = h->stream;
+  const bool dbg = getenv("DVS_LM_POLL_DEBUG") != nullptr;
+  const auto T0 = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double>> stamps;   // diagnostics (DVS_LM_POLL_DEBUG): printed for a solve that took > 3 ms
+  if (dbg) stamps.reserve(256);
+  auto stamp = [&](const char* what) {
+    if (dbg) stamps.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count());
+  };
   DVS_TRY(upload_params(h, h->q, h->t, h->X));
+  stamp("params");
   const dim3 copyGrid((std::max(4 * K, 3 * L) + 255) / 256);   // one launch instead of three copy commands
   hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0);
   LmStatus* S = h->h_status;
-  auto fetch_status = [&]() -> dvs_status {   // the last kernel wrote the record into the pinned host copy (lm_publish)
+  // the last kernel enqueued wrote the record into the pinned host copy (lm_publish): poll its sequence number — a bounded spin,
+  // then the stream wait — instead of sleeping in hipStreamSynchronize (a wake-up per trial step and per accepted step)
+  int expect_seq = 0;
+  S->seq = 0;
+  static const bool poll = !(getenv("DVS_LM_POLL") && !atoi(getenv("DVS_LM_POLL")));
+  auto fetch_status = [&]() -> dvs_status {
+    expect_seq++;
+    if (poll) {
+      const volatile int* seq = &S->seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int spin = 1; *seq != expect_seq; spin++) {
+        __builtin_ia32_pause();
+        if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (*seq == expect_seq) return DVS_OK;
+      if (getenv("DVS_LM_POLL_DEBUG")) fprintf(stderr, "[dvs] LM status poll timed out (seq %d, expected %d)\n", (int)*seq, expect_seq);
+    }
     DVS_HIP(hipStreamSynchronize(st));
     return DVS_OK;
   };
@@ -1467,6 +1504,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   };
   hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
   DVS_TRY(evaluate_full());
+  stamp("first eval");
   double x_cost = S->x_cost, gmax = S->gmax;
   summary->initial_cost = x_cost;
   double min_cost = x_cost;
@@ -1498,7 +1536,9 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
     hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, h->d_status, S);
     DVS_HIP(hipGetLastError());
+    stamp("trial enqueued");
     DVS_TRY(fetch_status());
+    stamp("trial done");
     const bool valid = S->ok && S->finite && S->model_change > 0.0;
     if (!valid) {
       h->log(radius, 0, 0, S->model_change, 0, 0);
@@ -1529,10 +1569,17 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   summary->final_cost = min_cost;
   // the accepted point becomes the problem's parameters (host mirror and evaluation buffers)
   hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_q, h->d_t, h->d_X);
-  DVS_HIP(hipMemcpyAsync(h->q.data(), h->d_q0, (size_t)K * 32, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipMemcpyAsync(h->t.data(), h->d_t0, (size_t)K * 24, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipMemcpyAsync(h->X.data(), h->d_X0, (size_t)L * 24, hipMemcpyDeviceToHost, st));
+  // ... the host mirror through the handle's pinned block, written by a kernel: the three device-to-host copy commands this replaces
+  // now and then blocked for 7 ms when enqueued (first solve after a warm-up, pageable or pinned destination alike)
+  double* ho = h->h_out;
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, ho, ho + 4 * (size_t)K, ho + 7 * (size_t)K);
+  stamp("copies enqueued");
   DVS_HIP(hipStreamSynchronize(st));
+  memcpy(h->q.data(), ho, (size_t)K * 32); memcpy(h->t.data(), ho + 4 * (size_t)K, (size_t)K * 24);
+  memcpy(h->X.data(), ho + 7 * (size_t)K, (size_t)L * 24);
+  stamp("end");
+  if (dbg && stamps.back().second > 3000.0)
+    for (auto& e : stamps) fprintf(stderr, "[dvs] LM %-16s %9.1f us\n", e.first, e.second);
   return DVS_OK;
 }
 

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "dynamic-visual
 import dvslam_amd
 from dvslam_amd import synth
 P = synth.make_ba_problem(K=10, L=2000, seed=42)
-gd = dvslam_amd.BAProblem(P, device=0); gd.solve_device(1)
+gd = dvslam_amd.BAProblem(P, device=0); gd.solve_device(20)   # warm-up: a whole solve
 ts = []
 for r in range(7):
     gd = dvslam_amd.BAProblem(P, device=0); gd.solve_device(0)
