@@ -745,27 +745,6 @@ __global__ __launch_bounds__(256) void k_lm_backsub(int K, int L, const double* 
   if (l < L && m == 0) { lmPart[2 * (size_t)l] = (g0 + g1) + g2; lmPart[2 * (size_t)l + 1] = (h0 + h1) + h2; }
 }
 
-// negate the camera steps, add the camera terms, reduce: model_cost_change = -(step.g + step^T H step / 2)
-__global__ __launch_bounds__(256) void k_lm_model(int K, int L, const double* __restrict__ Hpp, const double* __restrict__ g,
-                                                  const double* __restrict__ scale, double* __restrict__ step,
-                                                  const double* __restrict__ lmPart, LmStatus* __restrict__ st) {
-  __shared__ double sm[256];
-  const int tid = threadIdx.x;
-  for (int j = tid; j < 6 * K; j += 256) step[j] = -step[j];
-  __syncthreads();
-  double sg = 0.0, sHs = 0.0, fin = 0.0;
-  for (int j = tid; j < 6 * K; j += 256) { sg += step[j] * g[j] * scale[j]; if (!isfinite(step[j])) fin = 1.0; }
-  for (int c = tid; c < K; c += 256)
-    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
-      sHs += step[6 * c + a] * scale[6 * c + a] * Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + b] * step[6 * c + b];
-  for (int l = tid; l < L; l += 256) { sg += lmPart[2 * (size_t)l]; sHs += lmPart[2 * (size_t)l + 1]; }
-  const double tg = block_sum_fixed(sg, sm), th = block_sum_fixed(sHs, sm), tf = block_sum_fixed(fin, sm);
-  if (tid == 0) {
-    if (tf > 0.0) st->finite = 0;
-    st->model_change = -(tg + 0.5 * th);
-  }
-}
-
 // candidate point x + Plus(step * scale) into the evaluation buffers; partial sums of |x - cand|^2 and |x|^2 per workgroup
 __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double* __restrict__ q0, const double* __restrict__ t0,
                                                       const double* __restrict__ X0, const double* __restrict__ step,
@@ -779,9 +758,10 @@ __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double
     const int c = i;
     double cq[4], ct[3];
     if (active[6 * c]) {
-      const double d[3] = {step[6 * c] * scale[6 * c], step[6 * c + 1] * scale[6 * c + 1], step[6 * c + 2] * scale[6 * c + 2]};
+      // the camera steps are stored as k_lm_chol solved them (not negated: k_lm_backsub reads them so); the landmarks' are negated
+      const double d[3] = {-step[6 * c] * scale[6 * c], -step[6 * c + 1] * scale[6 * c + 1], -step[6 * c + 2] * scale[6 * c + 2]};
       quat_plus_dev(q0 + 4 * c, d, cq);
-      for (int k = 0; k < 3; k++) ct[k] = t0[3 * c + k] + step[6 * c + 3 + k] * scale[6 * c + 3 + k];
+      for (int k = 0; k < 3; k++) ct[k] = t0[3 * c + k] + -step[6 * c + 3 + k] * scale[6 * c + 3 + k];
       for (int k = 0; k < 4; k++) { sn += (q0[4 * c + k] - cq[k]) * (q0[4 * c + k] - cq[k]); xn += q0[4 * c + k] * q0[4 * c + k]; }
       for (int k = 0; k < 3; k++) { sn += (t0[3 * c + k] - ct[k]) * (t0[3 * c + k] - ct[k]); xn += t0[3 * c + k] * t0[3 * c + k]; }
     } else {
@@ -816,13 +796,28 @@ __device__ __forceinline__ void lm_publish(LmStatus* st, LmStatus* host) {
   __threadfence_system();
 }
 
-__global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __restrict__ part, const double* __restrict__ cost,
-                                                  LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
+// Last kernel of a trial step: the step / point norms from k_lm_candidate's partial sums, the candidate's cost, and the model cost
+// change -(step.g + step^T H step / 2) from the (negated) camera steps, the camera blocks and k_lm_backsub's landmark terms (was a
+// launch of its own between back-substitution and candidate).
+__global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __restrict__ part, const double* __restrict__ cost, int K, int L,
+                                                  const double* __restrict__ Hpp, const double* __restrict__ g,
+                                                  const double* __restrict__ scale, const double* __restrict__ step,
+                                                  const double* __restrict__ lmPart, LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
   __shared__ double sm[256];
+  const int tid = threadIdx.x;
   double sn = 0.0, xn = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) { sn += part[2 * i]; xn += part[2 * i + 1]; }
+  for (int i = tid; i < nparts; i += 256) { sn += part[2 * i]; xn += part[2 * i + 1]; }
+  double sg = 0.0, sHs = 0.0, fin = 0.0;
+  for (int j = tid; j < 6 * K; j += 256) { sg += -step[j] * g[j] * scale[j]; if (!isfinite(step[j])) fin = 1.0; }
+  for (int c = tid; c < K; c += 256)
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
+      sHs += -step[6 * c + a] * scale[6 * c + a] * Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + b] * -step[6 * c + b];
+  for (int l = tid; l < L; l += 256) { sg += lmPart[2 * (size_t)l]; sHs += lmPart[2 * (size_t)l + 1]; }
   const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
-  if (threadIdx.x == 0) {
+  const double tg = block_sum_fixed(sg, sm), th = block_sum_fixed(sHs, sm), tf = block_sum_fixed(fin, sm);
+  if (tid == 0) {
+    if (tf > 0.0) st->finite = 0;
+    st->model_change = -(tg + 0.5 * th);
     st->sn = a; st->xn = b; st->cand_cost = *cost;
     lm_publish(st, host);
     st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0;
@@ -1530,11 +1525,11 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
-    hipLaunchKernelGGL(k_lm_model, dim3(1), dim3(256), 0, st, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,
                        h->d_q, h->d_t, h->d_X, h->d_normPart);
     DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
-    hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, h->d_status, S);
+    hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step,
+                       h->d_lmPart, h->d_status, S);
     DVS_HIP(hipGetLastError());
     stamp("trial enqueued");
     DVS_TRY(fetch_status());
