@@ -32,6 +32,7 @@ struct BaDev {
   const int *cam, *lm;
   const unsigned char *pose_fixed, *lm_fixed;
   double fx, fy, cx, cy, inv_sigma, huber_a;
+  const int* gate;   // if set and *gate == 0 the evaluation launches do nothing (speculative launches of dvs_ba_solve_device)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
                                                  double* __restrict__ W, double* __restrict__ partial,
                                                  double* __restrict__ rawRes, double* __restrict__ rawJq,
                                                  double* __restrict__ rawJt, double* __restrict__ rawJX) {
+  if (P.gate && !*P.gate) return;
   ba_eval_body((int)blockIdx.x, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
 }
 
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nC
                                                    int withLm, int costOnly, double* __restrict__ Hpp, double* __restrict__ Hll,
                                                    double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
                                                    int* __restrict__ ticketCounter) {
+  if (P.gate && !*P.gate) return;
   ba_reduce_body((int)blockIdx.x, (int)gridDim.x, P, K, L, nChunks, chunks, camChunkStart, lmStart, lmObs, res, Jl, partial, lmBlocks, withLm, costOnly, Hpp, Hll, g, cost, costCam, ticketCounter);
 }
 
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void k_ba_fused(BaDev P, const BaChunk* __rest
                                     cost, costCam, ticketCounter);
 }
 
-struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; int seq, pad; };   // seq: number of this publication
+struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; int seq, accept; };   // seq: number of this publication; accept: the trial step's verdict (k_lm_norms)
 
 __device__ __forceinline__ double block_sum_fixed(double v, double* sm) {  // 256 threads, fixed tree
   const int tid = threadIdx.x;
@@ -790,7 +793,7 @@ __device__ __forceinline__ void lm_publish(LmStatus* st, LmStatus* host) {
   const int seq = st->seq + 1;
   st->seq = seq;
   host->ok = st->ok; host->finite = st->finite; host->model_change = st->model_change; host->sn = st->sn; host->xn = st->xn;
-  host->cand_cost = st->cand_cost; host->gmax = st->gmax; host->x_cost = st->x_cost;
+  host->cand_cost = st->cand_cost; host->gmax = st->gmax; host->x_cost = st->x_cost; host->accept = st->accept;
   __threadfence_system();
   *reinterpret_cast<volatile int*>(&host->seq) = seq;
   __threadfence_system();
@@ -802,7 +805,8 @@ __device__ __forceinline__ void lm_publish(LmStatus* st, LmStatus* host) {
 __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __restrict__ part, const double* __restrict__ cost, int K, int L,
                                                   const double* __restrict__ Hpp, const double* __restrict__ g,
                                                   const double* __restrict__ scale, const double* __restrict__ step,
-                                                  const double* __restrict__ lmPart, LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
+                                                  const double* __restrict__ lmPart, double ptol, double ftol, LmStatus* __restrict__ st,
+                                                  LmStatus* __restrict__ host) {
   __shared__ double sm[256];
   const int tid = threadIdx.x;
   double sn = 0.0, xn = 0.0;
@@ -819,6 +823,14 @@ __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __re
     if (tf > 0.0) st->finite = 0;
     st->model_change = -(tg + 0.5 * th);
     st->sn = a; st->xn = b; st->cand_cost = *cost;
+    // the verdict of dvs_ba_solve_device's loop, in its order and arithmetic (IEEE sqrt / divide on both sides): the launches that
+    // follow an accepted step are already enqueued behind this kernel and read it
+    int acc = 0;
+    if (st->ok && st->finite && st->model_change > 0.0 && !(sqrt(a) <= ptol * (sqrt(b) + ptol))) {
+      const double cost_change = st->x_cost - st->cand_cost;
+      if (!(fabs(cost_change) <= ftol * st->x_cost)) acc = cost_change / st->model_change > 1e-3 ? 1 : 0;
+    }
+    st->accept = acc;
     lm_publish(st, host);
     st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0;
   }
@@ -827,7 +839,8 @@ __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __re
 // the accepted candidate becomes the point of the next iteration (one launch instead of three copy commands)
 __global__ __launch_bounds__(256) void k_lm_accept(int K, int L, const double* __restrict__ q, const double* __restrict__ t,
                                                    const double* __restrict__ X, double* __restrict__ q0, double* __restrict__ t0,
-                                                   double* __restrict__ X0) {
+                                                   double* __restrict__ X0, const int* __restrict__ gate) {
+  if (gate && !*gate) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 4 * K) q0[i] = q[i];
   if (i < 3 * K) t0[i] = t[i];
@@ -837,7 +850,8 @@ __global__ __launch_bounds__(256) void k_lm_accept(int K, int L, const double* _
 // Ceres' gradient max-norm: |x - Plus(x, -g)|_inf over the active blocks, and the cost of the accepted point
 __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __restrict__ q0, const double* __restrict__ g,
                                                  const unsigned char* __restrict__ active, const double* __restrict__ cost,
-                                                 LmStatus* __restrict__ st, LmStatus* __restrict__ host) {
+                                                 LmStatus* __restrict__ st, LmStatus* __restrict__ host, const int* __restrict__ gate) {
+  if (gate && !*gate) return;
   __shared__ double sm[256];
   const int tid = threadIdx.x;
   double m = 0.0;
@@ -856,7 +870,7 @@ __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __r
   if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; lm_publish(st, host); }
 }
 
-__global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; st->seq = 0; }
+__global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; st->seq = 0; st->accept = 0; }
 
 }  // namespace dvs
 
@@ -894,6 +908,7 @@ struct dvs_ba {
   dvs::LmStatus* d_status = nullptr;
   dvs::LmStatus* h_status = nullptr;  // pinned
   double* h_out = nullptr;            // pinned staging of the solved parameters (q, t, X)
+  const int* eval_gate = nullptr;     // see BaDev::gate
   std::vector<double> trace;          // dvs_ba_get_trace: 6 doubles per trust-region iteration of the last solve
   void log(double radius, int kind, double dc, double dm, double rel, double cand) {
     const double row[6] = {radius, (double)kind, dc, dm, rel, cand};
@@ -933,6 +948,7 @@ BaDev dev_view(const dvs_ba* h) {
   P.q = h->d_q; P.t = h->d_t; P.X = h->d_X; P.uv = h->d_uv; P.cam = h->d_cam; P.lm = h->d_lm;
   P.pose_fixed = h->d_pf; P.lm_fixed = h->d_lf;
   P.fx = h->fx; P.fy = h->fy; P.cx = h->cx; P.cy = h->cy; P.inv_sigma = 1.0 / h->sigma; P.huber_a = h->huber;
+  P.gate = h->eval_gate;
   return P;
 }
 
@@ -1469,7 +1485,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   DVS_TRY(upload_params(h, h->q, h->t, h->X));
   stamp("params");
   const dim3 copyGrid((std::max(4 * K, 3 * L) + 255) / 256);   // one launch instead of three copy commands
-  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0);
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, nullptr);
   LmStatus* S = h->h_status;
   // the last kernel enqueued wrote the record into the pinned host copy (lm_publish): poll its sequence number — a bounded spin,
   // then the stream wait — instead of sleeping in hipStreamSynchronize (a wake-up per trial step and per accepted step)
@@ -1492,11 +1508,22 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_HIP(hipStreamSynchronize(st));
     return DVS_OK;
   };
-  auto evaluate_full = [&]() -> dvs_status {  // Jacobian blocks, gradient, cost of the point in the evaluation buffers
-    DVS_TRY(enqueue_eval(h, 1 | 2, true));
-    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, S);
-    return fetch_status();
+  // Jacobian blocks, gradient, cost of the point in the evaluation buffers; `gate`: only if the device's verdict says so
+  auto enqueue_full = [&](const int* gate) -> dvs_status {
+    h->eval_gate = gate;
+    const dvs_status e = enqueue_eval(h, 1 | 2, true);
+    h->eval_gate = nullptr;
+    DVS_TRY(e);
+    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, S, gate);
+    return DVS_OK;
   };
+  auto evaluate_full = [&]() -> dvs_status { DVS_TRY(enqueue_full(nullptr)); return fetch_status(); };
+  // The launches that follow an accepted step (accept, full evaluation, gradient norm: ~27 us of host launch time) are enqueued right
+  // behind the trial, gated on the verdict k_lm_norms leaves in the status record, so that they are ready when the trial ends; the
+  // host takes the same decision from the same numbers and insists that the two agree.  Not with the fused evaluation (its grid
+  // barrier counts launches on the host).
+  const int* verdict = &h->d_status->accept;
+  const bool speculate = !(h->fused && h->d_gbar) && !(getenv("DVS_LM_SPECULATE") && !atoi(getenv("DVS_LM_SPECULATE")));
   hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
   DVS_TRY(evaluate_full());
   stamp("first eval");
@@ -1529,27 +1556,42 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
                        h->d_q, h->d_t, h->d_X, h->d_normPart);
     DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
     hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step,
-                       h->d_lmPart, h->d_status, S);
+                       h->d_lmPart, ptol, ftol, h->d_status, S);
+    if (speculate) {
+      hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, verdict);
+      DVS_TRY(enqueue_full(verdict));
+    }
     DVS_HIP(hipGetLastError());
     stamp("trial enqueued");
     DVS_TRY(fetch_status());
     stamp("trial done");
     const bool valid = S->ok && S->finite && S->model_change > 0.0;
+    const int dev_verdict = S->accept;
+    auto agree = [&](int mine) -> dvs_status {
+      if (speculate && dev_verdict != mine) { set_error("LM: host and device disagree on a trial step (%d / %d)", mine, dev_verdict); return DVS_ERR_HIP; }
+      return DVS_OK;
+    };
     if (!valid) {
+      DVS_TRY(agree(0));
       h->log(radius, 0, 0, S->model_change, 0, 0);
       if (++invalid >= 5) { summary->termination = 2; break; }
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = false;
       continue;
     }
     invalid = 0;
-    if (sqrt(S->sn) <= ptol * (sqrt(S->xn) + ptol)) { h->log(radius, 3, x_cost - S->cand_cost, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
+    if (sqrt(S->sn) <= ptol * (sqrt(S->xn) + ptol)) { DVS_TRY(agree(0)); h->log(radius, 3, x_cost - S->cand_cost, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
     const double cost_change = x_cost - S->cand_cost;
-    if (fabs(cost_change) <= ftol * x_cost) { h->log(radius, 4, cost_change, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
+    if (fabs(cost_change) <= ftol * x_cost) { DVS_TRY(agree(0)); h->log(radius, 4, cost_change, S->model_change, 0, S->cand_cost); summary->termination = 0; break; }
     const double rel = cost_change / S->model_change;
     h->log(radius, rel > 1e-3 ? 1 : 2, cost_change, S->model_change, rel, S->cand_cost);
+    DVS_TRY(agree(rel > 1e-3 ? 1 : 0));
     if (rel > 1e-3) {
-      hipLaunchKernelGGL(k_lm_accept, dim3((std::max(4 * K, 3 * L) + 255) / 256), dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0);
-      DVS_TRY(evaluate_full());
+      if (speculate) {
+        DVS_TRY(fetch_status());         // the gated launches ran: wait for k_lm_gmax's record
+      } else {
+        hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, nullptr);
+        DVS_TRY(evaluate_full());
+      }
       x_cost = S->x_cost; gmax = S->gmax;
       summary->num_successful_steps++;
       min_cost = std::min(min_cost, x_cost);
@@ -1563,11 +1605,11 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   summary->num_iterations = iteration;
   summary->final_cost = min_cost;
   // the accepted point becomes the problem's parameters (host mirror and evaluation buffers)
-  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_q, h->d_t, h->d_X);
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_q, h->d_t, h->d_X, nullptr);
   // ... the host mirror through the handle's pinned block, written by a kernel: the three device-to-host copy commands this replaces
   // now and then blocked for 7 ms when enqueued (first solve after a warm-up, pageable or pinned destination alike)
   double* ho = h->h_out;
-  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, ho, ho + 4 * (size_t)K, ho + 7 * (size_t)K);
+  hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, ho, ho + 4 * (size_t)K, ho + 7 * (size_t)K, nullptr);
   stamp("copies enqueued");
   DVS_HIP(hipStreamSynchronize(st));
   memcpy(h->q.data(), ho, (size_t)K * 32); memcpy(h->t.data(), ho + 4 * (size_t)K, (size_t)K * 24);
