@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
 // extra.  The backward substitution applies its updates from the last unknown down (a different association from the host's:
 // rounding-level) — for n <= 64 in the registers of one wavefront (x_j broadcast by readlane, the factor's row prefetched: no LDS
 // round trip and no barrier on the chain of n dependent steps).  Writes the (not yet negated) camera steps.
-__global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
+constexpr int kCholThreads = 1024;   // one panel wavefront + fifteen for the trailing update
+__global__ __launch_bounds__(kCholThreads) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
                                                  const double* __restrict__ rhs, double* __restrict__ step, LmStatus* __restrict__ st) {
   extern __shared__ double lds[];
   double* A = lds;                             // working lower triangle, row-major (n + 1) x n: row n = the right-hand side
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   const int tid = threadIdx.x;
   // the system from k_lm_schur's pieces: the H_pp part minus the kSchurSplit landmark sums in split order (block lower triangle)
 #pragma unroll 4
-  for (int r = tid >> 6; r < n; r += 4) {            // a wavefront per row: no index division, the loads of four rows in flight together
+  for (int r = tid >> 6; r < n; r += kCholThreads / 64) {   // a wavefront per row: no index division, the loads of four rows in flight together
     const int cend = 6 * (r / 6) + 6;
     for (int c = tid & 63; c < n; c += 64) {
       const int i = r * n + c;
@@ -614,12 +615,12 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
       A[i] = v;
     }
   }
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += kCholThreads) {
     double tot = rhs[n + i];
     for (int sp = 1; sp < kSchurSplit; sp++) tot += rhs[(size_t)(sp + 1) * n + i];
     A[(size_t)n * n + i] = rhs[i] - tot;
   }
-  for (int i = tid; i < 6 * K; i += 256) step[i] = 0.0;
+  for (int i = tid; i < 6 * K; i += kCholThreads) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
   // Look-ahead: the first wavefront is the panel — at step j it applies column j's update to column j + 1 only, takes the square
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
   };
   if (wave == 0) panel(0, A[(size_t)min(lane, n) * n], A[(size_t)min(lane + 64, n) * n]);
   __syncthreads();
-  const int t3 = tid - 64, ty = t3 >> 4, tx = t3 & 15;   // waves 1..3: 12 x 16 tiling of the trailing block
+  constexpr int kTy = (kCholThreads - 64) / 16;
+  const int t3 = tid - 64, ty = t3 >> 4, tx = t3 & 15;   // the other wavefronts: kTy x 16 tiling of the trailing block
   for (int j = 0; j < n; j++) {
     const int m = n - j;                 // rows j+1 .. n (the right-hand side included) of the trailing block; columns j+1 .. n-1
     if (wave == 0) {
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(256) void k_lm_chol(int K, int n, const int* __rest
         panel(c, A[(size_t)r0 * n + c] - Lm[(size_t)r0 * n + j] * lc, a1);
       }
     } else {
-      for (int i = 1 + ty; i < m; i += 12) {
+      for (int i = 1 + ty; i < m; i += kTy) {
         const double li = Lm[(size_t)(j + 1 + i) * n + j];
         const int kmax = min(i, m - 2);  // the right-hand side row has no diagonal element
         for (int k = 1 + tx; k <= kmax; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
@@ -1549,7 +1551,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc, kSchurSplit), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
-    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(256), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
+    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(kCholThreads), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,
