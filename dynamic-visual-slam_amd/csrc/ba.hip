@@ -809,7 +809,6 @@ __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __re
                                                   const double* __restrict__ scale, const double* __restrict__ step,
                                                   const double* __restrict__ lmPart, double ptol, double ftol, LmStatus* __restrict__ st,
                                                   LmStatus* __restrict__ host) {
-  __shared__ double sm[256];
   const int tid = threadIdx.x;
   double sn = 0.0, xn = 0.0;
   for (int i = tid; i < nparts; i += 256) { sn += part[2 * i]; xn += part[2 * i + 1]; }
@@ -819,8 +818,18 @@ __global__ __launch_bounds__(256) void k_lm_norms(int nparts, const double* __re
     for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++)
       sHs += -step[6 * c + a] * scale[6 * c + a] * Hpp[36 * (size_t)c + 6 * a + b] * scale[6 * c + b] * -step[6 * c + b];
   for (int l = tid; l < L; l += 256) { sg += lmPart[2 * (size_t)l]; sHs += lmPart[2 * (size_t)l + 1]; }
-  const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
-  const double tg = block_sum_fixed(sg, sm), th = block_sum_fixed(sHs, sm), tf = block_sum_fixed(fin, sm);
+  // the five sums through ONE tree (block_sum_fixed's association for each; five passes of it were 45 barriers)
+  __shared__ double sm5[5][256];
+  sm5[0][tid] = sn; sm5[1][tid] = xn; sm5[2][tid] = sg; sm5[3][tid] = sHs; sm5[4][tid] = fin;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) sm5[k][tid] += sm5[k][tid + s];
+    }
+    __syncthreads();
+  }
+  const double a = sm5[0][0], b = sm5[1][0], tg = sm5[2][0], th = sm5[3][0], tf = sm5[4][0];
   if (tid == 0) {
     if (tf > 0.0) st->finite = 0;
     st->model_change = -(tg + 0.5 * th);
