@@ -756,7 +756,6 @@ __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double
                                                       const double* __restrict__ scale, const unsigned char* __restrict__ active,
                                                       double* __restrict__ q, double* __restrict__ t, double* __restrict__ X,
                                                       double* __restrict__ part) {
-  __shared__ double sm[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   double sn = 0.0, xn = 0.0;
   if (i < K) {
@@ -783,8 +782,16 @@ __global__ __launch_bounds__(256) void k_lm_candidate(int K, int L, const double
       X[3 * l + k] = v;
     }
   }
-  const double a = block_sum_fixed(sn, sm), b = block_sum_fixed(xn, sm);
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+  // both sums through one tree (block_sum_fixed's association for each)
+  __shared__ double sm2[2][256];
+  const int tid = threadIdx.x;
+  sm2[0][tid] = sn; sm2[1][tid] = xn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { sm2[0][tid] += sm2[0][tid + s]; sm2[1][tid] += sm2[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { part[2 * blockIdx.x] = sm2[0][0]; part[2 * blockIdx.x + 1] = sm2[1][0]; }
 }
 
 // publish the status record to the host's pinned copy (read after the stream synchronises: no D2H copy command), and — last kernel of
@@ -874,11 +881,12 @@ __global__ __launch_bounds__(256) void k_lm_gmax(int K, int L, const double* __r
     for (int i = 0; i < 3; i++) m = fmax(m, fabs(g[6 * c + 3 + i]));
   }
   for (int l = tid; l < L; l += 256) if (active[6 * K + 3 * l]) for (int i = 0; i < 3; i++) m = fmax(m, fabs(g[6 * K + 3 * l + i]));
+  // max is exact in any order: wavefront shuffles, then the four wavefronts' values (was an eight-barrier tree)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) sm[tid >> 6] = m;
   __syncthreads();
-  sm[tid] = m;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if (tid < s) sm[tid] = fmax(sm[tid], sm[tid + s]); __syncthreads(); }
-  if (tid == 0) { st->gmax = sm[0]; st->x_cost = *cost; lm_publish(st, host); }
+  if (tid == 0) { st->gmax = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])); st->x_cost = *cost; lm_publish(st, host); }
 }
 
 __global__ void k_lm_reset(LmStatus* st) { st->ok = 1; st->finite = 1; st->model_change = 0; st->sn = 0; st->xn = 0; st->cand_cost = 0; st->seq = 0; st->accept = 0; }
