@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <chrono>
 #include <vector>
 #include "common.h"
 #include "orb_kernels.h"
@@ -113,6 +114,11 @@ struct dvs_orb {
   dvs_keypoint* h_kps = nullptr;   // pinned
   u8* h_desc = nullptr;
   int* h_nout = nullptr;
+  int* h_seq = nullptr;            // pinned: sequence number k_export_host publishes (dvs_orb_extract[_batch] poll it)
+  int* d_ticket = nullptr;         // ... its last-workgroup ticket
+  int export_seq = 0;
+  int env_host_poll = 1;           // DVS_HOST_POLL=0: three device-to-host copy commands and a stream wait instead
+  double host_t[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // DVS_HOST_TIMING=1: phases of the host entry point (diagnostics)
   size_t octree_smem = 0;
   int octree_nmax = 0, octree_ptscap = 0;
   int last_nimg = 0;
@@ -135,6 +141,9 @@ void free_workspace(dvs_orb* h) {
   if (h->h_kps) (void)hipHostFree(h->h_kps);
   if (h->h_desc) (void)hipHostFree(h->h_desc);
   if (h->h_nout) (void)hipHostFree(h->h_nout);
+  if (h->h_seq) (void)hipHostFree(h->h_seq);
+  if (h->d_ticket) (void)hipFree(h->d_ticket);
+  h->h_seq = nullptr; h->d_ticket = nullptr;
   h->d_blurcols = nullptr; h->d_blurtab = nullptr;
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
@@ -548,6 +557,12 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipHostMalloc((void**)&h->h_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
   DVS_HIP(hipHostMalloc((void**)&h->h_desc, B * (size_t)G.outCap * 32));
   DVS_HIP(hipHostMalloc((void**)&h->h_nout, B * 4));
+  if (!h->h_seq) {
+    DVS_HIP(hipHostMalloc((void**)&h->h_seq, 64));
+    *h->h_seq = 0; h->export_seq = 0;
+    DVS_HIP(hipMalloc((void**)&h->d_ticket, 4));
+    DVS_HIP(hipMemset(h->d_ticket, 0, 4));
+  }
   h->octree_nmax = G.maxN + 8;
   {
     int maxPts = 0;
@@ -945,6 +960,7 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1' ? 1 : 0;
   if (const char* e4 = getenv("DVS_FAST_TAIL")) h->env_fast_tail = atoi(e4);
   if (const char* e5 = getenv("DVS_FAST_V")) h->env_fast_v = atoi(e5);
+  if (const char* e5 = getenv("DVS_HOST_POLL")) h->env_host_poll = atoi(e5);
   // byte-aligned tile origin (probed once per process and device): every cell's interior then starts on a dword of the tile, so a
   // 36-pixel interior is always 9 column groups = 7 rows per trip of the rejection loop (aligned origin: 9 or 10 groups by the
   // cell's phase, 6 rows per trip for the latter).  FAST alone 0.295 -> 0.287 ms per 64 frames.  DVS_FAST_BYTE_DMA=0 turns it off.
@@ -1236,21 +1252,53 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
   for (int b0 = 0; b0 < nimg; b0 += h->max_batch) {
     const int nb = std::min(h->max_batch, nimg - b0);
     // level 0 staged into the frame's pyramid block (the reference copies it too: copyMakeBorder, :1189)
+    static const bool timing = getenv("DVS_HOST_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = timing ? now() : 0.0;
     for (int i = 0; i < nb; i++)
       DVS_HIP(hipMemcpy2DAsync(h->d_pyr + (uint64_t)i * G.frameBytes + G.lv[0].off, G.lv[0].pitch, imgs[b0 + i], step, cols, rows,
                                hipMemcpyHostToDevice, h->stream));
+    const double T1 = timing ? now() : 0.0;
     ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr, ~0u, 0};
     DVS_TRY(enqueue_extract(h, src, nb, h->d_kps, h->d_desc, cap, h->d_nout));
-    DVS_HIP(hipMemcpyAsync(h->h_nout, h->d_nout, nb * 4, hipMemcpyDeviceToHost, h->stream));
-    DVS_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nb * cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream));
-    DVS_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nb * cap * 32, hipMemcpyDeviceToHost, h->stream));
-    DVS_HIP(hipStreamSynchronize(h->stream));
+    const double T2 = timing ? now() : 0.0;
+    if (h->env_host_poll) {
+      // results by k_export_host into the pinned block; poll its sequence number (bounded spin, then the stream wait)
+      static_assert(sizeof(dvs_keypoint) == 28, "k_export_host copies keypoints as 7 dwords");
+      const int seq = ++h->export_seq;
+      hipLaunchKernelGGL(k_export_host, dim3(4, nb), dim3(256), 0, h->stream, nb, cap, (const uint32_t*)h->d_kps, (const uint32_t*)h->d_desc,
+                         h->d_nout, (uint32_t*)h->h_kps, (uint32_t*)h->h_desc, h->h_nout, h->d_ticket, h->h_seq, seq);
+      DVS_HIP(hipGetLastError());
+      const volatile int* ps = h->h_seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int spin = 1; *ps != seq; spin++) {
+        __builtin_ia32_pause();
+        if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (*ps != seq) DVS_HIP(hipStreamSynchronize(h->stream));
+    } else {
+      DVS_HIP(hipMemcpyAsync(h->h_nout, h->d_nout, nb * 4, hipMemcpyDeviceToHost, h->stream));
+      DVS_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nb * cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream));
+      DVS_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nb * cap * 32, hipMemcpyDeviceToHost, h->stream));
+      DVS_HIP(hipStreamSynchronize(h->stream));
+    }
+    const double T3 = timing ? now() : 0.0;
     for (int i = 0; i < nb; i++) {
       const int n = h->h_nout[i];
       if (n > capacity) { set_error("frame %d: %d keypoints > capacity %d", b0 + i, n, capacity); return DVS_ERR_CAPACITY; }
       n_out[b0 + i] = n;
       memcpy(kps + (size_t)(b0 + i) * capacity, h->h_kps + (size_t)i * cap, (size_t)n * sizeof(dvs_keypoint));
       memcpy(desc + (size_t)(b0 + i) * capacity * 32, h->h_desc + (size_t)i * cap * 32, (size_t)n * 32);
+    }
+    if (timing) {
+      const double T4 = now();
+      h->host_t[0] += T1 - T0; h->host_t[1] += T2 - T1; h->host_t[2] += T3 - T2; h->host_t[3] += T4 - T3;
+      if (++h->host_calls % 64 == 0) {
+        fprintf(stderr, "[dvs] host entry, mean of 64 calls: upload enqueue %.1f us, kernels enqueue %.1f us, results + wait %.1f us, copy out %.1f us\n",
+                h->host_t[0] / 64, h->host_t[1] / 64, h->host_t[2] / 64, h->host_t[3] / 64);
+        h->host_t[0] = h->host_t[1] = h->host_t[2] = h->host_t[3] = 0;
+      }
     }
   }
   return DVS_OK;

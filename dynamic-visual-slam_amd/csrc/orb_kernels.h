@@ -2199,4 +2199,35 @@ __global__ __launch_bounds__(256) void k_merge_levels(LevelBlockLayout Y, const 
   dd[0] = sd[0]; dd[1] = sd[1];
 }
 
+
+// =============================================================================================
+// Host entry points (dvs_orb_extract[_batch]): the frames' results leave through this kernel — it writes the n_out[f] keypoints and
+// descriptors of every frame (not the whole capacity) and the counts straight into the handle's pinned host block, and the LAST
+// workgroup to finish (ticket) publishes a sequence number behind a system-scope fence, which the host polls.  Replaces three
+// device-to-host copy commands and a stream wait per call.
+__global__ __launch_bounds__(256) void k_export_host(int nimg, int cap, const uint32_t* __restrict__ kps, const uint32_t* __restrict__ desc,
+                                                     const int* __restrict__ nout, uint32_t* __restrict__ hkps, uint32_t* __restrict__ hdesc,
+                                                     int* __restrict__ hnout, int* __restrict__ ticket, int* __restrict__ hseq, int seq) {
+  const int f = blockIdx.y;
+  const int n = min(nout[f], cap);
+  const uint32_t* ks = kps + (uint64_t)f * cap * 7;
+  const uint32_t* ds = desc + (uint64_t)f * cap * 8;
+  uint32_t* kd = hkps + (uint64_t)f * cap * 7;
+  uint32_t* dd = hdesc + (uint64_t)f * cap * 8;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * 7; i += gridDim.x * 256) kd[i] = ks[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * 8; i += gridDim.x * 256) dd[i] = ds[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) hnout[f] = nout[f];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = gridDim.x * gridDim.y;
+    if (atomicAdd(ticket, 1) == total - 1) {
+      *ticket = 0;
+      __threadfence_system();
+      *reinterpret_cast<volatile int*>(hseq) = seq;
+      __threadfence_system();
+    }
+  }
+}
+
 }  // namespace dvs
