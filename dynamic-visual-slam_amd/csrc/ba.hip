@@ -33,6 +33,10 @@ struct BaDev {
   const unsigned char *pose_fixed, *lm_fixed;
   double fx, fy, cx, cy, inv_sigma, huber_a;
   const int* gate;   // if set and *gate == 0 the evaluation launches do nothing (speculative launches of dvs_ba_solve_device)
+  // dvs_ba_solve_device, after an accepted step: acc_blocks extra workgroups of k_ba_eval store the evaluated point (q, t, X) as the
+  // point of the next iteration (was a launch of its own in front of the evaluation; neither writes what the other reads)
+  double *acc_q0, *acc_t0, *acc_X0;
+  int acc_blocks, acc_K, acc_L;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -246,6 +250,14 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
                                                  double* __restrict__ rawRes, double* __restrict__ rawJq,
                                                  double* __restrict__ rawJt, double* __restrict__ rawJX) {
   if (P.gate && !*P.gate) return;
+  const int nEval = (int)gridDim.x - P.acc_blocks;
+  if ((int)blockIdx.x >= nEval) {
+    const int i0 = ((int)blockIdx.x - nEval) * 256 + (int)threadIdx.x, stride = P.acc_blocks * 256;
+    for (int i = i0; i < 4 * P.acc_K; i += stride) P.acc_q0[i] = P.q[i];
+    for (int i = i0; i < 3 * P.acc_K; i += stride) P.acc_t0[i] = P.t[i];
+    for (int i = i0; i < 3 * P.acc_L; i += stride) P.acc_X0[i] = P.X[i];
+    return;
+  }
   ba_eval_body((int)blockIdx.x, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
 }
 
@@ -928,6 +940,7 @@ struct dvs_ba {
   dvs::LmStatus* h_status = nullptr;  // pinned
   double* h_out = nullptr;            // pinned staging of the solved parameters (q, t, X)
   const int* eval_gate = nullptr;     // see BaDev::gate
+  bool eval_accept = false;           // see BaDev::acc_*
   std::vector<double> trace;          // dvs_ba_get_trace: 6 doubles per trust-region iteration of the last solve
   void log(double radius, int kind, double dc, double dm, double rel, double cand) {
     const double row[6] = {radius, (double)kind, dc, dm, rel, cand};
@@ -968,6 +981,8 @@ BaDev dev_view(const dvs_ba* h) {
   P.pose_fixed = h->d_pf; P.lm_fixed = h->d_lf;
   P.fx = h->fx; P.fy = h->fy; P.cx = h->cx; P.cy = h->cy; P.inv_sigma = 1.0 / h->sigma; P.huber_a = h->huber;
   P.gate = h->eval_gate;
+  P.acc_blocks = 0; P.acc_K = h->K; P.acc_L = h->L; P.acc_q0 = P.acc_t0 = P.acc_X0 = nullptr;
+  if (h->eval_accept) { P.acc_blocks = std::max(1, (3 * h->L + 1023) / 1024); P.acc_q0 = h->d_q0; P.acc_t0 = h->d_t0; P.acc_X0 = h->d_X0; }
   return P;
 }
 
@@ -979,6 +994,9 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
   const int nReduce = h->lmBlocks + (h->K + 7) / 8;
   if (h->fused && h->d_gbar && std::max(h->nChunks, nReduce) <= 512) {
     const int nb = std::max(h->nChunks, nReduce);
+    if (h->eval_accept)   // the fused kernel has no copy workgroups
+      hipLaunchKernelGGL(k_lm_accept, dim3((std::max(4 * h->K, 3 * h->L) + 255) / 256), dim3(256), 0, h->stream, h->K, h->L, h->d_q, h->d_t, h->d_X,
+                         h->d_q0, h->d_t0, h->d_X0, h->eval_gate);
     h->gbar_total += (unsigned)nb;
     hipLaunchKernelGGL(k_ba_fused, dim3(nb), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, raw,
                        raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr, raw ? raw + 16 * (size_t)h->R : nullptr,
@@ -987,7 +1005,7 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }
-  hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
+  hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks + P.acc_blocks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
                      h->d_partial, raw, raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr,
                      raw ? raw + 16 * (size_t)h->R : nullptr);
   hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + (h->K + 7) / 8), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
@@ -1528,15 +1546,17 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     return DVS_OK;
   };
   // Jacobian blocks, gradient, cost of the point in the evaluation buffers; `gate`: only if the device's verdict says so
-  auto enqueue_full = [&](const int* gate) -> dvs_status {
-    h->eval_gate = gate;
+  // accept: the evaluation buffers hold a candidate that becomes the point of the next iteration (stored by extra workgroups of
+  // the evaluation kernel)
+  auto enqueue_full = [&](const int* gate, bool accept) -> dvs_status {
+    h->eval_gate = gate; h->eval_accept = accept;
     const dvs_status e = enqueue_eval(h, 1 | 2, true);
-    h->eval_gate = nullptr;
+    h->eval_gate = nullptr; h->eval_accept = false;
     DVS_TRY(e);
     hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, S, gate);
     return DVS_OK;
   };
-  auto evaluate_full = [&]() -> dvs_status { DVS_TRY(enqueue_full(nullptr)); return fetch_status(); };
+  auto evaluate_full = [&](bool accept) -> dvs_status { DVS_TRY(enqueue_full(nullptr, accept)); return fetch_status(); };
   // The launches that follow an accepted step (accept, full evaluation, gradient norm: ~27 us of host launch time) are enqueued right
   // behind the trial, gated on the verdict k_lm_norms leaves in the status record, so that they are ready when the trial ends; the
   // host takes the same decision from the same numbers and insists that the two agree.  Not with the fused evaluation (its grid
@@ -1544,7 +1564,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   const int* verdict = &h->d_status->accept;
   const bool speculate = !(h->fused && h->d_gbar) && !(getenv("DVS_LM_SPECULATE") && !atoi(getenv("DVS_LM_SPECULATE")));
   hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
-  DVS_TRY(evaluate_full());
+  DVS_TRY(evaluate_full(false));
   stamp("first eval");
   double x_cost = S->x_cost, gmax = S->gmax;
   summary->initial_cost = x_cost;
@@ -1576,10 +1596,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_TRY(enqueue_eval(h, 0, false));  // cost of the candidate
     hipLaunchKernelGGL(k_lm_norms, dim3(1), dim3(256), 0, st, nparts, h->d_normPart, h->d_cost, K, L, h->d_Hpp, h->d_g, h->d_scale, h->d_step,
                        h->d_lmPart, ptol, ftol, h->d_status, S);
-    if (speculate) {
-      hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, verdict);
-      DVS_TRY(enqueue_full(verdict));
-    }
+    if (speculate) DVS_TRY(enqueue_full(verdict, true));
     DVS_HIP(hipGetLastError());
     stamp("trial enqueued");
     DVS_TRY(fetch_status());
@@ -1608,8 +1625,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
       if (speculate) {
         DVS_TRY(fetch_status());         // the gated launches ran: wait for k_lm_gmax's record
       } else {
-        hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, nullptr);
-        DVS_TRY(evaluate_full());
+        DVS_TRY(evaluate_full(true));
       }
       x_cost = S->x_cost; gmax = S->gmax;
       summary->num_successful_steps++;
