@@ -452,27 +452,41 @@ __global__ void k_lm_scale(int K, int L, const double* __restrict__ Hpp, const d
   else if (j < 6 * K + 3 * L) { const int k = j - 6 * K, l = k / 3, a = k - 3 * l; scale[j] = 1.0 / (1.0 + sqrt(Hll[9 * (size_t)l + 4 * a])); }
 }
 
-// per landmark: LM diagonal (when refreshed), (V + D/radius)^-1, the scaled W blocks and Y = W V^-1; per camera: its diagonal
-__global__ __launch_bounds__(256) void k_lm_landmarks(int K, int L, const double* __restrict__ Hpp, const double* __restrict__ Hll,
-                                                      const double* __restrict__ W, const int* __restrict__ lmStart,
-                                                      const int* __restrict__ lmObs, const int* __restrict__ cam,
-                                                      const double* __restrict__ scale, double* __restrict__ diag,
-                                                      const unsigned char* __restrict__ active, double radius, int refresh,
-                                                      double* __restrict__ Vinv, double* __restrict__ Ws, double* __restrict__ Y,
-                                                      LmStatus* __restrict__ st) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= L) {
-    const int c = i - L;
-    if (c < K && refresh)
+// per observation: the Jacobi-scaled W block and Y = W V^-1 of its landmark — every observation inverts its landmark's 3 x 3 block
+// itself (the same arithmetic as k_lm_landmarks, ~60 flops) instead of waiting for a launch that does it once per landmark; the
+// landmark's first observation stores Vinv and the refreshed LM diagonal.  Threads R .. R + L + K - 1 refresh the diagonal of the
+// cameras and of the landmarks nobody observes.
+__global__ __launch_bounds__(256) void k_lm_observations(int K, int L, int R, const double* __restrict__ Hpp, const double* __restrict__ Hll,
+                                                         const double* __restrict__ W, const int* __restrict__ cam, const int* __restrict__ lm,
+                                                         const int* __restrict__ lmStart, const int* __restrict__ lmObs,
+                                                         const double* __restrict__ scale, double* __restrict__ diag,
+                                                         const unsigned char* __restrict__ active, double radius, int refresh,
+                                                         double* __restrict__ Vinv, double* __restrict__ Ws, double* __restrict__ Y,
+                                                         LmStatus* __restrict__ st) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= R) {
+    const int i = p - R;
+    if (!refresh) return;
+    if (i < L) {
+      if (lmStart[i + 1] == lmStart[i]) {
+        const int j0 = 6 * K + 3 * i;
+        for (int a = 0; a < 3; a++) diag[j0 + a] = clampd(Hll[9 * (size_t)i + 4 * a] * scale[j0 + a] * scale[j0 + a], 1e-6, 1e32);
+      }
+    } else if (i - L < K) {
+      const int c = i - L;
       for (int a = 0; a < 6; a++) { const int j = 6 * c + a; diag[j] = clampd(Hpp[36 * (size_t)c + 7 * a] * scale[j] * scale[j], 1e-6, 1e32); }
+    }
     return;
   }
-  const int l = i, j0 = 6 * K + 3 * l;
-  if (refresh) for (int a = 0; a < 3; a++) diag[j0 + a] = clampd(Hll[9 * (size_t)l + 4 * a] * scale[j0 + a] * scale[j0 + a], 1e-6, 1e32);
+  const int l = lm[p], c = cam[p], j0 = 6 * K + 3 * l;
+  const bool first = lmObs[lmStart[l]] == p;
+  double dg[3];
+  for (int a = 0; a < 3; a++) dg[a] = refresh ? clampd(Hll[9 * (size_t)l + 4 * a] * scale[j0 + a] * scale[j0 + a], 1e-6, 1e32) : diag[j0 + a];
+  if (first && refresh) for (int a = 0; a < 3; a++) diag[j0 + a] = dg[a];
   if (!active[j0]) return;
   double V[9];
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) V[3 * a + b] = Hll[9 * (size_t)l + 3 * a + b] * scale[j0 + a] * scale[j0 + b];
-  for (int a = 0; a < 3; a++) V[4 * a] += diag[j0 + a] / radius;
+  for (int a = 0; a < 3; a++) V[4 * a] += dg[a] / radius;
   const double a_ = V[0], b_ = V[1], c_ = V[2], d_ = V[3], e_ = V[4], f_ = V[5], g_ = V[6], h_ = V[7], i_ = V[8];
   const double det = a_ * (e_ * i_ - f_ * h_) - b_ * (d_ * i_ - f_ * g_) + c_ * (d_ * h_ - e_ * g_);
   if (det == 0 || !isfinite(det)) { st->ok = 0; return; }
@@ -481,21 +495,7 @@ __global__ __launch_bounds__(256) void k_lm_landmarks(int K, int L, const double
   Vi[0] = (e_ * i_ - f_ * h_) * id; Vi[1] = (c_ * h_ - b_ * i_) * id; Vi[2] = (b_ * f_ - c_ * e_) * id;
   Vi[3] = (f_ * g_ - d_ * i_) * id; Vi[4] = (a_ * i_ - c_ * g_) * id; Vi[5] = (c_ * d_ - a_ * f_) * id;
   Vi[6] = (d_ * h_ - e_ * g_) * id; Vi[7] = (b_ * g_ - a_ * h_) * id; Vi[8] = (a_ * e_ - b_ * d_) * id;
-  for (int k = 0; k < 9; k++) Vinv[9 * (size_t)l + k] = Vi[k];
-}
-
-// per observation: the Jacobi-scaled W block and Y = W V^-1 of its landmark (one thread per observation instead of a loop over
-// a landmark's observations inside k_lm_landmarks: 20 000 threads instead of 2 000)
-__global__ __launch_bounds__(256) void k_lm_observations(int K, int R, const double* __restrict__ W, const int* __restrict__ cam,
-                                                         const int* __restrict__ lm, const double* __restrict__ scale,
-                                                         const unsigned char* __restrict__ active, const double* __restrict__ Vinv,
-                                                         double* __restrict__ Ws, double* __restrict__ Y) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= R) return;
-  const int l = lm[p], c = cam[p], j0 = 6 * K + 3 * l;
-  if (!active[j0]) return;
-  double Vi[9];
-  for (int k = 0; k < 9; k++) Vi[k] = Vinv[9 * (size_t)l + k];
+  if (first) for (int k = 0; k < 9; k++) Vinv[9 * (size_t)l + k] = Vi[k];
   for (int a = 0; a < 6; a++) {
     double w[3];
     for (int b = 0; b < 3; b++) { w[b] = W[18 * (size_t)p + 3 * a + b] * scale[6 * c + a] * scale[j0 + b]; Ws[18 * (size_t)p + 3 * a + b] = w[b]; }
@@ -1581,10 +1581,9 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     if (gmax <= gtol) { summary->termination = 0; break; }
     if (radius < 1e-32) { summary->termination = 0; break; }
     iteration++;
-    hipLaunchKernelGGL(k_lm_landmarks, dim3((L + K + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_W, h->d_lmStart, h->d_lmObs,
-                       h->d_cam, h->d_scale, h->d_diag, h->d_active, radius, reuse_diagonal ? 0 : 1, h->d_Vinv, h->d_Ws, h->d_Y, h->d_status);
-    hipLaunchKernelGGL(k_lm_observations, dim3((R + 255) / 256), dim3(256), 0, st, K, R, h->d_W, h->d_cam, h->d_lm, h->d_scale, h->d_active, h->d_Vinv,
-                       h->d_Ws, h->d_Y);
+    hipLaunchKernelGGL(k_lm_observations, dim3((R + L + K + 255) / 256), dim3(256), 0, st, K, L, R, h->d_Hpp, h->d_Hll, h->d_W, h->d_cam, h->d_lm,
+                       h->d_lmStart, h->d_lmObs, h->d_scale, h->d_diag, h->d_active, radius, reuse_diagonal ? 0 : 1, h->d_Vinv, h->d_Ws, h->d_Y,
+                       h->d_status);
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc, kSchurSplit), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
