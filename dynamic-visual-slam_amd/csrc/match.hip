@@ -346,6 +346,10 @@ struct dvs_matcher {
   void* d_expand[2] = {nullptr, nullptr};  // +8 / -8 byte images of the descriptor sets for the matrix-core kernel (grow-only)
   size_t cexpand[2] = {0, 0};
   int use_mfma = 1;        // DVS_MATCH_MFMA=0 keeps every job on the popcount kernel
+  // pinned in / out block of the small host entry points (RANSAC stages): inputs are placed here and imported by a kernel, results
+  // are exported by a kernel that publishes a sequence number the host polls — no copy commands, no stream wait
+  void* h_io = nullptr; size_t cio = 0;
+  int* h_seq = nullptr; int io_seq = 0;
 };
 
 namespace {
@@ -400,6 +404,17 @@ dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out) {
   return DVS_OK;
 }
 hipStream_t matcher_stream(dvs_matcher* m) { return m->stream; }
+dvs_status matcher_pinned(dvs_matcher* m, size_t bytes, void** out, int** h_seq, int** counter) {
+  if (bytes > m->cio || !m->h_io) {
+    if (m->h_io) { DVS_HIP(hipStreamSynchronize(m->stream)); DVS_HIP(hipHostFree(m->h_io)); m->h_io = nullptr; m->cio = 0; }
+    const size_t cap = std::max<size_t>(bytes + bytes / 2, 65536);
+    DVS_HIP(hipHostMalloc(&m->h_io, cap));
+    m->cio = cap;
+  }
+  if (!m->h_seq) { DVS_HIP(hipHostMalloc((void**)&m->h_seq, 64)); *m->h_seq = 0; m->io_seq = 0; }
+  *out = m->h_io; *h_seq = m->h_seq; *counter = &m->io_seq;
+  return DVS_OK;
+}
 int matcher_device(dvs_matcher* m) { return m->device; }
 
 // every (query, train) pair with distance < max_dist as (q, t, dist) triplets in (q, t) order, LEFT ON THE DEVICE:
@@ -469,6 +484,8 @@ void dvs_matcher_destroy(dvs_matcher* m) {
   (void)hipStreamSynchronize(m->stream);
   void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero, m->d_expand[0], m->d_expand[1]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (m->h_io) (void)hipHostFree(m->h_io);
+  if (m->h_seq) (void)hipHostFree(m->h_seq);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
 }

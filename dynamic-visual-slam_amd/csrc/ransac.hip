@@ -20,12 +20,14 @@
 #include <float.h>
 #include <math.h>
 #include <string.h>
+#include <chrono>
 #include <vector>
 #include "common.h"
 
 namespace dvs {
 
 dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out);
+dvs_status matcher_pinned(dvs_matcher* m, size_t bytes, void** out, int** h_seq, int** counter);
 hipStream_t matcher_stream(dvs_matcher* m);
 int matcher_device(dvs_matcher* m);
 
@@ -595,6 +597,30 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
 
 using namespace dvs;
 
+// in / out of the host entry points without copy commands: inputs sit in the matcher's pinned block and k_io_import brings them to
+// the device; k_io_export (one workgroup) writes the contiguous result region back into the pinned block and publishes a sequence
+// number behind a system-scope fence, which the host polls (bounded spin, then the stream wait).
+__global__ __launch_bounds__(256) void k_io_import(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int ndw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ndw) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_io_export(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int ndw, int* __restrict__ hseq, int seq) {
+  for (int i = threadIdx.x; i < ndw; i += 256) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { *reinterpret_cast<volatile int*>(hseq) = seq; __threadfence_system(); }
+}
+static dvs_status io_wait(const volatile int* hseq, int seq, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 1; *hseq != seq; spin++) {
+    __builtin_ia32_pause();
+    if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (*hseq != seq) DVS_HIP(hipStreamSynchronize(st));
+  return DVS_OK;
+}
+
 extern "C" {
 
 // host-logic test hooks (no GPU): the product's quartic and P3P routines, compiled for the host
@@ -629,19 +655,25 @@ dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, cons
   int* d_sel = d_counts + H;                       // 4 ints
   double* d_Fb = (double*)(((uintptr_t)(d_sel + 4) + 15) & ~(uintptr_t)15);
   unsigned char* d_mask = (unsigned char*)(d_Fb + 9);
-  DVS_HIP(hipMemcpyAsync(d_p1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  DVS_HIP(hipMemcpyAsync(d_p2, pts2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  // pinned block: [pts1 | pts2] in, [sel (16) | Fb (72) | mask (n)] out — the device lays the results out the same way
+  const size_t outb = ((size_t)(16 + 72 + n) + 3) & ~(size_t)3;
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, 2 * pb + outb, (void**)&hio, &hseq, &counter));
+  memcpy(hio, pts1, (size_t)n * 8); memcpy(hio + pb, pts2, (size_t)n * 8);
+  const int ndw_in = (int)(2 * pb / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   hipLaunchKernelGGL(k_f_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_p1, d_p2, n, H, (unsigned long long)seed, d_F, d_valid);
   hipLaunchKernelGGL(k_f_score, dim3(H), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_valid, threshold * threshold, d_counts);
   hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, H, n, 8, confidence, 1, d_sel);
   hipLaunchKernelGGL(k_f_mask, dim3((std::max(n, 9) + 255) / 256), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_sel, threshold * threshold, d_mask, d_Fb);
+  if ((const uint8_t*)d_Fb - (const uint8_t*)d_sel != 16) { set_error("fundamental result layout"); return DVS_ERR_HIP; }
+  const int seq = ++*counter;
+  hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_sel, (uint32_t*)(hio + 2 * pb), (int)(outb / 4), hseq, seq);
   DVS_HIP(hipGetLastError());
-  int sel[4] = {0, 0, 0, 0};
-  DVS_HIP(hipMemcpyAsync(sel, d_sel, 12, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipMemcpyAsync(inlier_mask, d_mask, (size_t)n, hipMemcpyDeviceToHost, st));
+  DVS_TRY(io_wait(hseq, seq, st));
+  int sel[4];
   double Fb[9];
-  DVS_HIP(hipMemcpyAsync(Fb, d_Fb, 72, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipStreamSynchronize(st));
+  memcpy(sel, hio + 2 * pb, 16); memcpy(Fb, hio + 2 * pb + 16, 72); memcpy(inlier_mask, hio + 2 * pb + 88, (size_t)n);
   if (F9) memcpy(F9, Fb, 72);
   if (n_inliers) *n_inliers = sel[0] >= 0 ? sel[2] : 0;
   return DVS_OK;
@@ -669,21 +701,27 @@ dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const floa
   int* d_nin = d_sel + 4; int* d_succ = d_nin + 1;
   double* d_rt = (double*)(((uintptr_t)(d_succ + 1) + 15) & ~(uintptr_t)15);
   int* d_inl = (int*)(d_rt + 6);
-  DVS_HIP(hipMemcpyAsync(d_obj, pts3d, (size_t)n * 12, hipMemcpyHostToDevice, st));
-  DVS_HIP(hipMemcpyAsync(d_img, pts2d, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  // pinned block: [pts3d | pts2d] in, [nin, succ (8 + 8 pad) | rt (48) | inliers (4 n)] out — the device's own layout from d_nin on
+  const size_t outb = 16 + 48 + (size_t)n * 4;
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, ob + ib + outb, (void**)&hio, &hseq, &counter));
+  memcpy(hio, pts3d, (size_t)n * 12); memcpy(hio + ob, pts2d, (size_t)n * 8);
+  const int ndw_in = (int)((ob + ib) / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], thr2 = reproj_err * reproj_err;
   hipLaunchKernelGGL(k_p3p_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_obj, d_img, n, H, fx, fy, cx, cy, (unsigned long long)seed, d_poses, d_valid);
   hipLaunchKernelGGL(k_pnp_score, dim3(4 * H), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_valid, fx, fy, cx, cy, thr2, d_counts);
   hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, 4 * H, n, 3, confidence, 4, d_sel);
   hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_sel, fx, fy, cx, cy, thr2, d_inl, d_nin, d_rt, d_succ);
+  if ((const uint8_t*)d_rt - (const uint8_t*)d_nin != 16 || (const uint8_t*)d_inl - (const uint8_t*)d_rt != 48) { set_error("pnp result layout"); return DVS_ERR_HIP; }
+  const int seq = ++*counter;
+  hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_nin, (uint32_t*)(hio + ob + ib), (int)(outb / 4), hseq, seq);
   DVS_HIP(hipGetLastError());
+  DVS_TRY(io_wait(hseq, seq, st));
   int nin = 0, succ = 0;
   double rt[6];
-  DVS_HIP(hipMemcpyAsync(&nin, d_nin, 4, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipMemcpyAsync(&succ, d_succ, 4, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipMemcpyAsync(rt, d_rt, 48, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipStreamSynchronize(st));
-  if (inliers && nin > 0) DVS_HIP(hipMemcpy(inliers, d_inl, (size_t)nin * 4, hipMemcpyDeviceToHost));
+  memcpy(&nin, hio + ob + ib, 4); memcpy(&succ, hio + ob + ib + 4, 4); memcpy(rt, hio + ob + ib + 16, 48);
+  if (inliers && nin > 0) memcpy(inliers, hio + ob + ib + 64, (size_t)nin * 4);
   if (n_inliers) *n_inliers = nin;
   *success = succ;
   if (succ) { memcpy(rvec3, rt, 24); memcpy(tvec3, rt + 3, 24); }
