@@ -15,6 +15,7 @@
 #include <new>
 #include <vector>
 #include "common.h"
+#include "io_pinned.h"
 
 namespace dvs {
 
@@ -585,8 +586,19 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
   DVS_TRY(grow(&m->d_idx, &m->cidx, (size_t)nq * 8));
   int* d_idx = (int*)m->d_idx;
   int* d_dist = d_idx + nq;
-  DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-  if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+  // frame-sized sets go through the pinned block (import / export kernels, polled sequence number): no copy commands, no stream wait
+  const bool pinned_io = nq <= 16384 && nt <= 16384;
+  uint8_t* hio = nullptr; int *hseq = nullptr, *counter = nullptr;
+  if (pinned_io) {
+    DVS_TRY(matcher_pinned(m, (size_t)(nq + nt) * 32 + (size_t)nq * 8, (void**)&hio, &hseq, &counter));
+    memcpy(hio, q, (size_t)nq * 32);
+    if (nt) memcpy(hio + (size_t)nq * 32, t, (size_t)nt * 32);
+    hipLaunchKernelGGL(k_io_import, dim3((nq * 8 + 255) / 256), dim3(256), 0, m->stream, (const uint32_t*)hio, (uint32_t*)m->d_q, nq * 8);
+    if (nt) hipLaunchKernelGGL(k_io_import, dim3((nt * 8 + 255) / 256), dim3(256), 0, m->stream, (const uint32_t*)(hio + (size_t)nq * 32), (uint32_t*)m->d_t, nt * 8);
+  } else {
+    DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+  }
   if (nq <= 16384)
     hipLaunchKernelGGL((k_match<16, 1>), dim3((nq + 63) / 64, 1), dim3(1024), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
@@ -594,6 +606,15 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
     hipLaunchKernelGGL((k_match<8, 2>), dim3((nq + 127) / 128, 1), dim3(512), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
   DVS_HIP(hipGetLastError());
+  if (pinned_io) {
+    uint8_t* hout = hio + (size_t)(nq + nt) * 32;
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, m->stream, (const uint32_t*)d_idx, (uint32_t*)hout, nq * 2, hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, m->stream));
+    memcpy(train_idx, hout, (size_t)nq * 4); memcpy(dist, hout + (size_t)nq * 4, (size_t)nq * 4);
+    return DVS_OK;
+  }
   DVS_HIP(hipMemcpyAsync(train_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
   DVS_HIP(hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
   DVS_HIP(hipStreamSynchronize(m->stream));
