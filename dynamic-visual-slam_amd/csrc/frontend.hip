@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <vector>
 #include "common.h"
+#include "io_pinned.h"
 
 namespace dvs {
 
@@ -21,6 +22,7 @@ typedef unsigned long long u64;
 
 // scratch + stream access to the matcher handle (match.hip)
 dvs_status matcher_scratch(dvs_matcher* m, int slot, size_t bytes, void** out);
+dvs_status matcher_pinned(dvs_matcher* m, size_t bytes, void** out, int** h_seq, int** counter);
 hipStream_t matcher_stream(dvs_matcher* m);
 int matcher_device(dvs_matcher* m);
 // match.hip: candidate pairs (Hamming < max_dist) as (q, t, dist) triplets + per-query offsets, left on the device
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void k_filter_depth(const dvs_keypoint* __rest
                                                       const int* __restrict__ nArr, int nConst, int strideRows,
                                                       const uint16_t* __restrict__ depth, uint64_t dstep, uint64_t dfstride, int rows,
                                                       int cols, float dmin, float dmax, dvs_keypoint* __restrict__ okps,
-                                                      uint8_t* __restrict__ odesc, int* __restrict__ oindex, int* __restrict__ nOut) {
+                                                      uint8_t* __restrict__ odesc, int* __restrict__ oindex, int* __restrict__ nOut,
+                                                      int* __restrict__ hseq, int seq) {
   __shared__ int wsum[5];
   const int f = blockIdx.x, tid = threadIdx.x;
   const int n = nArr ? min(max(nArr[f], 0), strideRows) : nConst;  // a stale / corrupt count must not walk past the frame's block (as k_match)
@@ -109,6 +112,11 @@ __global__ __launch_bounds__(256) void k_filter_depth(const dvs_keypoint* __rest
     carry += tot;
   }
   if (tid == 0) nOut[f] = carry;
+  if (hseq) {   // host entry point (one workgroup, inputs and outputs in the pinned block): publish for the polling host
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { *reinterpret_cast<volatile int*>(hseq) = seq; __threadfence_system(); }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_filter_matches(const int* __restrict__ idx, const int* __restrict__ dist, const int* __restrict__ nArr,
@@ -378,7 +386,8 @@ dvs_status dvs_filter_depth_batch_device(dvs_matcher* ctx, const dvs_keypoint* d
   if (nframes == 0) return DVS_OK;
   DVS_HIP(hipSetDevice(matcher_device(ctx)));
   hipLaunchKernelGGL(k_filter_depth, dim3(nframes), dim3(256), 0, matcher_stream(ctx), d_kps, d_desc, d_n, 0, stride_rows, d_depth,
-                     (uint64_t)step_bytes, (uint64_t)frame_stride_bytes, rows, cols, min_depth, max_depth, d_out_kps, d_out_desc, d_out_index, d_n_out);
+                     (uint64_t)step_bytes, (uint64_t)frame_stride_bytes, rows, cols, min_depth, max_depth, d_out_kps, d_out_desc, d_out_index, d_n_out,
+                     (int*)nullptr, 0);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
@@ -392,26 +401,30 @@ dvs_status dvs_filter_depth(dvs_matcher* ctx, const dvs_keypoint* kps, const uin
   DVS_ARG(kps && out_kps && (!desc || out_desc));
   DVS_HIP(hipSetDevice(matcher_device(ctx)));
   hipStream_t st = matcher_stream(ctx);
-  const size_t kb = (size_t)n * sizeof(dvs_keypoint), db = (size_t)n * 32;
-  uint8_t* base;
-  DVS_TRY(matcher_scratch(ctx, 0, 2 * kb + 2 * db + (size_t)n * 4 + 16 + (size_t)rows * cols * 2, (void**)&base));
-  dvs_keypoint* d_k = (dvs_keypoint*)base; dvs_keypoint* d_ok = (dvs_keypoint*)(base + kb);
-  uint8_t* d_d = base + 2 * kb; uint8_t* d_od = d_d + db;
-  int* d_oi = (int*)(d_od + db); int* d_no = d_oi + n;
-  uint16_t* d_dep = (uint16_t*)(((uintptr_t)(d_no + 2) + 15) & ~(uintptr_t)15);
-  DVS_HIP(hipMemcpyAsync(d_k, kps, kb, hipMemcpyHostToDevice, st));
-  if (desc) DVS_HIP(hipMemcpyAsync(d_d, desc, db, hipMemcpyHostToDevice, st));
-  DVS_HIP(hipMemcpy2DAsync(d_dep, (size_t)cols * 2, depth, step_bytes, (size_t)cols * 2, rows, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_filter_depth, dim3(1), dim3(256), 0, st, d_k, desc ? d_d : nullptr, (const int*)nullptr, n, n, d_dep, (uint64_t)cols * 2,
-                     (uint64_t)0, rows, cols, min_depth, max_depth, d_ok, d_od, d_oi, d_no);
+  // Everything through the matcher's pinned block, read and written by the kernel itself over PCIe (each byte once; of the depth
+  // image only the n pixels under the keypoints): no copy commands, and the host polls the sequence number the kernel publishes.
+  const size_t kb = ((size_t)n * sizeof(dvs_keypoint) + 15) & ~(size_t)15, db = (size_t)n * 32, ib = ((size_t)n * 4 + 16 + 15) & ~(size_t)15;
+  const size_t zb = (size_t)rows * cols * 2;
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, 2 * kb + 2 * db + ib + zb, (void**)&hio, &hseq, &counter));
+  dvs_keypoint* p_k = (dvs_keypoint*)hio; dvs_keypoint* p_ok = (dvs_keypoint*)(hio + kb);
+  uint8_t* p_d = hio + 2 * kb; uint8_t* p_od = p_d + db;
+  int* p_oi = (int*)(p_od + db); int* p_no = p_oi + n;
+  uint16_t* p_dep = (uint16_t*)(hio + 2 * kb + 2 * db + ib);
+  memcpy(p_k, kps, (size_t)n * sizeof(dvs_keypoint));
+  if (desc) memcpy(p_d, desc, db);
+  if (step_bytes == (size_t)cols * 2) memcpy(p_dep, depth, zb);
+  else for (int r = 0; r < rows; r++) memcpy((uint8_t*)p_dep + (size_t)r * cols * 2, (const uint8_t*)depth + (size_t)r * step_bytes, (size_t)cols * 2);
+  const int seq = ++*counter;
+  hipLaunchKernelGGL(k_filter_depth, dim3(1), dim3(256), 0, st, p_k, desc ? p_d : nullptr, (const int*)nullptr, n, n, p_dep, (uint64_t)cols * 2,
+                     (uint64_t)0, rows, cols, min_depth, max_depth, p_ok, p_od, p_oi, p_no, hseq, seq);
   DVS_HIP(hipGetLastError());
-  int m = 0;
-  DVS_HIP(hipMemcpyAsync(&m, d_no, 4, hipMemcpyDeviceToHost, st));
-  DVS_HIP(hipStreamSynchronize(st));
+  DVS_TRY(io_wait(hseq, seq, st));
+  const int m = *p_no;
   if (m) {
-    DVS_HIP(hipMemcpy(out_kps, d_ok, (size_t)m * sizeof(dvs_keypoint), hipMemcpyDeviceToHost));
-    if (desc) DVS_HIP(hipMemcpy(out_desc, d_od, (size_t)m * 32, hipMemcpyDeviceToHost));
-    if (out_index) DVS_HIP(hipMemcpy(out_index, d_oi, (size_t)m * 4, hipMemcpyDeviceToHost));
+    memcpy(out_kps, p_ok, (size_t)m * sizeof(dvs_keypoint));
+    if (desc) memcpy(out_desc, p_od, (size_t)m * 32);
+    if (out_index) memcpy(out_index, p_oi, (size_t)m * 4);
   }
   *n_out = m;
   return DVS_OK;

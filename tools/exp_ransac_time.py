@@ -23,3 +23,19 @@ for name, fn in [("fundamental", lambda s: g.find_fundamental_ransac(p1, p2, 2.0
         t0 = time.perf_counter(); fn(s); ts.append(time.perf_counter() - t0)
     ts.sort()
     print(f"{name}: median {1e6 * ts[100]:.1f} us, p10 {1e6 * ts[20]:.1f}, p90 {1e6 * ts[180]:.1f}")
+
+# the per-frame glue entry points at the replay's sizes (640 x 480 depth, ~1000 keypoints)
+from dvslam_amd import synth
+gray = synth.make_traj_frame(3, 640, 480) if hasattr(synth, "make_traj_frame") else synth.make_frame(3, cols=640, rows=480)
+orb = dvslam_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+nk, k, d = orb(gray)
+depth = np.full((480, 640), 1500, np.uint16)
+for _ in range(5): g.filter_depth(k, d, depth)
+ts = []
+for s in range(200):
+    t0 = time.perf_counter(); g.filter_depth(k, d, depth); ts.append(time.perf_counter() - t0)
+ts.sort(); print(f"filter_depth ({nk} keypoints): median {1e6 * ts[100]:.1f} us")
+ts = []
+for s in range(200):
+    t0 = time.perf_counter(); orb(gray); ts.append(time.perf_counter() - t0)
+ts.sort(); print(f"extract 640x480/1000: median {1e6 * ts[100]:.1f} us")
