@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
                                                     const int* __restrict__ sel, double fx, double fy, double cx, double cy, double thr2,
                                                     int* __restrict__ inliers, int* __restrict__ nin, double* __restrict__ rt, int* __restrict__ success) {
   __shared__ double sm[256];
+  __shared__ double sm27[27][256];   // 54 KB: all normal-equation sums of an iteration in one reduction tree
   __shared__ double sR[9], st[3], sRn[9], stn[3], sH[36], sg[6], sd[6];
   __shared__ int s_cnt, s_wsum[5];
   __shared__ double s_lambda, s_cost;
@@ -510,13 +511,27 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
       }
     }
     {
-      int k = 0;
-      for (int a = 0; a < 6; a++)
-        for (int b = a; b < 6; b++) {
-          const double v = block_sum256(H[k++], sm);
-          if (tid == 0) { sH[6 * a + b] = v; sH[6 * b + a] = v; }
+      // the 27 sums through ONE tree (block_sum256's association for each, so the same bits; 27 passes of it were ~250 barriers per
+      // iteration and most of this kernel's 165 us)
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 21; k++) sm27[k][tid] = H[k];
+#pragma unroll
+      for (int a = 0; a < 6; a++) sm27[21 + a][tid] = g[a];
+      __syncthreads();
+      for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) {
+#pragma unroll
+          for (int k = 0; k < 27; k++) sm27[k][tid] += sm27[k][tid + sft];
         }
-      for (int a = 0; a < 6; a++) { const double v = block_sum256(g[a], sm); if (tid == 0) sg[a] = v; }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        int k = 0;
+        for (int a = 0; a < 6; a++)
+          for (int b = a; b < 6; b++) { const double v = sm27[k++][0]; sH[6 * a + b] = v; sH[6 * b + a] = v; }
+        for (int a = 0; a < 6; a++) sg[a] = sm27[21 + a][0];
+      }
     }
     __syncthreads();
     bool accepted = false;
