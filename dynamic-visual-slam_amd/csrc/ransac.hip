@@ -107,32 +107,74 @@ __global__ __launch_bounds__(64) void k_f_hypotheses(const float* __restrict__ p
     const double u1 = (x1[i] - c1x) * s1, v1 = (y1[i] - c1y) * s1, u2 = (x2[i] - c2x) * s2, v2 = (y2[i] - c2y) * s2;
     A[i][0] = u2 * u1; A[i][1] = u2 * v1; A[i][2] = u2; A[i][3] = v2 * u1; A[i][4] = v2 * v1; A[i][5] = v2; A[i][6] = u1; A[i][7] = v1; A[i][8] = 1.0;
   }
-  // null vector of the 8 x 9 system by Gauss-Jordan elimination with complete pivoting; the column never chosen is the free one
+  // null vector of the 8 x 9 system by Gauss-Jordan elimination with complete pivoting; the column never chosen is the free one.
+  // Every loop is unrolled and the run-time row / column (pivot position) is applied by selects, so that the 72 matrix entries stay
+  // in registers: indexed with run-time subscripts the array lived in scratch memory and this kernel took 102 us.  Same operations
+  // in the same order on the same values.
   int colOf[8];
-  bool used[9] = {false, false, false, false, false, false, false, false, false};
-  for (int k = 0; k < 8 && ok; k++) {
-    int pr = k, pc = -1;
-    double best = 0;
-    for (int i = k; i < 8; i++)
-      for (int j = 0; j < 9; j++)
-        if (!used[j] && fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
-    if (pc < 0 || best < 1e-12) { ok = false; break; }
-    for (int j = 0; j < 9; j++) { const double tmp = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = tmp; }
-    used[pc] = true; colOf[k] = pc;
-    const double inv = 1.0 / A[k][pc];
-    for (int j = 0; j < 9; j++) A[k][j] *= inv;
-    for (int i = 0; i < 8; i++)
-      if (i != k) {
-        const double f = A[i][pc];
-        if (f != 0.0) for (int j = 0; j < 9; j++) A[i][j] -= f * A[k][j];
+  unsigned usedMask = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (ok) {
+      int pr = k, pc = -1;
+      double best = 0;
+#pragma unroll
+      for (int i = k; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const double a = fabs(A[i][j]);
+          const bool take = !((usedMask >> j) & 1u) && a > best;
+          best = take ? a : best; pr = take ? i : pr; pc = take ? j : pc;
+        }
+      if (pc < 0 || best < 1e-12) {
+        ok = false;
+      } else {
+        // rows k and pr change places
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const double tmp = A[k][j];
+          double apr = tmp;
+#pragma unroll
+          for (int i = k + 1; i < 8; i++) apr = i == pr ? A[i][j] : apr;
+          A[k][j] = apr;
+#pragma unroll
+          for (int i = k + 1; i < 8; i++) A[i][j] = i == pr ? tmp : A[i][j];
+        }
+        usedMask |= 1u << pc; colOf[k] = pc;
+        double piv = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) piv = j == pc ? A[k][j] : piv;
+        const double inv = 1.0 / piv;
+#pragma unroll
+        for (int j = 0; j < 9; j++) A[k][j] *= inv;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (i != k) {
+            double fcoef = 0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) fcoef = j == pc ? A[i][j] : fcoef;
+            const bool nz = fcoef != 0.0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) A[i][j] = nz ? A[i][j] - fcoef * A[k][j] : A[i][j];
+          }
       }
+    }
   }
   double f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (ok) {
     int fc = 0;
-    for (int j = 0; j < 9; j++) if (!used[j]) fc = j;
-    f[fc] = 1.0;
-    for (int k = 0; k < 8; k++) f[colOf[k]] = -A[k][fc];
+#pragma unroll
+    for (int j = 0; j < 9; j++) if (!((usedMask >> j) & 1u)) fc = j;
+#pragma unroll
+    for (int j = 0; j < 9; j++) f[j] = j == fc ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      double afc = 0;
+#pragma unroll
+      for (int j = 0; j < 9; j++) afc = j == fc ? A[k][j] : afc;
+#pragma unroll
+      for (int j = 0; j < 9; j++) f[j] = j == colOf[k] ? -afc : f[j];
+    }
     // rank 2: F <- F - (F v) v^T with v the right singular vector of the smallest singular value
     double S[9];
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[3 * a + b] = f[a] * f[b] + f[3 + a] * f[3 + b] + f[6 + a] * f[6 + b];
