@@ -579,25 +579,50 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
     bool accepted = false;
     for (int tries = 0; tries < 8 && !accepted; tries++) {
       if (tid == 0) {  // (H + lambda diag(H)) d = -g by Cholesky
+        // every loop unrolled: with run-time subscripts the 6 x 6 system lived in scratch memory (one thread, ~100 dependent
+        // scratch round trips per solve)
         double A[36], b6[6];
+#pragma unroll
         for (int k = 0; k < 36; k++) A[k] = sH[k];
+#pragma unroll
         for (int a = 0; a < 6; a++) { A[7 * a] += s_lambda * fmax(sH[7 * a], 1e-12); b6[a] = -sg[a]; }
         bool ok = true;
-        for (int jx = 0; jx < 6 && ok; jx++) {
-          double d = A[7 * jx];
-          for (int k = 0; k < jx; k++) d -= A[6 * jx + k] * A[6 * jx + k];
-          if (!(d > 0)) { ok = false; break; }
-          d = sqrt(d);
-          A[7 * jx] = d;
-          for (int i = jx + 1; i < 6; i++) {
-            double sacc = A[6 * i + jx];
-            for (int k = 0; k < jx; k++) sacc -= A[6 * i + k] * A[6 * jx + k];
-            A[6 * i + jx] = sacc / d;
+#pragma unroll
+        for (int jx = 0; jx < 6; jx++) {
+          if (ok) {
+            double d = A[7 * jx];
+#pragma unroll
+            for (int k = 0; k < jx; k++) d -= A[6 * jx + k] * A[6 * jx + k];
+            if (!(d > 0)) {
+              ok = false;
+            } else {
+              d = sqrt(d);
+              A[7 * jx] = d;
+#pragma unroll
+              for (int i = jx + 1; i < 6; i++) {
+                double sacc = A[6 * i + jx];
+#pragma unroll
+                for (int k = 0; k < jx; k++) sacc -= A[6 * i + k] * A[6 * jx + k];
+                A[6 * i + jx] = sacc / d;
+              }
+            }
           }
         }
         if (ok) {
-          for (int i = 0; i < 6; i++) { double sacc = b6[i]; for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * b6[k]; b6[i] = sacc / A[7 * i]; }
-          for (int i = 5; i >= 0; i--) { double sacc = b6[i]; for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * b6[k]; b6[i] = sacc / A[7 * i]; }
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            double sacc = b6[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * b6[k];
+            b6[i] = sacc / A[7 * i];
+          }
+#pragma unroll
+          for (int i = 5; i >= 0; i--) {
+            double sacc = b6[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * b6[k];
+            b6[i] = sacc / A[7 * i];
+          }
           double E[9];
           exp_so3(b6, E);
           for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sRn[3 * a + b] = E[3 * a] * sR[b] + E[3 * a + 1] * sR[3 + b] + E[3 * a + 2] * sR[6 + b];
