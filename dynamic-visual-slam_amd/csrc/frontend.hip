@@ -85,31 +85,55 @@ __global__ __launch_bounds__(256) void k_filter_depth(const dvs_keypoint* __rest
   const int n = nArr ? min(max(nArr[f], 0), strideRows) : nConst;  // a stale / corrupt count must not walk past the frame's block (as k_match)
   const dvs_keypoint* kp = kps + (size_t)f * strideRows;
   const uint8_t* dp = (const uint8_t*)depth + (uint64_t)f * dfstride;
+  // Four chunks of 256 keypoints per trip with their loads in flight together — keypoints, then the depth pixels, then the
+  // descriptors: through the host entry point every load is a PCIe round trip, and one chunk at a time made twelve of them per
+  // thousand keypoints where three suffice.  The compaction order is unchanged.
   int carry = 0;
-  for (int b = 0; b < n; b += 256) {
-    const int i = b + tid;
-    bool keep = false;
-    dvs_keypoint k;
-    if (i < n) {
-      k = kp[i];
-      const int x = round_half_away(k.x), y = round_half_away(k.y);
-      if (x >= 0 && y >= 0 && x < cols && y < rows) {
-        const float d = __fmul_rn((float)*(const uint16_t*)(dp + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
-        keep = !(d < dmin || d > dmax);
+  for (int b = 0; b < n; b += 1024) {
+    dvs_keypoint k[4];
+    bool keep[4];
+    uint4 d0[4], d1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = b + 256 * u + tid;
+      if (i < n) k[u] = kp[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = b + 256 * u + tid;
+      keep[u] = false;
+      if (i < n) {
+        const int x = round_half_away(k[u].x), y = round_half_away(k[u].y);
+        if (x >= 0 && y >= 0 && x < cols && y < rows) {
+          const float d = __fmul_rn((float)*(const uint16_t*)(dp + (uint64_t)y * dstep + 2 * (uint64_t)x), 0.001f);
+          keep[u] = !(d < dmin || d > dmax);
+        }
       }
     }
-    int tot;
-    const int pos = carry + blk_excl_scan(keep ? 1 : 0, wsum, tot);
-    if (keep) {
-      okps[(size_t)f * strideRows + pos] = k;
-      if (oindex) oindex[(size_t)f * strideRows + pos] = i;
-      if (desc) {
-        const uint4* sd = reinterpret_cast<const uint4*>(desc + ((size_t)f * strideRows + i) * 32);
-        uint4* dd = reinterpret_cast<uint4*>(odesc + ((size_t)f * strideRows + pos) * 32);
-        dd[0] = sd[0]; dd[1] = sd[1];
-      }
+    if (desc) {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (keep[u]) {
+          const uint4* sd = reinterpret_cast<const uint4*>(desc + ((size_t)f * strideRows + b + 256 * u + tid) * 32);
+          d0[u] = sd[0]; d1[u] = sd[1];
+        }
     }
-    carry += tot;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (b + 256 * u >= n) break;
+      const int i = b + 256 * u + tid;
+      int tot;
+      const int pos = carry + blk_excl_scan(keep[u] ? 1 : 0, wsum, tot);
+      if (keep[u]) {
+        okps[(size_t)f * strideRows + pos] = k[u];
+        if (oindex) oindex[(size_t)f * strideRows + pos] = i;
+        if (desc) {
+          uint4* dd = reinterpret_cast<uint4*>(odesc + ((size_t)f * strideRows + pos) * 32);
+          dd[0] = d0[u]; dd[1] = d1[u];
+        }
+      }
+      carry += tot;
+    }
   }
   if (tid == 0) nOut[f] = carry;
   if (hseq) {   // host entry point (one workgroup, inputs and outputs in the pinned block): publish for the polling host
