@@ -730,11 +730,40 @@ __global__ __launch_bounds__(256) void k_lm_backsub(int K, int L, const double* 
   const bool act = active[j0] != 0;
   const int e0 = lmStart[lc], e1 = lmStart[lc + 1];
   double bm = g[j0 + mc] * scale[j0 + mc];
-  if (act)
+  // A landmark's observations are a chain of dependent loads (slot -> camera -> 6 W entries and 6 step entries), twice.  For up to 16
+  // observations the slots and cameras are fetched up front and the data in groups of four observations with all 48 loads in flight;
+  // the sums keep their order.  More observations than that take the plain loops.
+  const int nobs = e1 - e0;
+  const bool quick = nobs <= 16;
+  int pp[16], cc[16];
+  if (act && quick) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) pp[u] = u < nobs ? lmObs[e0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 16; u++) cc[u] = pp[u] >= 0 ? cam[pp[u]] : 0;
+#pragma unroll
+    for (int u0 = 0; u0 < 16; u0 += 4) {
+      if (u0 >= nobs) break;
+      double wv[4][6], sv[4][6];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (pp[u0 + u] >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) { wv[u][a] = Ws[18 * (size_t)pp[u0 + u] + 3 * a + mc]; sv[u][a] = step[6 * cc[u0 + u] + a]; }
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (pp[u0 + u] >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) bm -= wv[u][a] * sv[u][a];
+        }
+    }
+  } else if (act) {
     for (int e = e0; e < e1; e++) {
       const int p = lmObs[e], c = cam[p];
       for (int a = 0; a < 6; a++) bm -= Ws[18 * (size_t)p + 3 * a + mc] * step[6 * c + a];
     }
+  }
   const int base = (int)(threadIdx.x & 63) & ~3;
   const double b0 = __shfl(bm, base), b1 = __shfl(bm, base + 1), b2 = __shfl(bm, base + 2);
   const double* Vi = Vinv + 9 * (size_t)lc;
@@ -748,11 +777,33 @@ __global__ __launch_bounds__(256) void k_lm_backsub(int K, int L, const double* 
     sg = slm * g[j0 + mc] * scale[j0 + mc];
     sHs = slm * scale[j0 + mc] * (Hll[9 * (size_t)lc + 3 * mc] * scale[j0] * s0 + Hll[9 * (size_t)lc + 3 * mc + 1] * scale[j0 + 1] * s1 +
                                   Hll[9 * (size_t)lc + 3 * mc + 2] * scale[j0 + 2] * s2);
-    for (int e = e0; e < e1; e++) {  // with the NEGATED camera step
-      const int p = lmObs[e], c = cam[p];
-      double w = 0.0;
-      for (int a = 0; a < 6; a++) w += (-step[6 * c + a]) * Ws[18 * (size_t)p + 3 * a + mc];
-      sHs += 2.0 * w * slm;
+    if (quick) {   // with the NEGATED camera step
+#pragma unroll
+      for (int u0 = 0; u0 < 16; u0 += 4) {
+        if (u0 >= nobs) break;
+        double wv[4][6], sv[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (pp[u0 + u] >= 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) { wv[u][a] = Ws[18 * (size_t)pp[u0 + u] + 3 * a + mc]; sv[u][a] = step[6 * cc[u0 + u] + a]; }
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (pp[u0 + u] >= 0) {
+            double w = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) w += (-sv[u][a]) * wv[u][a];
+            sHs += 2.0 * w * slm;
+          }
+      }
+    } else {
+      for (int e = e0; e < e1; e++) {
+        const int p = lmObs[e], c = cam[p];
+        double w = 0.0;
+        for (int a = 0; a < 6; a++) w += (-step[6 * c + a]) * Ws[18 * (size_t)p + 3 * a + mc];
+        sHs += 2.0 * w * slm;
+      }
     }
   }
   if (m == 3) { sg = 0.0; sHs = 0.0; }
