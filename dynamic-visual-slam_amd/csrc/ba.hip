@@ -1549,7 +1549,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
       DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
       DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
       DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
-      DVS_HIP(hipHostMalloc((void**)&h->h_status, sizeof(LmStatus)));
+      DVS_HIP(hipHostMalloc((void**)&h->h_status, 2 * sizeof(LmStatus)));   // [0]: the trial's record (k_lm_norms), [1]: the point's (k_lm_gmax)
       DVS_HIP(hipHostMalloc((void**)&h->h_out, ((size_t)7 * std::max(K, 1) + 3 * (size_t)std::max(L, 1)) * 8));
       DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
     }
@@ -1574,16 +1574,19 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   stamp("params");
   const dim3 copyGrid((std::max(4 * K, 3 * L) + 255) / 256);   // one launch instead of three copy commands
   hipLaunchKernelGGL(k_lm_accept, copyGrid, dim3(256), 0, st, K, L, h->d_q, h->d_t, h->d_X, h->d_q0, h->d_t0, h->d_X0, nullptr);
+  // two host records: the gated k_lm_gmax of an accepted step runs while the host may still be reading the trial's numbers, so it
+  // must not publish over them
   LmStatus* S = h->h_status;
+  LmStatus* SP = h->h_status + 1;
   // the last kernel enqueued wrote the record into the pinned host copy (lm_publish): poll its sequence number — a bounded spin,
   // then the stream wait — instead of sleeping in hipStreamSynchronize (a wake-up per trial step and per accepted step)
   int expect_seq = 0;
-  S->seq = 0;
+  S->seq = 0; SP->seq = 0;
   static const bool poll = !(getenv("DVS_LM_POLL") && !atoi(getenv("DVS_LM_POLL")));
-  auto fetch_status = [&]() -> dvs_status {
+  auto fetch_status = [&](const LmStatus* rec) -> dvs_status {
     expect_seq++;
     if (poll) {
-      const volatile int* seq = &S->seq;
+      const volatile int* seq = &rec->seq;
       const auto t0 = std::chrono::steady_clock::now();
       for (int spin = 1; *seq != expect_seq; spin++) {
         __builtin_ia32_pause();
@@ -1604,10 +1607,10 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     const dvs_status e = enqueue_eval(h, 1 | 2, true);
     h->eval_gate = nullptr; h->eval_accept = false;
     DVS_TRY(e);
-    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, S, gate);
+    hipLaunchKernelGGL(k_lm_gmax, dim3(1), dim3(256), 0, st, K, L, h->d_q0, h->d_g, h->d_active, h->d_cost, h->d_status, SP, gate);
     return DVS_OK;
   };
-  auto evaluate_full = [&](bool accept) -> dvs_status { DVS_TRY(enqueue_full(nullptr, accept)); return fetch_status(); };
+  auto evaluate_full = [&](bool accept) -> dvs_status { DVS_TRY(enqueue_full(nullptr, accept)); return fetch_status(SP); };
   // The launches that follow an accepted step (accept, full evaluation, gradient norm: ~27 us of host launch time) are enqueued right
   // behind the trial, gated on the verdict k_lm_norms leaves in the status record, so that they are ready when the trial ends; the
   // host takes the same decision from the same numbers and insists that the two agree.  Not with the fused evaluation (its grid
@@ -1617,7 +1620,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, h->d_status);
   DVS_TRY(evaluate_full(false));
   stamp("first eval");
-  double x_cost = S->x_cost, gmax = S->gmax;
+  double x_cost = SP->x_cost, gmax = SP->gmax;
   summary->initial_cost = x_cost;
   double min_cost = x_cost;
   hipLaunchKernelGGL(k_lm_scale, dim3((NT + 255) / 256), dim3(256), 0, st, K, L, h->d_Hpp, h->d_Hll, h->d_scale);
@@ -1649,7 +1652,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     if (speculate) DVS_TRY(enqueue_full(verdict, true));
     DVS_HIP(hipGetLastError());
     stamp("trial enqueued");
-    DVS_TRY(fetch_status());
+    DVS_TRY(fetch_status(S));
     stamp("trial done");
     const bool valid = S->ok && S->finite && S->model_change > 0.0;
     const int dev_verdict = S->accept;
@@ -1673,11 +1676,11 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     DVS_TRY(agree(rel > 1e-3 ? 1 : 0));
     if (rel > 1e-3) {
       if (speculate) {
-        DVS_TRY(fetch_status());         // the gated launches ran: wait for k_lm_gmax's record
+        DVS_TRY(fetch_status(SP));       // the gated launches ran: wait for k_lm_gmax's record
       } else {
         DVS_TRY(evaluate_full(true));
       }
-      x_cost = S->x_cost; gmax = S->gmax;
+      x_cost = SP->x_cost; gmax = SP->gmax;
       summary->num_successful_steps++;
       min_cost = std::min(min_cost, x_cost);
       radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
