@@ -1582,7 +1582,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   // then the stream wait — instead of sleeping in hipStreamSynchronize (a wake-up per trial step and per accepted step)
   int expect_seq = 0;
   S->seq = 0; SP->seq = 0;
-  static const bool poll = !(getenv("DVS_LM_POLL") && !atoi(getenv("DVS_LM_POLL")));
+  const bool poll = !(getenv("DVS_LM_POLL") && !atoi(getenv("DVS_LM_POLL")));
   auto fetch_status = [&](const LmStatus* rec) -> dvs_status {
     expect_seq++;
     if (poll) {

@@ -232,3 +232,31 @@ def test_one_launch_evaluation_with_grid_barrier_is_identical(gpu):
     assert a[:4] == b[:4]
     for x, y in zip(a[4:], b[4:]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("env", [{"DVS_LM_POLL": "0"}, {"DVS_LM_SPECULATE": "0"}, {"DVS_LM_POLL": "0", "DVS_LM_SPECULATE": "0"}])
+def test_lm_host_loop_variants_are_identical(gpu, env):
+    """dvs_ba_solve_device polls the status record its kernels publish and enqueues the launches of an accepted step behind the
+    trial, gated on the verdict computed on the device; with either switched off (stream waits / launches after the host's decision)
+    the run — every iteration's radius, decision and costs, the summary and the solved parameters — must be the same bit for bit,
+    also through rejected steps"""
+    import ba_bracket as bb
+    from dvslam_amd import BAProblem
+    for prob in (synth.make_ba_problem(K=10, L=2000, seed=42), synth.make_ba_problem(**bb.HARD[0])):
+        a = BAProblem(prob); sa = a.solve_device(30)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            b = BAProblem(prob); sb = b.solve_device(30)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert (sa.num_iterations, sa.num_successful_steps, sa.termination) == (sb.num_iterations, sb.num_successful_steps, sb.termination)
+        assert sa.final_cost == sb.final_cost and sa.initial_cost == sb.initial_cost
+        ta, tb = a.trace(), b.trace()
+        assert ta.shape == tb.shape and (ta.view(np.uint64) == tb.view(np.uint64)).all()
+        for x, y in zip(a.parameters(), b.parameters()):
+            assert (np.asarray(x).view(np.uint64) == np.asarray(y).view(np.uint64)).all()

@@ -378,11 +378,13 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
     _lib.stream_destroy(mstream)
 
 
-@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_GRAPH": "1"}])
+@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_GRAPH": "1"},
+                                 {"DVS_HOST_POLL": "0"}])
 @pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 500, 8), (720, 1280, 2000, 8), (360, 1000, 700, 6), (250, 332, 200, 4), (200, 136, 150, 3)])
 def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, nf, nl):
     """the matrix-core blur (k_blur_mfma: int8 band products, LDS-staged) and the dword-aligned FAST tile origin (the default is the
-    byte-aligned one where the LDS-DMA probe passes) and the captured-graph replay of single-frame calls are selected at
+    byte-aligned one where the LDS-DMA probe passes), the captured-graph replay of single-frame calls and the copy-command
+    result path of the host entry points (the default is k_export_host + a polled sequence number) are selected at
     handle creation (environment); all must reproduce the oracle bit for bit — blurred levels, candidates and the final result —
     including widths that are not a multiple of the 32-column strips / 128-column super-strips and rows not a multiple of 32"""
     old = {k: os.environ.get(k) for k in env}
