@@ -424,12 +424,9 @@ __global__ __launch_bounds__(64) void k_p3p_hypotheses(const float* __restrict__
     const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
     j[i][0] = bx * nn; j[i][1] = by * nn; j[i][2] = nn;
   }
-  double sol[48];
-  const int nsol = p3p_solve(P, j, sol);
-  for (int s = 0; s < 4; s++) {
-    valid[4 * h + s] = s < nsol ? 1 : 0;
-    if (s < nsol) for (int k = 0; k < 12; k++) poses[12 * ((size_t)4 * h + s) + k] = sol[12 * s + k];
-  }
+  // the solutions go straight to their slots (a local array indexed by the running solution count lived in scratch memory)
+  const int nsol = p3p_solve(P, j, poses + 12 * ((size_t)4 * h));
+  for (int s = 0; s < 4; s++) valid[4 * h + s] = s < nsol ? 1 : 0;
 }
 
 __device__ __forceinline__ double reproj_err2(const double* R, const double* t, double fx, double fy, double cx, double cy, const float* X, const float* uv) {
