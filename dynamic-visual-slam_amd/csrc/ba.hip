@@ -83,6 +83,7 @@ __device__ __forceinline__ void ba_eval_body(const int bid, BaDev P, const BaChu
     const double py = (jets ? (P.fy * pc1) * iz : P.fy * pc1 / pc2) + P.cy;
     r[0] = P.inv_sigma * (px - P.uv[2 * p]);
     r[1] = P.inv_sigma * (py - P.uv[2 * p + 1]);
+    if (jets) {   // a cost-only evaluation (a trust-region candidate) needs none of the derivatives
     // d r / d p_c
     const double a00 = P.inv_sigma * P.fx * iz, a02 = -P.inv_sigma * P.fx * pc0 * iz * iz;
     const double a11 = P.inv_sigma * P.fy * iz, a12 = -P.inv_sigma * P.fy * pc1 * iz * iz;
@@ -119,6 +120,7 @@ __device__ __forceinline__ void ba_eval_body(const int bid, BaDev P, const BaChu
       jq[j] = a00 * Dq[0][j] + a02 * Dq[2][j];
       jq[4 + j] = a11 * Dq[1][j] + a12 * Dq[2][j];
     }
+    }
   }
   if (act && (flags & 4)) {
     if (rawRes) { rawRes[2 * p] = r[0]; rawRes[2 * p + 1] = r[1]; }
@@ -145,6 +147,17 @@ __device__ __forceinline__ void ba_eval_body(const int bid, BaDev P, const BaChu
     const double rr = sqrt(sq);
     rho0 = 2.0 * P.huber_a * rr - b;
     rho1 = fmax(DBL_MIN, P.huber_a / rr);
+  }
+  if (flags == 0) {
+    // cost only: one value through the reduction below instead of 28 — the same association as the butterfly's (pairwise by lane
+    // bits 5 .. 0, then the four wavefronts in order), so the same bits
+    double cst = act ? 0.5 * rho0 : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cst += __shfl_xor(cst, o);
+    if ((tid & 63) == 0) wred[tid >> 6][27] = cst;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)bid * 28 + 27] = ((wred[0][27] + wred[1][27]) + wred[2][27]) + wred[3][27];
+    return;
   }
   const double sc = sqrt(rho1);
   r[0] *= sc; r[1] *= sc;
