@@ -8,6 +8,9 @@
 // carries an RCCL (PyTorch bundles one under the same SONAME librccl.so.1) shares that copy instead of loading a second.
 #include <dlfcn.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include "common.h"
 
@@ -70,17 +73,86 @@ __global__ void __launch_bounds__(256) k_pack_boundary(const uint4* __restrict__
   else if (i < blk16) block[i] = i == rows16 ? make_uint4((uint32_t)n[0], 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Loopback group (dvs_comm_create_loopback): `world` logical ranks of ONE process on ONE device, each driven by its own host thread
+// with its own streams.  The all-gather keeps the collective's contract — every rank contributes one block and receives all — with a
+// host rendezvous in place of RCCL's: each rank records an event behind its send block, all ranks meet (a timed barrier: a rank
+// that never arrives fails the others instead of hanging them), then every rank's stream waits for the peers' events and pulls
+// their blocks with device-to-device copies.  It exists so that the multi-rank branches of dvs_exchange_boundary (rank > 0: the
+// previous rank's block of this call; rank 0: the last rank's block of the previous call) run on a one-GPU box.
+struct LoopGroup {
+  int world = 0, device = 0, refs = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long generation = 0;
+  bool broken = false;
+  const void* send[DVS_COMM_MAX_LOOPBACK] = {};
+  hipEvent_t ev_sent[DVS_COMM_MAX_LOOPBACK] = {};     // rank's send block is complete (its stream)
+  hipEvent_t ev_pulled[DVS_COMM_MAX_LOOPBACK] = {};   // rank has pulled every peer's block of its latest call (its stream)
+  bool pulled_once = false;
+  // every rank arrives; false when the group is broken (a peer timed out or failed)
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
+    const unsigned long gen = generation;
+    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return true; }
+    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); }
+    return !broken;
+  }
+};
+
 }  // namespace
 
 struct dvs_comm {
   int device = 0, rank = 0, world = 1;
   NcclComm comm = nullptr;
+  LoopGroup* loop = nullptr;   // loopback communicator: no RCCL
   uint8_t* gather[3] = {nullptr, nullptr, nullptr};  // [world][block] x 3: a call's result points into this call's and the previous
                                                      // call's buffer, and stays valid while the next call gathers into the third
   long calls = 0;
   size_t block = 0;
   int turn = 0;
 };
+
+namespace {
+
+// loopback: a rank's send block may be pulled by peers until their latest pulls have run — order the block's next overwrite behind them
+dvs_status loop_before_send(dvs_comm* c, hipStream_t st) {
+  LoopGroup* G = c->loop;
+  if (!G->pulled_once) return DVS_OK;
+  for (int p = 0; p < G->world; p++)
+    if (p != c->rank) DVS_HIP(hipStreamWaitEvent(st, G->ev_pulled[p], 0));
+  return DVS_OK;
+}
+
+dvs_status loop_all_gather(dvs_comm* c, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  LoopGroup* G = c->loop;
+  G->send[c->rank] = send;
+  DVS_HIP(hipEventRecord(G->ev_sent[c->rank], st));
+  if (!G->barrier()) { set_error("loopback all-gather: a rank of the group did not arrive (rank %d waited)", c->rank); return DVS_ERR_HIP; }
+  for (int p = 0; p < G->world; p++) {
+    uint8_t* dst = (uint8_t*)recv + (size_t)p * bytes;
+    if (p == c->rank) {
+      if (dst != send) DVS_HIP(hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, st));
+      continue;
+    }
+    DVS_HIP(hipStreamWaitEvent(st, G->ev_sent[p], 0));
+    DVS_HIP(hipMemcpyAsync(dst, G->send[p], bytes, hipMemcpyDeviceToDevice, st));
+  }
+  DVS_HIP(hipEventRecord(G->ev_pulled[c->rank], st));
+  // nobody re-records its events or moves its send pointer before every rank has enqueued its pulls
+  if (!G->barrier()) { set_error("loopback all-gather: a rank of the group did not arrive (rank %d waited)", c->rank); return DVS_ERR_HIP; }
+  G->pulled_once = true;
+  return DVS_OK;
+}
+
+dvs_status comm_all_gather(dvs_comm* c, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  if (c->loop) return loop_all_gather(c, send, recv, bytes, st);
+  DVS_NCCL(g_rccl.AllGather(send, recv, bytes, kNcclUint8, c->comm, st));
+  return DVS_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -115,10 +187,48 @@ dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const ui
   return DVS_OK;
 }
 
+dvs_status dvs_comm_create_loopback(int32_t device, int32_t world, dvs_comm** out) {
+  DVS_ARG(out && world >= 1 && world <= DVS_COMM_MAX_LOOPBACK);
+  for (int r = 0; r < world; r++) out[r] = nullptr;
+  DVS_TRY(check_device(device));
+  LoopGroup* G = new (std::nothrow) LoopGroup();
+  if (!G) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  G->world = world; G->device = device;
+  bool ok = true;
+  for (int r = 0; r < world; r++)
+    ok = ok && hipEventCreateWithFlags(&G->ev_sent[r], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&G->ev_pulled[r], hipEventDisableTiming) == hipSuccess;
+  for (int r = 0; ok && r < world; r++) {
+    dvs_comm* c = new (std::nothrow) dvs_comm();
+    if (!c) { ok = false; break; }
+    c->device = device; c->rank = r; c->world = world; c->loop = G;
+    G->refs++;
+    out[r] = c;
+  }
+  if (!ok) {
+    for (int r = 0; r < world; r++) { delete out[r]; out[r] = nullptr; }
+    for (int r = 0; r < world; r++) { if (G->ev_sent[r]) (void)hipEventDestroy(G->ev_sent[r]); if (G->ev_pulled[r]) (void)hipEventDestroy(G->ev_pulled[r]); }
+    delete G;
+    set_error("loopback communicator: event creation failed");
+    return DVS_ERR_HIP;
+  }
+  return DVS_OK;
+}
+
 void dvs_comm_destroy(dvs_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  if (c->loop) {
+    LoopGroup* G = c->loop;
+    bool last;
+    { std::lock_guard<std::mutex> lk(G->mu); G->broken = true; last = --G->refs == 0; }   // a group that lost a rank cannot gather any more
+    G->cv.notify_all();
+    if (last) {
+      for (int r = 0; r < G->world; r++) { (void)hipEventDestroy(G->ev_sent[r]); (void)hipEventDestroy(G->ev_pulled[r]); }
+      delete G;
+    }
+  }
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   for (uint8_t* p : c->gather) if (p) (void)hipFree(p);
   delete c;
@@ -136,8 +246,8 @@ dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, vo
   DVS_ARG(c && d_send && d_recv);
   DVS_HIP(hipSetDevice(c->device));
   if (bytes_per_rank == 0) return DVS_OK;
-  DVS_NCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, kNcclUint8, c->comm, (hipStream_t)stream));
-  return DVS_OK;
+  if (c->loop) DVS_TRY(loop_before_send(c, (hipStream_t)stream));   // (the caller's send block was written before this call: see the header)
+  return comm_all_gather(c, d_send, d_recv, bytes_per_rank, (hipStream_t)stream);
 }
 
 dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_desc_last, const int32_t* d_n_last, int32_t cap,
@@ -157,12 +267,13 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   c->turn = (c->turn + 1) % 3;
   c->calls++;
   hipStream_t st = (hipStream_t)stream;
+  if (c->loop) DVS_TRY(loop_before_send(c, st));
   uint8_t* mine = g + (size_t)c->rank * blk;
   const int rows16 = cap * 2, blk16 = (int)(blk / 16);
   hipLaunchKernelGGL(k_pack_boundary, dim3((blk16 + 255) / 256), dim3(256), 0, st, (const uint4*)d_desc_last, d_n_last, (uint4*)mine, rows16, blk16);
   DVS_HIP(hipGetLastError());
   // in place: this rank's block already sits at its slot of the receive buffer
-  DVS_NCCL(g_rccl.AllGather(mine, g, blk, kNcclUint8, c->comm, st));
+  DVS_TRY(comm_all_gather(c, mine, g, blk, st));
   // predecessor of this rank's FIRST frame of the batch: the previous rank's last frame of the SAME batch — or, for rank 0, the
   // last rank's last frame of the PREVIOUS batch (the previous call's gather; nothing on the first call)
   const uint8_t* pb = c->rank > 0 ? g + (size_t)(c->rank - 1) * blk : (gprev ? gprev + (size_t)(c->world - 1) * blk : nullptr);

@@ -29,13 +29,16 @@ struct dvs_orb {
   dvs_orb_params prm;
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  hipStream_t pf_stream = nullptr;         // the NEXT batch's pyramid chain (dvs_orb_hint_next_batch_device)
-  hipStream_t aux_stream = nullptr;        // blur runs here, concurrently with FAST + quad-tree (both only need the pyramid)
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr;
-  hipEvent_t ev_desc = nullptr, ev_prefetch = nullptr;  // descriptor stage reached / next batch's pyramid complete
-  hipEvent_t ev_pf2[2] = {nullptr, nullptr};   // ev_prefetch alternates between these: this call may still wait for its own chain
-  int pf_idx = 0;                               // after it has launched (and recorded) the next batch's
-  hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete
+  hipStream_t pf_stream = nullptr;         // highest priority: the NEXT batch's level chain (dvs_orb_hint_next_batch_device)
+  hipStream_t aux_stream = nullptr;        // lowest priority: in-step level chain, blur, a deferred descriptor stage
+  hipEvent_t ev_fork = nullptr;            // FAST finished (main stream): the blur's fork when the caller gave no after-FAST event
+  hipEvent_t ev_blur = nullptr;            // blur finished (auxiliary stream): the descriptor stage's join
+  hipEvent_t ev_start = nullptr;           // start of a call on the main stream: gate of an in-step level chain on the auxiliary stream
+  hipEvent_t ev_chain_gate = nullptr;      // gate of the next batch's chain when the previous call left no end-of-call event
+  hipEvent_t ev_prefetch = nullptr;        // the announced batch's chain is complete; alternates between ev_pf2[]: this call may still
+  hipEvent_t ev_pf2[2] = {nullptr, nullptr};   // wait for its own chain after it has launched (and recorded) the next batch's
+  int pf_idx = 0;
+  hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete (in-step chain beside FAST)
   bool overlap = true;
   int max_batch = 1;
   // ctor tables (ORBextractor.cpp:414-445)
@@ -56,69 +59,47 @@ struct dvs_orb {
   ResizeGroup* d_rgroups = nullptr;
   PyrTile* d_pyrtiles = nullptr;
   int *d_xofs = nullptr, *d_alpha = nullptr, *d_yofs = nullptr, *d_beta = nullptr;
-  u8 *d_pyr = nullptr, *d_blur = nullptr;
-  // cross-batch software pipeline (dvs_orb_hint_next_batch_device): the NEXT batch's pyramid is built into d_pyr_alt on the
-  // auxiliary stream while this batch's descriptor kernel (fetch-bound) and the caller's match run; the next call swaps
-  u8* d_pyr_alt = nullptr;
-  u8* d_pyr_3rd = nullptr;         // deferred descriptor stages: the pyramid of the batch before is still being read while the next one is built
-  hipEvent_t ev_outs[2] = {nullptr, nullptr};   // the last two deferred descriptor stages (ev_out points at the latest)
-  int out_gen = 0;
-  hipEvent_t output_event = nullptr;       // caller's event: outputs complete (dvs_orb_set_output_event => deferred descriptor stage)
-  hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // deferred mode: descriptor stage finished (auxiliary stream) / quad-tree finished
-  bool out_pending = false;                // the previous call's descriptor stage is still only ordered on the auxiliary stream
-  hipEvent_t guard_event = nullptr;        // caller's event: outputs may only be overwritten behind it (dvs_orb_set_reuse_guard_event)
+  // pyramid blocks: d_pyr = this batch; d_pyr_alt = the announced next batch (built on pf_stream beside this batch's FAST, swapped in
+  // by the next call); d_pyr_3rd = with deferred descriptor stages the pyramid of the batch before is still being read while the next
+  // one is built, so the three rotate.  The last two are allocated on first use.
+  u8 *d_pyr = nullptr, *d_pyr_alt = nullptr, *d_pyr_3rd = nullptr, *d_blur = nullptr;
+  // deferred descriptor stage (dvs_orb_set_output_event + dvs_orb_set_defer_outputs): ordered on the auxiliary stream only
+  hipEvent_t ev_outs[2] = {nullptr, nullptr};   // completion of the last two deferred stages (ev_out = the latest)
+  hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // ... / quad-tree finished (main stream): the deferred stage's join
+  int out_gen = 0;                         // deferred stages enqueued so far
+  bool out_pending = false;                // the previous call's descriptor stage has not been joined with the main stream
+  bool defer_outputs = false;              // dvs_orb_set_defer_outputs
+  hipEvent_t output_event = nullptr;       // caller's event: outputs complete
+  hipEvent_t guard_event = nullptr;        // caller's event: outputs may only be overwritten behind it (one-shot)
+  hipEvent_t after_fast_event = nullptr;   // caller's event, recorded on the main stream behind FAST
   hipEvent_t ev_end = nullptr;             // end of the previous call (gate of the next call's prefetch chain: no extra record)
   hipEvent_t gate_event = nullptr;         // = ev_end or the caller's output event, whichever the last call recorded at its end
-  bool defer_outputs = false;              // dvs_orb_set_defer_outputs
   bool pf_joined = false;                  // the prefetched pyramid's completion already precedes the main stream (joined through the blur)
-  int env_hops = 1;                        // DVS_HOPS=0: round-2a placement of the cross-stream joins (A/B)
-  hipEvent_t after_fast_event = nullptr;   // caller's event, recorded on the main stream behind FAST (dvs_orb_set_after_fast_event)
-  const u8* next_hint = nullptr;   // one-shot, set by the hint call, consumed by the next extract_batch_device
-  int env_cascade = -1;            // diagnostics (environment, read at creation): -1 = automatic
-  int env_fast_tail = 0;
-  int fast_byte_dma = 0;           // LDS-DMA with byte-aligned global addresses probed exact (DVS_FAST_BYTE_DMA=0 turns it off)
-  int env_fast_v = 2;              // DVS_FAST_V=1: the round-1 FAST kernel
-  int env_desc_split = 0;          // DVS_DESC_SPLIT=1: orientation kernel before the blur joins, descriptor kernel after (round 1's schedule)
-  int env_blur_mfma = 0;           // DVS_BLUR_MFMA=1: the matrix-core blur (k_blur_mfma) instead of the VALU streaming one; measured slower (memory side)
-  int env_oct_threads = 0;         // DVS_OCT_T=512: quad-tree workgroup size for every batch size
-  int env_pf_after_fast = 0;       // DVS_PF_AFTER_FAST=1: the next batch's level chain starts when this batch's FAST has finished
-  hipEvent_t ev_fast = nullptr;
-  // FAST look-ahead (DVS_LOOKAHEAD, default on): with the next batch announced, not only its pyramid but also its FAST runs
-  // ahead — on fa_stream, into the OTHER candidate buffer set — beside THIS batch's quad-tree / blur / descriptor kernels and
-  // the caller's match (latency-, fetch- and MFMA-bound, while FAST is VALU-bound).  One FAST at a time: the streams order it.
-  hipStream_t fa_stream = nullptr;
-  hipEvent_t ev_front = nullptr, ev_back[2] = {nullptr, nullptr};
-  int env_lookahead = 0;           // measured slower (0.767 vs 0.733 ms per step): off unless DVS_LOOKAHEAD=1
-  int cset = 0;                    // candidate buffer set of the batch being extracted
-  bool la_valid = false;           // FAST of the announced batch is (being) computed into set 1 - cset
-  uint32_t* d_cand2[2] = {nullptr, nullptr};
-  int* d_cellcount2[2] = {nullptr, nullptr};
-  unsigned back_calls = 0;
-  bool pf_valid = false;
+  const u8* next_hint = nullptr;           // one-shot, set by the hint call, consumed by the next extract_batch_device
+  bool pf_valid = false;                   // d_pyr_alt holds (or is being filled with) the pyramid of exactly this announced batch:
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
+  // switches read ONCE at creation (dvs_orb_create); each is covered by tests/test_gpu_orb.py::test_opt_in_kernel_variants_are_bit_identical
+  int env_cascade = -1;            // DVS_CASCADE=1 / 0: all-levels-in-one-launch pyramid always / never (-1 = automatic: <= 8 frames)
+  int fast_byte_dma = 0;           // LDS-DMA with byte-aligned global addresses probed exact (DVS_FAST_BYTE_DMA=0 turns it off)
+  int env_blur_mfma = 0;           // DVS_BLUR_MFMA=1: the matrix-core blur (k_blur_mfma); measured slower (memory side), DESIGN.md 4b
+  int env_oct_threads = 0;         // DVS_OCT_T=256 / 512: quad-tree workgroup size for every batch size (0 = by batch size)
+  int env_host_poll = 1;           // DVS_HOST_POLL=0: three device-to-host copy commands and a stream wait instead of k_export_host
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
-  uint32_t* d_lvlkp2[2] = {nullptr, nullptr};   // level keypoint lists, two sets: a deferred descriptor stage still reads one while the
-  int* d_lvlcount2[2] = {nullptr, nullptr};     // next call's quad-tree writes the other (no wait on the main stream in front of it)
+  // level keypoint lists, three sets in rotation: deferred descriptor stages k - 1 and k - 2 may both still read theirs when call k's
+  // quad-tree writes (stage k - 3 precedes the level chain call k's FAST waited for) — no wait on the main stream in front of it
+  uint32_t* d_lvlkp3[3] = {nullptr, nullptr, nullptr};
+  int* d_lvlcount3[3] = {nullptr, nullptr, nullptr};
   int lset = 0;
-  float4* d_orient = nullptr;  // per keypoint slot: (angle, cos, sin, -) between the two halves of the descriptor stage
   int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
   u8* d_desc = nullptr;
   int* d_nout = nullptr;
-  // experiment: the single-frame host path as ONE hipGraph (H2D of the staged frame, every kernel of the two streams,
-  // the three D2H copies), captured once per resolution and replayed per frame.  Bit-identical, not faster: off by default.
-  u8* h_img = nullptr;             // pinned staging of the caller's frame (rows x cols, tight)
-  hipGraphExec_t g_exec = nullptr;
-  int g_rows = 0, g_cols = 0;
-  int env_graph = 0;               // DVS_GRAPH=1: replay a captured graph (measured: no faster on ROCm 7.2 — 640x480 0.224 vs 0.171 ms, 720p 0.229 vs 0.236)
   dvs_keypoint* h_kps = nullptr;   // pinned
   u8* h_desc = nullptr;
   int* h_nout = nullptr;
   int* h_seq = nullptr;            // pinned: sequence number k_export_host publishes (dvs_orb_extract[_batch] poll it)
   int* d_ticket = nullptr;         // ... its last-workgroup ticket
   int export_seq = 0;
-  int env_host_poll = 1;           // DVS_HOST_POLL=0: three device-to-host copy commands and a stream wait instead
-  double host_t[5] = {0, 0, 0, 0, 0}; long host_calls = 0;   // DVS_HOST_TIMING=1: phases of the host entry point (diagnostics)
   size_t octree_smem = 0;
   int octree_nmax = 0, octree_ptscap = 0;
   int last_nimg = 0;
@@ -129,27 +110,19 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
-  if (h->d_cand2[1]) (void)hipFree(h->d_cand2[1]);
-  if (h->d_cellcount2[1]) (void)hipFree(h->d_cellcount2[1]);
-  h->d_cand2[0] = h->d_cand2[1] = nullptr; h->d_cellcount2[0] = h->d_cellcount2[1] = nullptr; h->la_valid = false;
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_pyr_alt, h->d_pyr_3rd, h->d_orient, h->d_cand, h->d_pts, h->d_lvlkp2[0], h->d_lvlkp2[1], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
-                  h->d_lvlcount2[0], h->d_lvlcount2[1], h->d_kps, h->d_desc, h->d_nout};
+                  h->d_pyr_alt, h->d_pyr_3rd, h->d_cand, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+                  h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_kps, h->d_desc, h->d_nout, h->d_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
-  if (h->h_img) { (void)hipHostFree(h->h_img); h->h_img = nullptr; }
-  if (h->h_kps) (void)hipHostFree(h->h_kps);
-  if (h->h_desc) (void)hipHostFree(h->h_desc);
-  if (h->h_nout) (void)hipHostFree(h->h_nout);
-  if (h->h_seq) (void)hipHostFree(h->h_seq);
-  if (h->d_ticket) (void)hipFree(h->d_ticket);
+  void* pinned[] = {h->h_kps, h->h_desc, h->h_nout, h->h_seq};
+  for (void* p : pinned) if (p) (void)hipHostFree(p);
   h->h_seq = nullptr; h->d_ticket = nullptr;
   h->d_blurcols = nullptr; h->d_blurtab = nullptr;
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
-  h->d_lvlkp2[0] = h->d_lvlkp2[1] = nullptr; h->d_lvlcount2[0] = h->d_lvlcount2[1] = nullptr;
-  h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->out_gen = 0; h->d_orient = nullptr; h->pf_valid = false; h->next_hint = nullptr;
+  for (int k = 0; k < 3; k++) { h->d_lvlkp3[k] = nullptr; h->d_lvlcount3[k] = nullptr; }
+  h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->out_gen = 0; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
   h->rows = h->cols = 0;
@@ -224,7 +197,6 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
   G.iniTh = std::min(std::max(h->prm.ini_th_fast, 0), 255);  // cv::FAST clamps the threshold
   G.minTh = std::min(std::max(h->prm.min_th_fast, 0), 255);
   G.outCap = h->prm.nfeatures + 3 * nl;
-  if (const char* dbg = getenv("DVS_DEBUG")) G.debug = atoi(dbg);
   memcpy(G.gk, h->prm.gauss_kernel, sizeof(G.gk));
   memcpy(G.umax, h->umax, sizeof(G.umax));
   for (int lane = 0; lane < 64; lane++) {
@@ -402,10 +374,8 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     for (const Cell& c : cells) { maxw = std::max<int>(maxw, c.cw); maxh = std::max<int>(maxh, c.ch); }
     G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
     G.fastRows = maxh;
-    int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);
-    if (const char* el = getenv("DVS_FAST_LIST")) listBytes = atoi(el);   // EXPERIMENT ONLY (occupancy probe): no overflow handling
+    const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);   // worst case: every interior pixel survives
     G.fastByteDma = h->fast_byte_dma;
-    G.fastXcd = getenv("DVS_FAST_XCD") ? atoi(getenv("DVS_FAST_XCD")) : 1;
     G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
     G.fastWaveLds = (int)align_up((size_t)G.fastTile + (size_t)G.fastRows * G.fastP + listBytes, 16);
   }
@@ -470,19 +440,6 @@ static bool build_blur_mfma(const Geom& G, std::vector<BlurCol>& items, std::vec
   return true;
 }
 
-// look-ahead experiment: the stream of the next batch's FAST, optionally confined to a subset of the CUs (DVS_FA_CUMASK = one
-// 32-bit pattern repeated over the 256 CU bits) so that this batch's latency-bound kernels find free CUs beside it
-static hipError_t create_fa_stream(hipStream_t* st, int prio_lo, int prio_hi) {
-  if (const char* m = getenv("DVS_FA_CUMASK")) {
-    const uint32_t pat = (uint32_t)strtoul(m, nullptr, 16);
-    uint32_t mask[8];
-    for (int i = 0; i < 8; i++) mask[i] = pat;
-    return hipExtStreamCreateWithCUMask(st, 8, mask);
-  }
-  const char* p = getenv("DVS_FA_PRIO");
-  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, p ? (atoi(p) > 0 ? prio_hi : (atoi(p) < 0 ? prio_lo : 0)) : prio_lo);
-}
-
 // one probe per process and device (see k_probe_lds_dma)
 static int probe_byte_dma(int device, hipStream_t st) {
   static int cache[64]; static bool done[64];
@@ -510,8 +467,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
-  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
-  h->out_pending = false; h->pf_joined = false; h->pf_valid = false; h->la_valid = false;
+  h->out_pending = false; h->pf_joined = false; h->pf_valid = false;
   free_workspace(h);
   Geom G;
   std::vector<Cell> cells; std::vector<BlurTile> tiles; std::vector<BlurStrip> strips; std::vector<ResizeGroup> rgroups;
@@ -538,19 +494,16 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes + 256));   // + slack: k_resize4 reads whole 12-byte windows at a row's end
   DVS_HIP(hipMalloc((void**)&h->d_blur, B * G.frameBytes));
   DVS_HIP(hipMalloc((void**)&h->d_cand, B * G.candPerFrame * 4));
-  h->d_cand2[0] = h->d_cand; h->d_cand2[1] = nullptr; h->cset = 0; h->la_valid = false;
   DVS_HIP(hipMalloc((void**)&h->d_pts, B * G.ptsPerFrame * 4));
   DVS_HIP(hipMalloc((void**)&h->d_nodeof, B * G.ptsPerFrame * 4));
   DVS_HIP(hipMalloc((void**)&h->d_cellcount, B * G.totalCells * 4));
-  h->d_cellcount2[0] = h->d_cellcount; h->d_cellcount2[1] = nullptr;
   DVS_HIP(hipMalloc((void**)&h->d_celloff, B * G.totalCells * 4));
   DVS_HIP(hipMalloc((void**)&h->d_candtotal, B * G.nlevels * 4));
-  for (int k = 0; k < 2; k++) {
-    DVS_HIP(hipMalloc((void**)&h->d_lvlcount2[k], B * G.nlevels * 4));
-    DVS_HIP(hipMalloc((void**)&h->d_lvlkp2[k], B * (size_t)G.kpBlock * 4));
+  for (int k = 0; k < 3; k++) {
+    DVS_HIP(hipMalloc((void**)&h->d_lvlcount3[k], B * G.nlevels * 4));
+    DVS_HIP(hipMalloc((void**)&h->d_lvlkp3[k], B * (size_t)G.kpBlock * 4));
   }
-  h->lset = 0; h->d_lvlcount = h->d_lvlcount2[0]; h->d_lvlkp = h->d_lvlkp2[0];
-  DVS_HIP(hipMalloc((void**)&h->d_orient, B * (size_t)G.kpBlock * sizeof(float4)));
+  h->lset = 0; h->d_lvlcount = h->d_lvlcount3[0]; h->d_lvlkp = h->d_lvlkp3[0];
   DVS_HIP(hipMalloc((void**)&h->d_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
   DVS_HIP(hipMalloc((void**)&h->d_desc, B * (size_t)G.outCap * 32));
   DVS_HIP(hipMalloc((void**)&h->d_nout, B * 4));
@@ -579,9 +532,6 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
-  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
-  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
-  DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave_r1<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   h->rows = rows; h->cols = cols;
   return DVS_OK;
 }
@@ -611,251 +561,62 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
   return DVS_OK;
 }
 
-// enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`
-dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout,
-                           const u8* next_img0 = nullptr, bool may_defer = false) {
+// ---- the stages of one extraction, each a launch on the stream the schedule (enqueue_extract) picks --------------------------------
+
+// FAST on cells [c0, c1) of the level-major cell table
+void launch_fast(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t fs, int c0, int c1) {
+  if (c1 <= c0) return;
   const Geom& G = h->geom;
-  hipStream_t st = h->stream;
-  // deferred descriptor stage of the previous call (dvs_orb_set_output_event): it runs on the auxiliary stream beside THIS call's
-  // FAST.  What it still reads — the other pyramid buffer, the blurred block, the level keypoint lists — is protected below: the
-  // prefetch chain and this call's quad-tree wait for it, the blur follows it on the same stream.
-  bool pend = h->out_pending;
-  h->out_pending = false;
-  // a pyramid prefetched for exactly this batch (same buffer, layout and count)?  then it is already (being) built in d_pyr_alt
-  const bool prefetched = h->pf_valid && h->overlap && h->pf_img == src.img0 && h->pf_step == src.step0 &&
-                          h->pf_fstride == src.fstride0 && h->pf_nimg == nimg;
-  h->pf_valid = false;
-  const bool la_hit = prefetched && h->la_valid;   // ... and so is its FAST, in the other candidate set
-  h->la_valid = false;
-  if (pend && !(prefetched && may_defer && h->overlap)) {   // anything but the pipelined pattern: plain join first
-    DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));
-    pend = false;
+  if ((((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 != 0) {   // rows not dword aligned: the generic workgroup-per-cell kernel
+    hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0);
+    return;
   }
-  // experiment (DVS_FAST_SPLIT=1): a prefetched pyramid is only needed from level 1 on, so FAST could start on level 0 (52 % of its
-  // cells) at once with the wait for the chain in front of the rest.  Measured: 0.544-0.551 ms per step against 0.524-0.533 with
-  // one FAST launch behind the wait — off.
-  hipEvent_t my_pf = nullptr;
-  if (prefetched) {
-    std::swap(h->d_pyr, h->d_pyr_alt);
-    // (non-deferred calls: the previous call joined the chain through its blur, below — no barrier packet at all then)
-    if (!h->pf_joined) my_pf = h->ev_prefetch;
-  }
-  h->pf_joined = false;
-  const bool fast_split = my_pf && h->geom.nlevels >= 2 && getenv("DVS_FAST_SPLIT") && atoi(getenv("DVS_FAST_SPLIT"));
-  if (my_pf && !fast_split) DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));
-  if (la_hit) {
-    h->cset ^= 1;
-    DVS_HIP(hipStreamWaitEvent(st, h->ev_front, 0));
-  }
-  h->d_cand = h->d_cand2[h->cset]; h->d_cellcount = h->d_cellcount2[h->cset];
-  src.pyr = h->d_pyr;
-  // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192).  The seven resize launches are short and
-  //    latency-bound, FAST is throughput-bound and level 0 needs no pyramid at all: with overlap on, the chain runs on the
-  //    auxiliary stream while FAST starts on level 0, continues on level 1 once it exists, then takes the remaining levels.
-  const bool aligned0 = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
-  // k_pyr_cascade (all levels in one launch, LDS ping-pong) is bit-identical and reads level 0 only ~1.1x, but measured
-  // SLOWER than the per-level chain running beside FAST (0.29 vs 0.20 ms per 64 frames: the resize arithmetic is VALU-issue
-  // bound, so removing the launches and the re-reads buys nothing).  Kept selectable for HBM-traffic experiments.
-  // few frames (the live one-frame-per-callback pattern): the launch chain, not the arithmetic, sets the latency -> all levels in
-  // one launch (0.31 -> 0.25 ms per 1280x720 frame); larger batches keep the per-level chain that runs beside FAST
-  const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 8;  // measured: +26 % at 2, +12 % at 8, -2 % at 16 frames
-  const uint32_t allLevels = G.nlevels >= 32 ? ~0u : ((1u << G.nlevels) - 1u);
-  const bool sharded = (src.levelMask & allLevels) != allLevels || src.slotted;   // level-sharded call: the chain up to its top level, its levels only
-  int topLevel = 0;
-  for (int l = 0; l < G.nlevels; l++) if ((src.levelMask >> l) & 1u) topLevel = l;
-  const bool cascade = !prefetched && !sharded && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
-  const bool ov = !prefetched && !cascade && !sharded && h->overlap && G.nlevels >= 2;
-  hipStream_t pst = st;
-  if (prefetched) {
-    // nothing to build
-  } else if (cascade) {
-    // all levels in ONE launch: each workgroup stages a level-0 region in LDS and walks down the levels (k_pyr_cascade)
-    h->timer.begin(DVS_STAGE_PYRAMID, st);
-    hipLaunchKernelGGL(k_pyr_cascade, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
-                       h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, G.pyrLds);
-    h->timer.end(st);
+  const dim3 grid((c1 - c0 + 3) / 4, nimg);
+  const size_t lds = 4 * (size_t)G.fastWaveLds;
+  if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+  else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+  else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+}
+
+// The announced next batch's level chain on pf_stream into d_pyr_alt, beside THIS batch's FAST: the chain is latency-bound, FAST is
+// VALU-bound and insensitive to its cache traffic (beside the fetch-bound descriptor stage the chain doubled that stage's time), and
+// with its pyramid built ahead the next call launches FAST on all levels at once.  `pend`: the previous call's deferred descriptor
+// stage still reads that batch's pyramid (d_pyr_alt after the caller's swap).
+dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* next_img0, bool pend) {
+  const Geom& G = h->geom;
+  if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes + 256));
+  if (pend) {
+    // build into the THIRD buffer instead of waiting for that stage — the chain then runs beside FAST from the start, as without
+    // deferral (when it waited it ended after FAST and became the critical path).  The third buffer held the pyramid of two batches
+    // ago; its last reader is that batch's descriptor stage, whose event is the only gate (nothing on the main stream).
+    if (!h->d_pyr_3rd) DVS_HIP(hipMalloc((void**)&h->d_pyr_3rd, (size_t)h->max_batch * G.frameBytes + 256));
+    std::swap(h->d_pyr_alt, h->d_pyr_3rd);
+    if (h->out_gen >= 2) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_outs[h->out_gen & 1], 0));
   } else {
-    if (ov) {
-      pst = h->aux_stream;
-      DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
-      DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
-    }
-    h->timer.begin(DVS_STAGE_PYRAMID, pst);
-    DVS_TRY(launch_pyramid_chain(h, src, nimg, h->d_pyr, pst, ov, sharded ? topLevel : -1));
-    h->timer.end(pst);
+    // d_pyr_alt's last readers are the previous call's kernels: its end-of-call event if it left one (no extra record), else this
+    // point of the main stream
+    hipEvent_t gate = h->gate_event;
+    if (!gate) { gate = h->ev_chain_gate; DVS_HIP(hipEventRecord(gate, h->stream)); }
+    DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
   }
-  // the next batch's pyramid (if announced) runs on the auxiliary stream beside THIS batch's FAST: the chain is latency-bound
-  // and FAST is VALU-bound and insensitive to its cache traffic (beside the fetch-bound descriptor stage it doubled that
-  // stage's time), and with this batch's own pyramid prefetched the same way FAST needs no per-level gating at all
-  // FAST launcher: cells [c0, c1) of `isrc` on stream `fs` into candidate set `cs`
-  const bool wavek = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
-  auto launch_fast = [&](const ImgSrc& isrc, hipStream_t fs, int cs, int c0, int c1) {
-    if (c1 <= c0) return;
-    uint32_t* cand = h->d_cand2[cs];
-    int* ccnt = h->d_cellcount2[cs];
-    if (wavek) {
-      const dim3 grid((c1 - c0 + 3) / 4, nimg);
-      const size_t lds = 4 * (size_t)G.fastWaveLds;
-      if (h->env_fast_v == 1) {  // round-1 kernel, for A/B measurements
-        if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave_r1<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-        else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave_r1<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-        else hipLaunchKernelGGL(k_fast_wave_r1<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-      } else if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-      else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-      else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0, c1);
-    } else {
-      hipLaunchKernelGGL(k_fast_cell, dim3(c1 - c0, nimg), dim3(256), 0, fs, h->d_geom, h->d_cells, isrc, cand, ccnt, c0);
-    }
-  };
-  // the next batch's front half (if announced): its level chain on pf_stream and — with look-ahead — its FAST on fa_stream into
-  // the other candidate set.  Both overwrite what the PREVIOUS batch's back half read (the other pyramid buffer, the other
-  // candidate set): gated on that call's last kernel (ev_back of the previous call; it precedes this point of `st` anyway).
-  auto launch_prefetch = [&](bool after_fast) -> dvs_status {
-    if (!(next_img0 && h->overlap && G.nlevels >= 2)) return DVS_OK;
-    if (!h->d_pyr_alt) DVS_HIP(hipMalloc((void**)&h->d_pyr_alt, (size_t)h->max_batch * G.frameBytes + 256));
-    ImgSrc nsrc = src;
-    nsrc.img0 = next_img0;
-    hipEvent_t gate = after_fast ? h->ev_fast : h->ev_desc;
-    if (pend && !after_fast && !h->env_lookahead && !(getenv("DVS_PYR_TRIPLE") && !atoi(getenv("DVS_PYR_TRIPLE")))) {
-      // the previous call's descriptor stage is still reading that batch's pyramid (d_pyr_alt after the swap above): build into a
-      // THIRD buffer instead of waiting for it — the chain then runs beside FAST from the start, as without deferral (when it waited,
-      // it ended after FAST and became the critical path as soon as FAST got faster).  The third buffer held the pyramid of two
-      // batches ago; its last reader is that batch's descriptor stage, whose event is the only gate (nothing on the main stream).
-      if (!h->d_pyr_3rd) DVS_HIP(hipMalloc((void**)&h->d_pyr_3rd, (size_t)h->max_batch * G.frameBytes + 256));
-      std::swap(h->d_pyr_alt, h->d_pyr_3rd);
-      if (h->out_gen >= 2) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_outs[h->out_gen & 1], 0));
-      gate = nullptr;
-    } else if (!after_fast && h->env_hops && h->gate_event) {
-      gate = h->gate_event;                // the previous call's end, recorded there: every reader of d_pyr_alt precedes it
-    } else {
-      DVS_HIP(hipEventRecord(gate, st));   // d_pyr_alt's last readers (the previous batch) precede this point of the stream
-    }
-    if (gate) DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
-    if (pend && gate) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_out, 0));   // ... except a deferred descriptor stage
-    const bool la = h->env_lookahead && h->fa_stream && !after_fast;
-    const int ns = h->cset ^ 1;
-    if (la) {
-      if (!h->d_cand2[1]) {
-        DVS_HIP(hipMalloc((void**)&h->d_cand2[1], (size_t)h->max_batch * G.candPerFrame * 4));
-        DVS_HIP(hipMalloc((void**)&h->d_cellcount2[1], (size_t)h->max_batch * G.totalCells * 4));
-      }
-      nsrc.pyr = h->d_pyr_alt;
-      DVS_HIP(hipStreamWaitEvent(h->fa_stream, gate, 0));
-      h->timer.begin(DVS_STAGE_FAST, h->fa_stream);
-      launch_fast(nsrc, h->fa_stream, ns, 0, G.lv[0].nCells);   // level 0 needs no pyramid
-      h->timer.end(h->fa_stream);
-    }
-    h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
-    DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
-    h->timer.end(h->pf_stream);
-    h->pf_idx ^= 1;
-    h->ev_prefetch = h->ev_pf2[h->pf_idx];
-    DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
-    if (la) {
-      DVS_HIP(hipStreamWaitEvent(h->fa_stream, h->ev_prefetch, 0));
-      h->timer.begin(DVS_STAGE_FAST, h->fa_stream, false);
-      launch_fast(nsrc, h->fa_stream, ns, G.lv[0].nCells, G.totalCells);
-      h->timer.end(h->fa_stream);
-      DVS_HIP(hipEventRecord(h->ev_front, h->fa_stream));
-      h->la_valid = true;
-    }
-    h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
-    return DVS_OK;
-  };
-  if (!h->env_pf_after_fast) DVS_TRY(launch_prefetch(false));
-  // joins that only the descriptor stage needs ride on the blur's (auxiliary) stream, off the main stream's critical path, and are
-  // enqueued there BEFORE FAST so that their barrier packets are consumed while FAST runs: the caller's reuse guard (outputs are
-  // written by the descriptor stage, which waits for the blur) and the completion of the next batch's level chain (then the next
-  // call's FAST needs no barrier packet in front of it; the chain ends before FAST does)
-  if (h->overlap && h->aux_stream) {
-    // (with a deferred descriptor stage the guard is waited for right in front of that stage instead — see below — so that a slow
-    // reader of the output buffers does not hold up the blur as well)
-    const bool guard_late = may_defer && h->output_event && h->defer_outputs && !sharded && !h->env_desc_split;
-    if (h->guard_event && !guard_late) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->guard_event, 0)); h->guard_event = nullptr; }
-    if (h->env_hops && (h->env_hops > 1 || !(h->defer_outputs && h->output_event)) && h->pf_valid && !sharded && !h->env_pf_after_fast) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_prefetch, 0)); h->pf_joined = true; }
-  }
-  // 2. FAST per cell: level 0 | level 1 | levels >= 2 (one launch without overlap); nothing to do when it ran ahead
-  bool split_here = fast_split && !la_hit && !ov && !sharded;
-  if (fast_split && !split_here) DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));   // any other FAST schedule: the chain first
-  if (!la_hit) {
-    if (ov) {  // one launch per level, each gated on its own level only; the small tail levels share one launch
-      int tail = G.nlevels;  // first level of the merged tail: levels whose cells are < 1/16 of all cells each
-      while (tail > 2 && G.lv[tail - 1].nCells * 16 < G.totalCells) tail--;
-      if (h->env_fast_tail > 0) tail = std::max(1, std::min(G.nlevels, h->env_fast_tail));
-      for (int l = 0; l < G.nlevels; l++) {
-        const bool merged = l >= tail;
-        if (merged && l > tail) continue;
-        const int lastl = merged ? G.nlevels - 1 : l;
-        if (lastl > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[lastl], 0));
-        h->timer.begin(DVS_STAGE_FAST, st, l == 0);
-        launch_fast(src, st, h->cset, G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
-        h->timer.end(st);
-      }
-    } else if (sharded) {
-      h->timer.begin(DVS_STAGE_FAST, st);
-      for (int l = 0; l < G.nlevels; l++)
-        if ((src.levelMask >> l) & 1u) launch_fast(src, st, h->cset, G.lv[l].cellBase, G.lv[l].cellBase + G.lv[l].nCells);
-      h->timer.end(st);
-    } else {
-      h->timer.begin(DVS_STAGE_FAST, st);
-      if (split_here) {
-        launch_fast(src, st, h->cset, 0, G.lv[0].nCells);                 // level 0 reads the caller's frames only
-        DVS_HIP(hipStreamWaitEvent(st, my_pf, 0));                         // this batch's level chain
-        launch_fast(src, st, h->cset, G.lv[0].nCells, G.totalCells);
-      } else {
-        launch_fast(src, st, h->cset, 0, G.totalCells);
-      }
-      h->timer.end(st);
-    }
-  }
-  if (h->env_pf_after_fast) DVS_TRY(launch_prefetch(true));
-  // blur only depends on the pyramid.  It is forked onto the auxiliary stream AFTER FAST so that the throughput-bound
-  // blur fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked
-  // before FAST the two throughput-bound kernels merely shared the CUs (measured: no gain).
-  hipStream_t bst = st;
-  hipEvent_t ev_fastdone = h->ev_pyr;
-  if (h->after_fast_event) {
-    DVS_HIP(hipEventRecord(h->after_fast_event, st));
-    if (h->env_hops) ev_fastdone = h->after_fast_event;   // one record serves the caller and the blur's fork
-  }
-  if (h->overlap) {
-    bst = h->aux_stream;
-    if (ev_fastdone == h->ev_pyr) DVS_HIP(hipEventRecord(h->ev_pyr, st));
-  }
-  // 3. quad-tree.  A deferred descriptor stage of the previous call still reads that call's level keypoint lists: this call takes the
-  //    other set instead of waiting for it (the set before that is free: its reader precedes the prefetch chain this call's FAST
-  //    waited for)
-  if (pend) { h->lset ^= 1; h->d_lvlkp = h->d_lvlkp2[h->lset]; h->d_lvlcount = h->d_lvlcount2[h->lset]; }
-  h->timer.begin(DVS_STAGE_OCTREE, st);
-  // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames);
-  // with two per CU beside the blur the wave slots they take cost more than the shorter tree gains (kOctT)
-  // ... and 256 threads for larger batches: two workgroups per CU run beside the blur (and a pipelined caller's match), and the wave
-  // slots 512-thread workgroups hold cost those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 and
-  // 384 threads: 0.729 / 0.690).  DVS_OCT_T=512 keeps 512 with the per-level grading of oct_threads().
-  const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
-  hipLaunchKernelGGL(k_octree, dim3(nimg, G.nlevels), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
-                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
-  h->timer.end(st);
-  // the quad-tree workgroups are already queued: they become resident first, the blur fills the remaining CUs
-  const bool will_defer = bst != st && may_defer && h->output_event && h->defer_outputs && !sharded && !h->env_desc_split;
-  // experiment (DVS_BLUR_LATE=1): with a deferred descriptor stage the blur — only the descriptors need it — could wait for the
-  // quad-tree too and run beside the next call's FAST.  Measured: neutral at 64 frames per step (0.6177 against 0.6194-0.6408 ms),
-  // worse everywhere else (1 frame 9.8 k -> 7.4 k frames/s, 32: 95.8 k -> 90.7 k, 128: 106.4 k -> 99.1 k): off.
-  const bool blur_late = will_defer && getenv("DVS_BLUR_LATE") && atoi(getenv("DVS_BLUR_LATE"));
-  if (blur_late) {
-    DVS_HIP(hipEventRecord(h->ev_oct, st));
-    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
-  } else if (bst != st) {
-    DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
-  } else if (h->guard_event) {
-    DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
-  }
-  hipEvent_t late_guard = (bst != st) ? h->guard_event : nullptr;   // still set only in the deferred case (guard_late above)
-  h->guard_event = nullptr;   // one-shot
-  h->timer.begin(DVS_STAGE_BLUR, bst);
+  ImgSrc nsrc = src;
+  nsrc.img0 = next_img0;
+  h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
+  DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+  h->timer.end(h->pf_stream);
+  h->pf_idx ^= 1;
+  h->ev_prefetch = h->ev_pf2[h->pf_idx];
+  DVS_HIP(hipEventRecord(h->ev_prefetch, h->pf_stream));
+  h->pf_valid = true; h->pf_img = next_img0; h->pf_step = src.step0; h->pf_fstride = src.fstride0; h->pf_nimg = nimg;
+  return DVS_OK;
+}
+
+// 7x7 fixed-point Gaussian of every level (ORBextractor.cpp:1132-1133)
+void launch_blur(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t bst, bool cascade) {
+  const Geom& G = h->geom;
   // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
   // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
-  bool stream_ok = aligned0 && G.lv[0].w % 4 == 0;
+  bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
   for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && (cascade || G.lv[l].gtab >= 0);
   // matrix-core blur: 16-byte aligned rows (the pyramid block always is; a caller's level 0 when its pointer and strides are)
   const bool mfma_ok = h->env_blur_mfma && h->blur_mfma_ok && stream_ok &&
@@ -867,51 +628,159 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     hipLaunchKernelGGL(k_blur_stream, dim3((G.blurStrips + 3) / 4, nimg), dim3(256), 0, bst, h->d_geom, h->d_strips, G.blurStrips, src, h->d_blur);
   else
     hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
-  h->timer.end(bst);
-  if (bst != st) DVS_HIP(hipEventRecord(h->ev_blur, bst));
-  // 5. orientation + descriptors + output records.  With the blur on its own stream the orientation half (pyramid + keypoints
-  //    only, fetch-bound) runs while the blur (VALU-bound) is still in flight; the descriptor half joins both.
-  const dim3 dgrid((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg);
-  if (bst != st && h->env_desc_split) {
-    h->timer.begin(DVS_STAGE_DESCRIBE, st);
-    hipLaunchKernelGGL(k_describe<1>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
-                       capacity, h->d_orient);
+}
+
+// Enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`.  Schedule:
+//   main stream      [wait: this batch's chain]  FAST ............  quad-tree ......................  [descriptors, if not deferred]
+//   prefetch stream  next batch's level chain (beside FAST)
+//   auxiliary stream [reuse guard, chain join]                     blur (beside the quad-tree)  ->  [descriptors, if deferred]
+// A caller stream released by the after-FAST event runs beside quad-tree and blur (bench.py: the previous batch's match).
+dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps, u8* d_desc, int capacity, int* d_nout,
+                           const u8* next_img0 = nullptr, bool may_defer = false) {
+  const Geom& G = h->geom;
+  hipStream_t st = h->stream;
+  const bool aligned0 = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0;
+  const uint32_t allLevels = G.nlevels >= 32 ? ~0u : ((1u << G.nlevels) - 1u);
+  const bool sharded = (src.levelMask & allLevels) != allLevels || src.slotted;   // level-sharded call: the chain up to its top level, its levels only
+  // a pyramid prefetched for exactly this batch (same buffer, layout and count)?  then it is already (being) built in d_pyr_alt
+  const bool prefetched = h->pf_valid && h->overlap && h->pf_img == src.img0 && h->pf_step == src.step0 &&
+                          h->pf_fstride == src.fstride0 && h->pf_nimg == nimg;
+  h->pf_valid = false;
+  // A deferred descriptor stage of the previous call (`pend`) runs on the auxiliary stream beside THIS call's FAST.  What it still
+  // reads is protected without a wait on the main stream: the pyramids rotate over three buffers (launch_prefetch), the level
+  // keypoint lists over three sets (below), the blurred block is rewritten on its own stream.  Anything but the pipelined pattern
+  // (a prefetched batch from a caller that takes its outputs by event) joins it first.
+  bool pend = h->out_pending;
+  h->out_pending = false;
+  if (pend && !(prefetched && may_defer)) {
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_out, 0));
+    pend = false;
+  }
+  // this call defers its own descriptor stage: outputs by event, stage on the auxiliary stream, main stream not joined
+  const bool will_defer = h->overlap && may_defer && h->output_event && h->defer_outputs && !sharded;
+
+  // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192)
+  //    prefetched: nothing to build (non-deferred calls joined the chain through their blur — no barrier packet at all then);
+  //    few frames (the live one-frame-per-callback pattern): the launch chain, not the arithmetic, sets the latency -> all levels in
+  //    ONE launch (k_pyr_cascade: +26 % at 2 frames, +12 % at 8, -2 % at 16; beside FAST at 64 frames the chain wins, 0.20 vs 0.29 ms);
+  //    otherwise the seven launches run on the auxiliary stream while FAST starts on level 0 and follows level by level.
+  if (prefetched) {
+    std::swap(h->d_pyr, h->d_pyr_alt);
+    if (!h->pf_joined) DVS_HIP(hipStreamWaitEvent(st, h->ev_prefetch, 0));
+  }
+  h->pf_joined = false;
+  src.pyr = h->d_pyr;
+  int topLevel = 0;
+  for (int l = 0; l < G.nlevels; l++) if ((src.levelMask >> l) & 1u) topLevel = l;
+  const bool want_cascade = h->env_cascade >= 0 ? h->env_cascade == 1 : nimg <= 8;
+  const bool cascade = !prefetched && !sharded && want_cascade && aligned0 && G.pyrTiles > 0 && 2 * (size_t)G.pyrLds <= 160 * 1024;
+  const bool ov = !prefetched && !cascade && !sharded && h->overlap && G.nlevels >= 2;   // in-step chain beside FAST
+  if (cascade) {
+    h->timer.begin(DVS_STAGE_PYRAMID, st);
+    hipLaunchKernelGGL(k_pyr_cascade, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
+                       h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, G.pyrLds);
     h->timer.end(st);
-    DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
-    h->timer.begin(DVS_STAGE_DESCRIBE, st, false);
-    hipLaunchKernelGGL(k_describe<2>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
-                       capacity, h->d_orient);
-    h->timer.end(st);
-  } else if (bst != st && may_defer && h->output_event && h->defer_outputs && !sharded) {
-    // deferred: the descriptor stage follows the blur on the auxiliary stream and the main stream is NOT joined — the next call's
-    // FAST (vector-ALU bound, light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the
-    // caller's output event.
-    if (!blur_late) {
-      DVS_HIP(hipEventRecord(h->ev_oct, st));
-      DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+  } else if (!prefetched) {
+    hipStream_t pst = st;
+    if (ov) {
+      pst = h->aux_stream;
+      DVS_HIP(hipEventRecord(h->ev_start, st));          // inputs ready / previous call's consumers of the pyramid done
+      DVS_HIP(hipStreamWaitEvent(pst, h->ev_start, 0));
     }
-    if (late_guard) DVS_HIP(hipStreamWaitEvent(bst, late_guard, 0));   // the caller's readers of the output buffers
-    h->timer.begin(DVS_STAGE_DESCRIBE, bst);
-    hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, bst, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
-                       capacity, h->d_orient);
-    h->timer.end(bst);
-    h->ev_out = h->ev_outs[h->out_gen & 1];
-    h->out_gen++;
-    DVS_HIP(hipEventRecord(h->ev_out, bst));
-    DVS_HIP(hipEventRecord(h->output_event, bst));
-    h->out_pending = true;
+    h->timer.begin(DVS_STAGE_PYRAMID, pst);
+    DVS_TRY(launch_pyramid_chain(h, src, nimg, h->d_pyr, pst, ov, sharded ? topLevel : -1));
+    h->timer.end(pst);
+  }
+  if (next_img0 && h->overlap && G.nlevels >= 2) DVS_TRY(launch_prefetch(h, src, nimg, next_img0, pend));
+
+  // Joins that only the descriptor stage needs ride on the blur's (auxiliary) stream, off the main stream's critical path, and are
+  // enqueued there BEFORE FAST so that their barrier packets (5-8 us each between two dependent kernels of one queue) are consumed
+  // while FAST runs: the caller's reuse guard (outputs are written by the descriptor stage, which follows the blur) and the
+  // completion of the next batch's chain (then the next call's FAST needs no barrier packet in front of it).  A deferring call
+  // takes the guard right in front of its descriptor stage instead, so that a slow reader does not hold up the blur as well.
+  if (h->overlap) {
+    if (h->guard_event && !will_defer) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->guard_event, 0)); h->guard_event = nullptr; }
+    if (h->pf_valid && !sharded && !(h->defer_outputs && h->output_event)) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_prefetch, 0)); h->pf_joined = true; }
+  }
+
+  // 2. FAST per cell.  One launch over all levels; with the in-step chain one launch per level, each gated on its own level only
+  //    (the small tail levels — each < 1/16 of the cells — share one); a level-sharded call launches its levels.
+  if (ov) {
+    int tail = G.nlevels;
+    while (tail > 2 && G.lv[tail - 1].nCells * 16 < G.totalCells) tail--;
+    for (int l = 0; l <= tail && l < G.nlevels; l++) {
+      const int lastl = l == tail ? G.nlevels - 1 : l;
+      if (lastl > 0) DVS_HIP(hipStreamWaitEvent(st, h->ev_level[lastl], 0));
+      h->timer.begin(DVS_STAGE_FAST, st, l == 0);
+      launch_fast(h, src, nimg, st, G.lv[l].cellBase, G.lv[lastl].cellBase + G.lv[lastl].nCells);
+      h->timer.end(st);
+    }
   } else {
-    if (bst != st) DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));  // join
-    h->timer.begin(DVS_STAGE_DESCRIBE, st);
-    hipLaunchKernelGGL(k_describe<0>, dgrid, dim3(256), 0, st, h->d_geom, src, h->d_blur, h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout,
-                       capacity, h->d_orient);
+    h->timer.begin(DVS_STAGE_FAST, st);
+    if (sharded) {
+      for (int l = 0; l < G.nlevels; l++)
+        if ((src.levelMask >> l) & 1u) launch_fast(h, src, nimg, st, G.lv[l].cellBase, G.lv[l].cellBase + G.lv[l].nCells);
+    } else {
+      launch_fast(h, src, nimg, st, 0, G.totalCells);
+    }
     h->timer.end(st);
   }
-  if (!h->out_pending) {   // end of the call on the main stream: the caller's output event, or our own — next call's prefetch gate
+  // The blur only depends on the pyramid, but it is forked onto the auxiliary stream AFTER FAST so that the throughput-bound blur
+  // fills the machine while the latency-bound quad-tree (one workgroup per frame x level) runs beside it; forked before FAST the two
+  // throughput-bound kernels merely shared the CUs.  One record behind FAST serves the caller and the blur's fork.
+  hipStream_t bst = h->overlap ? h->aux_stream : st;
+  hipEvent_t ev_fastdone = h->after_fast_event ? h->after_fast_event : h->ev_fork;
+  if (h->after_fast_event || h->overlap) DVS_HIP(hipEventRecord(ev_fastdone, st));
+
+  // 3. quad-tree (latency-bound: launched first so that its workgroups become resident ahead of the blur's).  After a deferred stage
+  //    it takes the next of the three level keypoint sets: stages k - 1 and k - 2 may still read theirs; stage k - 3 wrote its event
+  //    before the level chain of THIS batch started, which this call's FAST waited for.
+  if (pend) { h->lset = (h->lset + 1) % 3; h->d_lvlkp = h->d_lvlkp3[h->lset]; h->d_lvlcount = h->d_lvlcount3[h->lset]; }
+  // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames); beyond,
+  // two 256-thread workgroups per CU run beside the blur and a pipelined caller's match, and the wave slots 512 threads hold cost
+  // those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 / 384 threads: 0.729 / 0.690)
+  const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
+  h->timer.begin(DVS_STAGE_OCTREE, st);
+  hipLaunchKernelGGL(k_octree, dim3(nimg, G.nlevels), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
+                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
+  h->timer.end(st);
+
+  // 4. blur
+  if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
+  else if (h->guard_event) DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
+  hipEvent_t late_guard = bst != st ? h->guard_event : nullptr;   // still set only for a deferring call (see above)
+  h->guard_event = nullptr;   // one-shot
+  h->timer.begin(DVS_STAGE_BLUR, bst);
+  launch_blur(h, src, nimg, bst, cascade);
+  h->timer.end(bst);
+
+  // 5. orientation + descriptors + output records
+  hipStream_t dst = st;
+  if (will_defer) {
+    // the stage follows the blur on the auxiliary stream and the main stream is NOT joined: the next call's FAST (vector-ALU bound,
+    // light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the caller's output event.
+    dst = bst;
+    DVS_HIP(hipEventRecord(h->ev_oct, st));
+    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+    if (late_guard) DVS_HIP(hipStreamWaitEvent(bst, late_guard, 0));   // the caller's readers of the output buffers
+  } else if (bst != st) {
+    DVS_HIP(hipEventRecord(h->ev_blur, bst));
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));
+  }
+  h->timer.begin(DVS_STAGE_DESCRIBE, dst);
+  hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, dst, h->d_geom, src, h->d_blur,
+                     h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
+  h->timer.end(dst);
+  if (will_defer) {
+    h->ev_out = h->ev_outs[h->out_gen & 1];
+    h->out_gen++;
+    DVS_HIP(hipEventRecord(h->ev_out, dst));
+    DVS_HIP(hipEventRecord(h->output_event, dst));
+    h->out_pending = true;
+    h->gate_event = nullptr;   // the next call's chain is gated on ev_outs (launch_prefetch)
+  } else {   // end of the call on the main stream: the caller's output event, or our own — the next call's prefetch gate
     h->gate_event = (may_defer && h->output_event) ? h->output_event : h->ev_end;
     DVS_HIP(hipEventRecord(h->gate_event, st));
-  } else {
-    h->gate_event = nullptr;   // deferred: the next call gates on ev_out
   }
   DVS_HIP(hipGetLastError());
   h->last_nimg = nimg;
@@ -943,70 +812,39 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   if (ksum > 257) { delete h; set_error("gauss_kernel sum %d would overflow the Q8.8 row buffer", ksum); return DVS_ERR_ARG; }
   h->device = device;
   h->max_batch = params->max_batch > 0 ? params->max_batch : 1;
-  hipError_t e;
-  {
-    int plo = 0, phi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-    const char* mp = getenv("DVS_MAIN_PRIO");
-    const int v = mp ? atoi(mp) : 0;
-    e = hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, v > 0 ? phi : (v < 0 ? plo : 0));
-  }
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
-  // diagnostics, read once: DVS_NO_OVERLAP=1 every stage alone on the stream; DVS_CASCADE=1 / 0 all-levels-in-one-launch pyramid
-  // always / never (default: for <= 4 frames);
-  // DVS_FAST_TAIL=l first level of the merged FAST tail launch (in-step pyramid only)
-  if (const char* e2 = getenv("DVS_NO_OVERLAP")) h->overlap = !(e2[0] == '1');
-  if (const char* e3 = getenv("DVS_CASCADE")) h->env_cascade = e3[0] == '1' ? 1 : 0;
-  if (const char* e4 = getenv("DVS_FAST_TAIL")) h->env_fast_tail = atoi(e4);
-  if (const char* e5 = getenv("DVS_FAST_V")) h->env_fast_v = atoi(e5);
-  if (const char* e5 = getenv("DVS_HOST_POLL")) h->env_host_poll = atoi(e5);
+  // The switches of this handle, read once (see the struct).  DVS_NO_OVERLAP=1 = dvs_orb_set_overlap(h, 0) from the start: every
+  // stage alone on the main stream.
+  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0;
+  h->env_cascade = env_int("DVS_CASCADE", -1);
+  h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
+  h->env_host_poll = env_int("DVS_HOST_POLL", 1);
+  h->env_oct_threads = env_int("DVS_OCT_T", 0);
+  if (h->env_oct_threads != 0 && h->env_oct_threads != kOctT && h->env_oct_threads != kOctTMax) h->env_oct_threads = 0;
   // byte-aligned tile origin (probed once per process and device): every cell's interior then starts on a dword of the tile, so a
   // 36-pixel interior is always 9 column groups = 7 rows per trip of the rejection loop (aligned origin: 9 or 10 groups by the
-  // cell's phase, 6 rows per trip for the latter).  FAST alone 0.295 -> 0.287 ms per 64 frames.  DVS_FAST_BYTE_DMA=0 turns it off.
-  h->fast_byte_dma = probe_byte_dma(device, h->stream);
-  if (const char* e9 = getenv("DVS_FAST_BYTE_DMA")) h->fast_byte_dma = h->fast_byte_dma && atoi(e9);
-  if (const char* e6 = getenv("DVS_DESC_SPLIT")) h->env_desc_split = atoi(e6);
-  if (const char* e7 = getenv("DVS_OCT_T")) h->env_oct_threads = atoi(e7);
-  if (const char* eh = getenv("DVS_HOPS")) h->env_hops = atoi(eh);
-  if (const char* eg = getenv("DVS_GRAPH")) h->env_graph = atoi(eg);
-  if (const char* e8 = getenv("DVS_BLUR_MFMA")) h->env_blur_mfma = atoi(e8);
-  if (const char* e8 = getenv("DVS_PF_AFTER_FAST")) h->env_pf_after_fast = atoi(e8);
-  if (const char* e9 = getenv("DVS_LOOKAHEAD")) h->env_lookahead = atoi(e9);
+  // cell's phase, 6 rows per trip for the latter).  FAST alone 0.295 -> 0.287 ms per 64 frames.
+  h->fast_byte_dma = probe_byte_dma(device, h->stream) && env_int("DVS_FAST_BYTE_DMA", 1);
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  auto env_prio = [&](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return v > 0 ? prio_hi : (v < 0 ? prio_lo : 0); };
   // the auxiliary stream carries the blur (and a deferred descriptor stage): LOWEST dispatch priority, so that the quad-tree
   // workgroups launched at the same moment on the main stream all become resident first — with the blur's workgroups dispatched
   // ahead of them some quad-tree workgroups started 90 us late and the kernel took 170 us instead of 110 (64 frames per step:
-  // 0.628 -> 0.592 ms, neutral below 64; DVS_AUX_PRIO=1 restores round 1's highest priority)
-  if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, env_prio("DVS_AUX_PRIO", -1)) != hipSuccess ||
-      hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, env_prio("DVS_PF_PRIO", 1)) != hipSuccess ||
-      (h->env_lookahead && create_fa_stream(&h->fa_stream, prio_lo, prio_hi) != hipSuccess) ||
-      hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_back[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_desc, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_outs[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_outs[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_end, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_oct, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_pf2[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_pf2[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fast, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
+  // 0.628 -> 0.592 ms, neutral below 64)
+  bool ok = hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+            hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  hipEvent_t* evs[] = {&h->ev_fork, &h->ev_blur, &h->ev_start, &h->ev_chain_gate, &h->ev_pf2[0], &h->ev_pf2[1], &h->ev_outs[0], &h->ev_outs[1],
+                       &h->ev_oct, &h->ev_end};
+  for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+  for (int l = 1; l < params->nlevels; l++) ok = ok && hipEventCreateWithFlags(&h->ev_level[l], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     dvs_orb_destroy(h);
-    set_error("aux stream / event creation failed");
+    set_error("stream / event creation failed");
     return DVS_ERR_HIP;
   }
-  for (int l = 1; l < params->nlevels; l++)
-    if (hipEventCreateWithFlags(&h->ev_level[l], hipEventDisableTiming) != hipSuccess) {
-      dvs_orb_destroy(h);
-      set_error("event creation failed");
-      return DVS_ERR_HIP;
-    }
   build_ctor_tables(h);
   *out = h;
   return DVS_OK;
@@ -1015,26 +853,14 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
 void dvs_orb_destroy(dvs_orb* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
-  if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
-  if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
-  if (h->fa_stream) (void)hipStreamSynchronize(h->fa_stream);
+  hipStream_t streams[] = {h->stream, h->aux_stream, h->pf_stream};
+  for (hipStream_t q : streams) if (q || q == h->stream) (void)hipStreamSynchronize(q);
   h->timer.resolve();
   free_workspace(h);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
-  if (h->fa_stream) (void)hipStreamDestroy(h->fa_stream);
-  if (h->ev_front) (void)hipEventDestroy(h->ev_front);
-  for (hipEvent_t e : h->ev_back) if (e) (void)hipEventDestroy(e);
-  if (h->ev_pyr) (void)hipEventDestroy(h->ev_pyr);
-  if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
-  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-  if (h->ev_fast) (void)hipEventDestroy(h->ev_fast);
-  if (h->ev_desc) (void)hipEventDestroy(h->ev_desc);
-  for (hipEvent_t e : h->ev_outs) if (e) (void)hipEventDestroy(e);
-  if (h->ev_end) (void)hipEventDestroy(h->ev_end);
-  if (h->ev_oct) (void)hipEventDestroy(h->ev_oct);
-  for (hipEvent_t e : h->ev_pf2) if (e) (void)hipEventDestroy(e);
+  hipEvent_t evs[] = {h->ev_fork, h->ev_blur, h->ev_start, h->ev_chain_gate, h->ev_pf2[0], h->ev_pf2[1], h->ev_outs[0], h->ev_outs[1], h->ev_oct, h->ev_end};
+  for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -1055,8 +881,7 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   DVS_HIP(hipStreamSynchronize(h->aux_stream));
   DVS_HIP(hipStreamSynchronize(h->pf_stream));
-  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));
-  h->la_valid = false; h->pf_valid = false; h->pf_joined = false;
+  h->pf_valid = false; h->pf_joined = false;
   h->out_pending = false;   // everything, a deferred descriptor stage included, has completed above
   h->overlap = on != 0;
   return DVS_OK;
@@ -1076,7 +901,6 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->out_pending) { DVS_HIP(hipStreamSynchronize(h->aux_stream)); h->out_pending = false; }   // a deferred descriptor stage
   DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
-  if (h->fa_stream) DVS_HIP(hipStreamSynchronize(h->fa_stream));  // ... and so may its FAST
   return DVS_OK;
 }
 
@@ -1207,61 +1031,14 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
   DVS_TRY(ensure_workspace(h, rows, cols));
   const Geom& G = h->geom;
   const int cap = G.outCap;
-  if (nimg == 1 && h->env_graph && h->overlap && !h->timer.on && !h->out_pending) {
-    // one frame: replay the captured graph of exactly this call (same buffers every time: the frame goes through pinned staging)
-    if (!h->h_img) DVS_HIP(hipHostMalloc((void**)&h->h_img, (size_t)rows * cols));
-    for (int r = 0; r < rows; r++) memcpy(h->h_img + (size_t)r * cols, imgs[0] + (size_t)r * step, (size_t)cols);
-    if (!h->g_exec || h->g_rows != rows || h->g_cols != cols) {
-      if (h->g_exec) { (void)hipGraphExecDestroy(h->g_exec); h->g_exec = nullptr; }
-      DVS_HIP(hipStreamSynchronize(h->stream));
-      h->pf_valid = false; h->la_valid = false; h->pf_joined = false;
-      hipGraph_t graph = nullptr;
-      dvs_status rc = DVS_OK;
-      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        hipError_t e = hipMemcpy2DAsync(h->d_pyr + G.lv[0].off, G.lv[0].pitch, h->h_img, cols, cols, rows, hipMemcpyHostToDevice, h->stream);
-        ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr, ~0u, 0};
-        if (e == hipSuccess) rc = enqueue_extract(h, src, 1, h->d_kps, h->d_desc, cap, h->d_nout);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->h_nout, h->d_nout, 4, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)cap * sizeof(dvs_keypoint), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream);
-        const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
-        h->gate_event = nullptr;   // the call's end event was recorded inside the capture: not waitable outside it
-        if (e == hipSuccess && ee == hipSuccess && rc == DVS_OK && graph && hipGraphInstantiate(&h->g_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-          h->g_rows = rows; h->g_cols = cols;
-        } else {
-          h->g_exec = nullptr;
-        }
-        if (graph) (void)hipGraphDestroy(graph);
-      }
-      (void)hipGetLastError();
-      if (!h->g_exec) h->env_graph = 0;   // capture is not available here: plain launches from now on
-    }
-    if (h->g_exec) {
-      DVS_HIP(hipGraphLaunch(h->g_exec, h->stream));
-      DVS_HIP(hipStreamSynchronize(h->stream));
-      h->last_nimg = 1;
-      h->gate_event = nullptr;
-      const int n = h->h_nout[0];
-      if (n > capacity) { set_error("frame 0: %d keypoints > capacity %d", n, capacity); return DVS_ERR_CAPACITY; }
-      n_out[0] = n;
-      memcpy(kps, h->h_kps, (size_t)n * sizeof(dvs_keypoint));
-      memcpy(desc, h->h_desc, (size_t)n * 32);
-      return DVS_OK;
-    }
-  }
   for (int b0 = 0; b0 < nimg; b0 += h->max_batch) {
     const int nb = std::min(h->max_batch, nimg - b0);
     // level 0 staged into the frame's pyramid block (the reference copies it too: copyMakeBorder, :1189)
-    static const bool timing = getenv("DVS_HOST_TIMING") != nullptr;
-    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double T0 = timing ? now() : 0.0;
     for (int i = 0; i < nb; i++)
       DVS_HIP(hipMemcpy2DAsync(h->d_pyr + (uint64_t)i * G.frameBytes + G.lv[0].off, G.lv[0].pitch, imgs[b0 + i], step, cols, rows,
                                hipMemcpyHostToDevice, h->stream));
-    const double T1 = timing ? now() : 0.0;
     ImgSrc src{h->d_pyr + G.lv[0].off, (uint64_t)G.lv[0].pitch, G.frameBytes, h->d_pyr, ~0u, 0};
     DVS_TRY(enqueue_extract(h, src, nb, h->d_kps, h->d_desc, cap, h->d_nout));
-    const double T2 = timing ? now() : 0.0;
     if (h->env_host_poll) {
       // results by k_export_host into the pinned block; poll its sequence number (bounded spin, then the stream wait)
       static_assert(sizeof(dvs_keypoint) == 28, "k_export_host copies keypoints as 7 dwords");
@@ -1283,22 +1060,12 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
       DVS_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nb * cap * 32, hipMemcpyDeviceToHost, h->stream));
       DVS_HIP(hipStreamSynchronize(h->stream));
     }
-    const double T3 = timing ? now() : 0.0;
     for (int i = 0; i < nb; i++) {
       const int n = h->h_nout[i];
       if (n > capacity) { set_error("frame %d: %d keypoints > capacity %d", b0 + i, n, capacity); return DVS_ERR_CAPACITY; }
       n_out[b0 + i] = n;
       memcpy(kps + (size_t)(b0 + i) * capacity, h->h_kps + (size_t)i * cap, (size_t)n * sizeof(dvs_keypoint));
       memcpy(desc + (size_t)(b0 + i) * capacity * 32, h->h_desc + (size_t)i * cap * 32, (size_t)n * 32);
-    }
-    if (timing) {
-      const double T4 = now();
-      h->host_t[0] += T1 - T0; h->host_t[1] += T2 - T1; h->host_t[2] += T3 - T2; h->host_t[3] += T4 - T3;
-      if (++h->host_calls % 64 == 0) {
-        fprintf(stderr, "[dvs] host entry, mean of 64 calls: upload enqueue %.1f us, kernels enqueue %.1f us, results + wait %.1f us, copy out %.1f us\n",
-                h->host_t[0] / 64, h->host_t[1] / 64, h->host_t[2] / 64, h->host_t[3] / 64);
-        h->host_t[0] = h->host_t[1] = h->host_t[2] = h->host_t[3] = 0;
-      }
     }
   }
   return DVS_OK;
@@ -1344,25 +1111,6 @@ dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int3
   *n = cnt;
   if (cnt > cap) return DVS_ERR_CAPACITY;
   return read_packed(h, h->d_pts + (uint64_t)frame * h->geom.ptsPerFrame + h->geom.lv[level].ptsOff, cnt, xys);
-}
-
-int32_t dvs_test_graph_active(const dvs_orb* h) { return h && h->g_exec ? 1 : 0; }
-
-dvs_status dvs_test_octree_stamps_frame(dvs_orb* h, int32_t frame, int32_t level, uint64_t* out64) {
-  DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels && frame >= 0 && frame < h->max_batch);
-  DVS_HIP(hipSetDevice(h->device));
-  const LevelGeom& L = h->geom.lv[level];
-  DVS_HIP(hipMemcpy(out64, h->d_nodeof + (uint64_t)frame * h->geom.ptsPerFrame + ((L.ptsOff + L.ptsCap - 128) & ~1ull), 64 * 8, hipMemcpyDeviceToHost));
-  return DVS_OK;
-}
-
-dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64) {
-  DVS_ARG(h && out64 && h->d_geom && level >= 0 && level < h->geom.nlevels);
-  DVS_HIP(hipSetDevice(h->device));
-  DVS_HIP(hipStreamSynchronize(h->stream));
-  const LevelGeom& L = h->geom.lv[level];
-  DVS_HIP(hipMemcpy(out64, h->d_nodeof + ((L.ptsOff + L.ptsCap - 128) & ~1ull), 64 * 8, hipMemcpyDeviceToHost));
-  return DVS_OK;
 }
 
 dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {

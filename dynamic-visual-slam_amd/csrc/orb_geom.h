@@ -46,11 +46,9 @@ struct Geom {
   int32_t fastRows;     // max cell height (rows of the LDS tile)
   int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
   int32_t fastTile;     // bytes of the staged tile, a multiple of 256 (whole LDS-DMA wave-instructions)
-  int32_t fastXcd;      // 1: FAST workgroups are dealt to the XCDs frame by frame (DVS_FAST_XCD=0: round-robin)
   int32_t fastByteDma;  // 1: the LDS-DMA takes byte-aligned global addresses here (checked at start-up): tiles start 1 column left of the cell
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
-  int32_t debug;        // diagnostics only (DVS_DEBUG env): bit 0 = skip the quad-tree sort (results invalid)
   int32_t gk[7];
   int32_t umax[16];
   // intensity-centroid patch as per-lane byte weights: lane = 2*row + half covers 16 bytes of one patch row;

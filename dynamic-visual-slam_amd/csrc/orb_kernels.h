@@ -8,7 +8,7 @@
 //   k_octree                             candidate gather + quad-tree distribution, workgroup per (frame, level)
 //                                                                                   ORBextractor.cpp:555-779, 874-890
 //   k_blur_stream / k_blur               7x7 fixed-point Gaussian of every level    ORBextractor.cpp:1132-1133
-//   k_describe<0> | <1> + <2>            IC orientation + steered BRIEF + output    ORBextractor.cpp:76-146, 1142-1163
+//   k_describe                           IC orientation + steered BRIEF + output    ORBextractor.cpp:76-146, 1142-1163
 // The second name of a pair is the generic variant for inputs the fast one does not take (rows not dword aligned).
 //
 // Everything is integer or explicitly-rounded float32/float64 arithmetic; the file is compiled with
@@ -569,41 +569,6 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
 //   * survivors (~17 % of pixels) are compacted IN ORDER by ballots, scored exactly, and the corners
 //     (~3 %) compacted again; NMS and the threshold fallback then touch only that short list.
 // ---------------------------------------------------------------------------------------------
-template <int P>
-__device__ __forceinline__ int fast_corner_score_p(const u8* c, int v) {
-  // cornerScore<16> on the RAW ring samples r_k (no per-sample subtraction): with d_k = v - r_k,
-  //   max over 9-arcs of min(d)  = v - min over arcs of max(r)   and   max over arcs of min(-d) = max over arcs of min(r) - v,
-  // so score = max(v - min_k hi9_k, max_k lo9_k - v) - 1 where hi9 / lo9 are the 9-window max / min (3 + 3 + 3 by v_max3 / v_min3).
-  const int o[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,  -P + 3,  -2 * P + 2,  -3 * P + 1,
-                     -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3,   2 * P - 2,   3 * P - 1};
-  int r[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = (int)c[o[k]];
-  int lo3[16], hi3[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo3[k] = min(min(r[k], r[(k + 1) & 15]), r[(k + 2) & 15]);
-    hi3[k] = max(max(r[k], r[(k + 1) & 15]), r[(k + 2) & 15]);
-  }
-  int lo9[16], hi9[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo9[k] = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
-    hi9[k] = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
-  }
-  // 16 -> 1 by 3-operand trees
-  int mn[6], mx[6];
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    mn[k] = min(min(hi9[3 * k], hi9[3 * k + 1]), hi9[3 * k + 2]);
-    mx[k] = max(max(lo9[3 * k], lo9[3 * k + 1]), lo9[3 * k + 2]);
-  }
-  mn[5] = hi9[15]; mx[5] = lo9[15];
-  const int minHi = min(min(min(mn[0], mn[1]), mn[2]), min(min(mn[3], mn[4]), mn[5]));
-  const int maxLo = max(max(max(mx[0], mx[1]), mx[2]), max(max(mx[3], mx[4]), mx[5]));
-  return max(v - minHi, maxLo - v) - 1;
-}
-
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -622,168 +587,9 @@ __global__ void k_probe_lds_dma(const u8* __restrict__ src, uint32_t* __restrict
   out[lane] = lds[lane];
 }
 
-// round-1 form of the kernel (register staging, one survivor per lane in the score stage); kept selectable (DVS_FAST_V=1) as the
-// A/B reference of the round-2 instruction diet below
-template <int P>
-__global__ __launch_bounds__(256) void k_fast_wave_r1(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
-                                                      uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  const int lane = lane_id();
-  const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
-  const int ci = cell0 + blockIdx.x * 4 + wvi;                        // every size derived from them stay on the scalar unit
-  if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
-  const int f = blockIdx.y;
-  unsigned char* base = fsm + wvi * g->fastWaveLds;
-  const int tileBytes = g->fastRows * P;
-  u8* tile = base;
-  u8* score = base + tileBytes;
-  uint16_t* work = reinterpret_cast<uint16_t*>(base + 2 * tileBytes);
-  const Cell cell = cells[ci];
-  const LevelGeom& L = g->lv[cell.level];
-  int pitch;
-  const u8* img = level_ptr(g, src, f, cell.level, pitch);
-  const int cw = cell.cw, ch = cell.ch;
-  const int iw = cw - 6, ih = ch - 6;
-  int* countOut = cellCount + (uint64_t)f * g->totalCells + ci;
-  if (iw <= 0 || ih <= 0) { if (lane == 0) *countOut = 0; return; }
-  const int xa = cell.x0 & ~3, ox = cell.x0 - xa;
-  // 1. stage (dword granularity, byte phase preserved) + clear the score tile
-  {
-    const int wpr = (ox + cw + 3) >> 2;  // <= P/4
-    const int kr = 64 / wpr;
-    const int myr = lane / wpr, myc = lane - myr * wpr;
-    const u8* rb = img + (uint64_t)cell.y0 * pitch + xa;
-    uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
-    if (myr < kr)
-      for (int r = myr; r < ch; r += kr) t32[r * (P / 4) + myc] = *reinterpret_cast<const uint32_t*>(rb + (uint64_t)r * pitch + 4 * myc);
-    uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
-    for (int i = lane; i < ch * (P / 4); i += 64) s32[i] = 0;
-  }
-  wave_lds_fence();
-  const int tmin = g->minTh, tini = g->iniTh;
-  const unsigned long long ltmask = (1ull << lane) - 1ull;
-  // 2. rejection test, 4 pixels per lane
-  const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
-  const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
-  const int total = ng * ih;
-  const float invng = 1.0f / (float)ng;
-  int nwork = 0;
-  const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
-  for (int i0 = 0; i0 < total; i0 += 64) {
-    const int idx = i0 + lane;
-    const bool valid = idx < total;
-    const int row = valid ? (int)(((float)idx + 0.5f) * invng) : 0;
-    const int gi = valid ? mad_i24(row, -ng, idx) : 0;  // idx - row * ng; 24-bit forms: v_mul_lo_u32 / v_mad_u64_u32 run at 1/4 rate
-    const int y = row + 3;
-    const int wcol = g0 + gi;  // word column
-    const uint32_t* rp = t32 + mad_i24(y, P / 4, wcol);
-    const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
-    const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
-    const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
-    const uint32_t Lp2 = rp[2 * (P / 4) - 1], Op2 = rp[2 * (P / 4)], Rp2 = rp[2 * (P / 4) + 1];
-    const uint32_t s4 = __builtin_amdgcn_alignbyte(R0, O0, 3);    // ring 4  ( 3, 0)
-    const uint32_t s12 = __builtin_amdgcn_alignbyte(O0, L0, 1);   // ring 12 (-3, 0)
-    const uint32_t s2 = __builtin_amdgcn_alignbyte(Rp2, Op2, 2);  // ring 2  ( 2, 2)
-    const uint32_t s14 = __builtin_amdgcn_alignbyte(Op2, Lp2, 2); // ring 14 (-2, 2)
-    const uint32_t s6 = __builtin_amdgcn_alignbyte(Rm2, Om2, 2);  // ring 6  ( 2,-2)
-    const uint32_t s10 = __builtin_amdgcn_alignbyte(Om2, Lm2, 2); // ring 10 (-2,-2)
-    // packed 16-bit evaluation, two pixels per instruction: with r_k the raw ring samples,
-    //   all four opposite pairs hold a darker sample   <=>  max_pairs(min(r_k, r_k+8)) < v - t
-    //   all four opposite pairs hold a brighter sample <=>  min_pairs(max(r_k, r_k+8)) > v + t
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    auto lo2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); };
-    auto hi2 = [](uint32_t w) -> s16x2 { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); };
-    const s16x2 T2 = {(short)tmin, (short)tmin};
-    uint32_t sgn[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
-      auto un = [&](uint32_t w) -> s16x2 { return hh ? hi2(w) : lo2(w); };
-      const s16x2 v2 = un(O0);
-      const s16x2 r0 = un(Op3), r8 = un(Om3), r4 = un(s4), r12 = un(s12), r2 = un(s2), r10 = un(s10), r6 = un(s6), r14 = un(s14);
-      const s16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
-                                                 __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
-      const s16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
-                                                 __builtin_elementwise_min(__builtin_elementwise_max(r2, r10), __builtin_elementwise_max(r6, r14)));
-      const s16x2 e1 = (mn + T2) - v2;   // < 0  <=>  mn < v - t
-      const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
-      sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
-    }
-    bool pass[4];
-    {
-      const int col0 = wcol * 4;
-      pass[0] = valid && col0 >= cx0 && col0 < cx1 && (sgn[0] & 0x8000u);
-      pass[1] = valid && col0 + 1 >= cx0 && col0 + 1 < cx1 && (sgn[0] & 0x80000000u);
-      pass[2] = valid && col0 + 2 >= cx0 && col0 + 2 < cx1 && (sgn[1] & 0x8000u);
-      pass[3] = valid && col0 + 3 >= cx0 && col0 + 3 < cx1 && (sgn[1] & 0x80000000u);
-    }
-    const unsigned long long b0 = __ballot(pass[0]), b1 = __ballot(pass[1]), b2 = __ballot(pass[2]), b3 = __ballot(pass[3]);
-    auto below = [](unsigned long long b) -> int {  // set bits of b in lanes below this one: v_mbcnt_lo + v_mbcnt_hi
-      return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-    };
-    int pos = nwork + below(b0) + below(b1) + below(b2) + below(b3);
-    const int cbase = mad_i24(y, P, wcol * 4);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (pass[j]) work[pos++] = (uint16_t)(cbase + j);
-    nwork += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-  }
-  wave_lds_fence();
-  // 3. exact score for the survivors; corners (score >= minTh) are re-compacted in place, still row-major
-  int ncorner = 0;
-  for (int e0 = 0; e0 < nwork; e0 += 64) {
-    const int e = e0 + lane;
-    const bool valid = e < nwork;
-    const int c = valid ? work[e] : 0;
-    int sc = 0;
-    if (valid) sc = fast_corner_score_p<P>(tile + c, (int)tile[c]);
-    const bool isc = valid && sc >= tmin;
-    if (isc) score[c] = (u8)sc;
-    const unsigned long long b = __ballot(isc);
-    wave_lds_fence();
-    if (isc) work[ncorner + __popcll(b & ltmask)] = (uint16_t)c;
-    ncorner += __popcll(b);
-  }
-  wave_lds_fence();
-  // 4. NMS on the corner list: bit 14 = strict 3x3 maximum, bit 15 = ... and score >= iniTh
-  bool any20 = false;
-  for (int e0 = 0; e0 < ncorner; e0 += 64) {
-    const int e = e0 + lane;
-    bool hi = false;
-    if (e < ncorner) {
-      const int c = work[e];
-      const int sc = score[c];
-      const bool ismax = sc > score[c - 1] && sc > score[c + 1] && sc > score[c - P - 1] && sc > score[c - P] && sc > score[c - P + 1] &&
-                         sc > score[c + P - 1] && sc > score[c + P] && sc > score[c + P + 1];
-      hi = ismax && sc >= tini;
-      work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0) | (hi ? 0x8000 : 0));
-    }
-    any20 = any20 || (__ballot(hi) != 0ull);
-  }
-  wave_lds_fence();
-  // 5. ordered emission
-  uint32_t* out = cand + (uint64_t)f * g->candPerFrame + L.candOff + (uint64_t)cell.slot * L.cellCap;
-  const int cap = L.cellCap;
-  const int selbit = any20 ? 0x8000 : 0x4000;
-  int nout = 0;
-  for (int e0 = 0; e0 < ncorner; e0 += 64) {
-    const int e = e0 + lane;
-    const int w = e < ncorner ? work[e] : 0;
-    const bool sel = (w & selbit) != 0;
-    const unsigned long long b = __ballot(sel);
-    if (sel) {
-      const int c = w & 0x3fff;
-      const int yy = c / P, xx = c - yy * P - ox;  // sub-image coordinates
-      const int rank = nout + __popcll(b & ltmask);
-      if (rank < cap) out[rank] = pack_pt(xx + cell.j * L.wCell, yy + cell.i * L.hCell, score[c]);
-    }
-    nout += __popcll(b);
-  }
-  if (lane == 0) *countOut = min(nout, cap);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Round-2 form (the instruction diet).  Same phases and results as k_fast_wave_r1; what changed, with the
-// wave-level VALU instructions per cell of the two (hipcc -S listings):
+// What keeps the instruction count down (hipcc -S listings; round 1's register-staged, one-survivor-per-lane form of the same
+// phases retired 36 % more wave-level VALU instructions per cell):
 //   * staging by LDS-DMA: the tile's LDS image is dword-linear in lane order, so each global_load_lds_dword wave-instruction
 //     lands 64 consecutive dwords with no VGPR round trip (no ds_write, no per-row 64-bit address arithmetic); the score tile
 //     is cleared with 16-byte stores
@@ -861,7 +667,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   // frames -> XCDs contiguously (xcd_contiguous_id): the workgroups of one frame — whose cells share halo rows and 128-byte lines —
   // then meet in ONE L2 instead of eight (HBM fetch 2.1x -> see profiles of the algorithmic bytes; FAST is not fetch-bound, the
   // time is unchanged)
-  const int xid = g->fastXcd ? xcd_contiguous_id() : (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int xid = xcd_contiguous_id();
   const int f = xid / (int)gridDim.x;
   const int ci = cell0 + (xid - f * (int)gridDim.x) * 4 + wvi;       // every size derived from them stay on the scalar unit
   if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
@@ -1303,13 +1109,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     return;
   }
   const LevelGeom& L = g->lv[level];
-  // diagnostics (DVS_DEBUG bit 1): thread 0 of frame 0 stamps the 100 MHz wall clock at phase boundaries into the unused tail of
-  // the level's global node-of-point block (dvs_test_octree_stamps)
-  unsigned long long* stamps = (unsigned long long*)(nodeOfAll + (uint64_t)((g->debug & 4) ? f : 0) * g->ptsPerFrame + ((L.ptsOff + L.ptsCap - 128) & ~1ull));
-  int si = 0;
-  const bool stamping = (g->debug & 2) && tid == 0 && (f == 0 || (g->debug & 4));   // bit 2: every frame stamps (into its own block)
-#define QT_STAMP(id) do { if (stamping && si < 62) { stamps[1 + si] = ((unsigned long long)(id) << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFull); si++; stamps[0] = si; } } while (0)
-  QT_STAMP(1);
 
   QtShared sh;
   {
@@ -1390,7 +1189,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   const int n = s_n;
   const int N = L.N;
   int cur = 0;
-  QT_STAMP(2);
 
   // ---- roots (:559-601) ------------------------------------------------------------------------
   {
@@ -1458,15 +1256,12 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     }
     __syncthreads();
   }
-
-  QT_STAMP(3);
   // ---- main loop ---------------------------------------------------------------------------------
   bool finish = (n == 0);
   while (!finish) {
     const int S = s_S;
     // full sweep: split every multi-point node (:622-681)
     qt_count_children(sh.nodes_(cur), S, sh.childCnt, pts, nodeOf, n);
-    QT_STAMP(4);
     int nExpandLocal = 0;
     {
       // children block: node k's children sit in front of the children of all earlier nodes
@@ -1508,9 +1303,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       __syncthreads();
       nUnsplit = s_c;
     }
-    QT_STAMP(5);
     qt_rebuild(sh, cur, S, T, pts, nodeOf, n, wsum);
-    QT_STAMP(6);
     cur ^= 1;
     int Snew = T + nUnsplit;
     if (tid == 0) s_S = Snew;
@@ -1520,7 +1313,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
 
     // ordered phase (:692-753)
     int m = qt_build_expand_list(sh, cur, T, wsum);
-    QT_STAMP(7);
     while (!finish) {
       const int Sb = s_S;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
@@ -1532,9 +1324,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       }
       for (int k = tid; k < Sb; k += OCT_T) sh.flag[k] = 0;
       __syncthreads();
-      QT_STAMP(8);
-      if (!(g->debug & 1)) qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
-      QT_STAMP(9);
+      qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
       if (tid == 0) s_c = 0;
@@ -1566,9 +1356,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
         sh.posArr[k] = Tm - sh.ecum[r];
       }
       __syncthreads();
-      QT_STAMP(10);
       qt_rebuild(sh, cur, Sb, Tm, pts, nodeOf, n, wsum);
-      QT_STAMP(11);
       cur ^= 1;
       const int Sn = Tm + (Sb - M);
       if (tid == 0) s_S = Sn;
@@ -1577,8 +1365,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       m = qt_build_expand_list(sh, cur, Tm, wsum);
     }
   }
-
-  QT_STAMP(12);
   // ---- best point per node (:757-776), list order = output order ----------------------------------
   const int S = (n == 0) ? 0 : s_S;
   QNode* nodes = sh.nodes_(cur);
@@ -1602,8 +1388,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     if (k < N + 4) outp[k] = pts[i];
   }
   if (tid == 0) lvlKpCount[f * g->nlevels + level] = min(S, N + 4);
-  QT_STAMP(13);
-#undef QT_STAMP
 }
 
 #undef OCT_T
@@ -1969,14 +1753,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 //    samples are LDS byte reads.  The pattern is unpacked to floats once per wave.
 constexpr int kDescKP = 8;
 constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinPitch = 48;
-// MODE 0: orientation + descriptors in one launch.  MODE 1 / 2: the same code split at the angle — the orientation half only
-// needs the pyramid and the quad-tree's keypoints, so it can run while the blur is still in flight (it is fetch-bound, the
-// blur VALU-bound), and the descriptor half then only fetches the blurred windows.  orient[slot] = (angle, cos, sin, -).
-template <int MODE>
+// (Round 1 split the kernel at the angle so that the orientation half could run beside the blur; with the deferred descriptor
+// stage of the pipelined schedule that bought nothing — 0.686 vs 0.681 ms per step — and the split was removed.)
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
                                                   const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
-                                                  int* __restrict__ nOut, int capacity, float4* __restrict__ orient) {
+                                                  int* __restrict__ nOut, int capacity) {
   typedef uint4 __attribute__((aligned(1))) uint4u;
   __shared__ __attribute__((aligned(16))) u8 win[4][2][kWinRows * kWinPitch];
   DVS_CHAIN_PRIO();
@@ -1987,7 +1769,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int nl = g->nlevels;
   const int* cnt = lvlKpCount + f * nl;
   const int slot0 = (bx * 4 + wv) * kDescKP;
-  if (MODE != 1 && bx == 0 && threadIdx.x == 0) {
+  if (bx == 0 && threadIdx.x == 0) {
     if (src.slotted) {
       for (int l = 0; l < nl; l++) nOut[f * nl + l] = cnt[l];   // per-level counts of the slotted block
     } else {
@@ -2026,16 +1808,12 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   const int v = prow - kHalfPatch;
   const int pcol = half ? 1 : -kHalfPatch;
   uint4 d[kDescKP];
-  if constexpr (MODE != 2) {
 #pragma unroll
-    for (int i = 0; i < kDescKP; i++) {
-      const u8* ib = DVS_RLP(imgL, i);
-      const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
-      d[i] = *reinterpret_cast<const uint4u*>(ib + (uint32_t)(mul_i24(yi + v, pi) + xi + pcol));  // all terms >= 0, 24-bit product
-    }
+  for (int i = 0; i < kDescKP; i++) {
+    const u8* ib = DVS_RLP(imgL, i);
+    const int pi = DVS_RL(pitchL, i), xi = DVS_RL(x, i), yi = DVS_RL(y, i);
+    d[i] = *reinterpret_cast<const uint4u*>(ib + (uint32_t)(mul_i24(yi + v, pi) + xi + pcol));  // all terms >= 0, 24-bit product
   }
-  float4 ori = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (MODE == 2) ori = orient[(uint64_t)f * g->kpBlock + slot];
   // blurred window of keypoint 0
   const int e0 = lane, e1 = 64 + lane;  // 111 = 37 rows x 3 sixteen-byte pieces
   const int wr0 = e0 / 3, wc0 = e0 - 3 * wr0, wr1 = min(e1 / 3, kWinRows - 1), wc1 = e1 - 3 * (e1 / 3);
@@ -2053,20 +1831,15 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   }
   // a wave's life is one latency chain (slot -> patches / windows -> samples), so every window is requested up front: the
   // first half behind the patches, the second half into the registers the patches free
-  if constexpr (MODE != 1) { DVS_REQUEST_WINDOW(0) DVS_REQUEST_WINDOW(1) DVS_REQUEST_WINDOW(2) DVS_REQUEST_WINDOW(3) }
+  DVS_REQUEST_WINDOW(0) DVS_REQUEST_WINDOW(1) DVS_REQUEST_WINDOW(2) DVS_REQUEST_WINDOW(3)
   // pattern -> floats, once per wave
   float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
-  for (int r = 0; r < 4 && MODE != 1; r++) {
+  for (int r = 0; r < 4; r++) {
     const int pat = reinterpret_cast<const int*>(c_pattern)[64 * r + lane];
     px0[r] = (float)(int8_t)(pat & 0xff); py0[r] = (float)(int8_t)((pat >> 8) & 0xff);
     px1[r] = (float)(int8_t)((pat >> 16) & 0xff); py1[r] = (float)(int8_t)((pat >> 24) & 0xff);
   }
-  float angleK = 0.f, cosK = 0.f, sinK = 0.f;
-  if constexpr (MODE == 2) {
-    angleK = ori.x; cosK = valid ? ori.y : 1.f; sinK = valid ? ori.z : 0.f;   // keypoint lane & 7 (empty slots: any in-window steering)
-    DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7)
-  } else {
   // ---- IC_Angle (ORBextractor.cpp:76-103): membership and the u weights are per-lane byte tables (Geom::icw):
   // sum u*I = sum (u+15)*I - 15 * sum I, exact integers
   const uint32_t* wt = g->icw[lane];
@@ -2085,7 +1858,7 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     q[i] = (int)su - kHalfPatch * (int)sm;
     q[kDescKP + i] = v * (int)sm;
   }
-  if constexpr (MODE == 0) { DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7) }
+  DVS_REQUEST_WINDOW(4) DVS_REQUEST_WINDOW(5) DVS_REQUEST_WINDOW(6) DVS_REQUEST_WINDOW(7)
   // transposing butterfly: after the step with lane bit B, a lane keeps the half of the quantities selected by its bit B
 #define DVS_BFLY(n, o)                                        \
   {                                                           \
@@ -2104,19 +1877,13 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   // lane bits 5 | 4 3 2 = (m01 ? : m10) | keypoint index bits 2 1 0  (bit 4 chose between i and i+4, bit 3 i and i+2, bit 2 i and i+1)
   const int other = __shfl_xor(tot, 32);
   const int m10 = lane < 32 ? tot : other, m01 = lane < 32 ? other : tot;
-  angleK = fast_atan2_deg((float)m01, (float)m10);  // keypoint (lane >> 2) & 7
+  const float angleK = fast_atan2_deg((float)m01, (float)m10);  // keypoint (lane >> 2) & 7
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angleK, factorPI);
-  cosK = gsc::cosf_(arad); sinK = gsc::sinf_(arad);
-  }
+  const float cosK = gsc::cosf_(arad), sinK = gsc::sinf_(arad);
   // ---- steered BRIEF on the blurred level (:107-146), one keypoint after the other
   const unsigned vmask = (unsigned)(__ballot(valid) & 0xffull);
-  if constexpr (MODE == 1) {  // keypoint k's values live in lanes 4k..4k+3
-    const int k = lane >> 2;
-    if (lane < 32 && (lane & 3) == 0 && ((vmask >> k) & 1u)) orient[(uint64_t)f * g->kpBlock + slot0 + k] = make_float4(angleK, cosK, sinK, 0.f);
-    return;
-  }
-  constexpr int kCsLane = MODE == 2 ? 1 : 4;  // lane stride of the per-keypoint (cos, sin, angle)
+  constexpr int kCsLane = 4;  // lane stride of the per-keypoint (cos, sin, angle)
   const int giL = gi;
   auto brief = [&](const int i, const uint4& wa, const uint4& wb) __attribute__((always_inline)) {
     u8* wl = win[wv][i & 1];

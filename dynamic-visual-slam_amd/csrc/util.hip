@@ -56,6 +56,12 @@ StageTimer::~StageTimer() { for (int i = 0; i < npool; i++) hipEventDestroy(pool
 
 }  // namespace dvs
 
+// test hook: one wavefront that holds its stream for `ticks` of the 100 MHz wall clock (bounded: every lane leaves at the deadline)
+__global__ void k_test_spin(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" {
 
 const char* dvs_last_error(void) { return dvs::g_err; }
@@ -103,6 +109,21 @@ dvs_status dvs_event_create(int32_t device, void** out_event) {
   *out_event = e;
   return DVS_OK;
 }
+dvs_status dvs_event_create_timing(int32_t device, void** out_event) {
+  DVS_ARG(out_event);
+  *out_event = nullptr;
+  DVS_TRY(dvs::check_device(device));
+  DVS_HIP(hipSetDevice(device));
+  hipEvent_t e = nullptr;
+  DVS_HIP(hipEventCreate(&e));
+  *out_event = e;
+  return DVS_OK;
+}
+dvs_status dvs_event_elapsed_ms(void* start, void* stop, float* ms) {
+  DVS_ARG(start && stop && ms);
+  DVS_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DVS_OK;
+}
 dvs_status dvs_event_destroy(void* event) {
   if (event) DVS_HIP(hipEventDestroy((hipEvent_t)event));
   return DVS_OK;
@@ -110,6 +131,13 @@ dvs_status dvs_event_destroy(void* event) {
 dvs_status dvs_event_synchronize(void* event) {
   DVS_ARG(event);
   DVS_HIP(hipEventSynchronize((hipEvent_t)event));
+  return DVS_OK;
+}
+dvs_status dvs_event_query(void* event, int32_t* done) {
+  DVS_ARG(event && done);
+  const hipError_t e = hipEventQuery((hipEvent_t)event);
+  if (e != hipSuccess && e != hipErrorNotReady) DVS_HIP(e);
+  *done = e == hipSuccess;
   return DVS_OK;
 }
 dvs_status dvs_event_record(void* event, void* stream) {
@@ -158,6 +186,12 @@ dvs_status dvs_memset(int32_t device, void* dst, int value, size_t bytes) {
   DVS_TRY(dvs::check_device(device));
   DVS_HIP(hipMemset(dst, value, bytes));
   DVS_HIP(hipStreamSynchronize(nullptr));  // complete before the caller enqueues on a non-blocking stream
+  return DVS_OK;
+}
+dvs_status dvs_test_stream_delay(void* stream, int32_t microseconds) {
+  DVS_ARG(microseconds >= 0 && microseconds <= 200000);   // bounded: 0.2 s
+  hipLaunchKernelGGL(k_test_spin, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
 }

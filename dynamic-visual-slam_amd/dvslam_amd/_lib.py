@@ -77,6 +77,10 @@ def lib():
     L.dvs_stream_destroy.argtypes = [vp]
     L.dvs_stream_synchronize.argtypes = [vp]
     L.dvs_event_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_test_stream_delay.argtypes = [vp, i32]
+    L.dvs_event_query.argtypes = [vp, C.POINTER(i32)]
+    L.dvs_event_create_timing.argtypes = [i32, C.POINTER(vp)]
+    L.dvs_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.dvs_event_destroy.argtypes = [vp]
     L.dvs_event_synchronize.argtypes = [vp]
     L.dvs_event_record.argtypes = [vp, vp]
@@ -106,6 +110,7 @@ def lib():
     L.dvs_match_hamming_thresh.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.dvs_comm_get_unique_id.argtypes = [vp]
     L.dvs_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    L.dvs_comm_create_loopback.argtypes = [i32, i32, C.POINTER(vp)]
     L.dvs_comm_destroy.argtypes = [vp]; L.dvs_comm_destroy.restype = None
     L.dvs_comm_rank.argtypes = [vp]
     L.dvs_comm_world.argtypes = [vp]
@@ -121,8 +126,6 @@ def lib():
     L.dvs_test_quartic_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
     L.dvs_test_p3p.argtypes = [vp, vp, vp]
     L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
-    L.dvs_test_octree_stamps.argtypes = [vp, i32, vp]
-    L.dvs_test_octree_stamps_frame.argtypes = [vp, i32, i32, vp]
     L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):
         L.dvs_ba_create.argtypes = [i32, C.POINTER(vp)]
@@ -153,6 +156,18 @@ def device_count():
     return lib().dvs_device_count()
 
 
+def kernel_source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources csrc/*.hip, *.h, *.inc — stamps profile data (profiles/pmc_traffic.json)
+    with the code it was collected on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_PKG, "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stream_create(device=0, high_priority=False):
     """raw hipStream_t (int) created by the library (wrap with torch.cuda.ExternalStream when torch should use it)"""
     out = C.c_void_p()
@@ -165,6 +180,18 @@ def event_create(device=0):
     out = C.c_void_p()
     check(lib().dvs_event_create(device, C.byref(out)))
     return int(out.value)
+
+
+def timing_event_create(device=0):
+    out = C.c_void_p()
+    check(lib().dvs_event_create_timing(device, C.byref(out)))
+    return int(out.value)
+
+
+def event_elapsed_ms(start, stop):
+    ms = C.c_float()
+    check(lib().dvs_event_elapsed_ms(start, stop, C.byref(ms)))
+    return float(ms.value)
 
 
 def stream_synchronize(stream):

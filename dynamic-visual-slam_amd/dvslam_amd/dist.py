@@ -109,6 +109,20 @@ class Comm:
     """dvs_comm of the C-ABI: RCCL communicator + the boundary exchange on a raw HIP stream.  `bcast_id(id_bytes_or_None)`
     is the caller's out-of-band broadcast of the 128-byte unique id from rank 0 (bench.py: torch.distributed's store)."""
 
+    @classmethod
+    def loopback(cls, device: int, world: int):
+        """`world` logical ranks of this process on one device (dvs_comm_create_loopback): a list of Comm, one per rank, each to be
+        driven by its own thread — a collective call blocks until every rank of the group has made it"""
+        from ._lib import lib, check
+        hs = (C.c_void_p * world)()
+        check(lib().dvs_comm_create_loopback(device, world, hs))
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c._L, c._check, c.h, c.rank, c.world = lib(), check, C.c_void_p(hs[r]), r, world
+            out.append(c)
+        return out
+
     def __init__(self, device: int, rank: int, world: int, bcast_id):
         from ._lib import lib, check
         self._L, self._check = lib(), check

@@ -51,6 +51,9 @@ dvs_status dvs_stream_destroy(void* stream);
 dvs_status dvs_event_create(int32_t device, void** out_event);
 dvs_status dvs_event_destroy(void* event);
 dvs_status dvs_event_synchronize(void* event);
+dvs_status dvs_event_create_timing(int32_t device, void** out_event);   /* an event that records a time stamp */
+dvs_status dvs_event_elapsed_ms(void* start, void* stop, float* ms);    /* both created with _create_timing and completed */
+dvs_status dvs_event_query(void* event, int32_t* done);   /* *done = 1 when everything recorded before the event has completed */
 dvs_status dvs_event_record(void* event, void* stream);
 dvs_status dvs_stream_wait_event(void* stream, void* event);
 /* "gfx950" etc. for the given device, "" on error */
@@ -220,6 +223,12 @@ typedef struct dvs_comm dvs_comm;
 #define DVS_COMM_ID_BYTES 128
 dvs_status dvs_comm_get_unique_id(uint8_t* id /* [DVS_COMM_ID_BYTES] */);
 dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t* id, dvs_comm** out);
+/* Loopback group for one-GPU rehearsals and tests: out[0 .. world) = `world` logical ranks of THIS process on ONE device, no RCCL.
+ * Each rank must be driven by its own host thread with its own streams; a collective call (dvs_exchange_boundary,
+ * dvs_comm_all_gather) blocks on the host until every rank of the group has made the same call (30 s, then it fails on all ranks),
+ * then pulls the peers' blocks with device-to-device copies behind their events.  Same results as the RCCL communicator. */
+#define DVS_COMM_MAX_LOOPBACK 16
+dvs_status dvs_comm_create_loopback(int32_t device, int32_t world, dvs_comm** out /* [world] */);
 void dvs_comm_destroy(dvs_comm* c);
 int32_t dvs_comm_rank(const dvs_comm* c);
 int32_t dvs_comm_world(const dvs_comm* c);
@@ -413,12 +422,8 @@ void dvs_test_sincosf(float a, float* s, float* c);
 /* the PnP stage's quartic (Ferrari + Newton) and P3P (Grunert) routines on the host: real roots (unordered) / up to 4 poses x 12 */
 int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, double a0, double* roots4);
 int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48);
-/* diagnostics: with DVS_DEBUG bit 1 set at handle creation the quad-tree workgroup of (frame 0, level) stamps the 100 MHz wall clock at
- * its phase boundaries; out64[0] = count, out64[1 + i] = id << 56 | ticks (tools/exp_octree_phases.py) */
-dvs_status dvs_test_octree_stamps(dvs_orb* h, int32_t level, uint64_t* out64);
-dvs_status dvs_test_octree_stamps_frame(dvs_orb* h, int32_t frame, int32_t level, uint64_t* out64);   /* DVS_DEBUG bit 2: every frame stamps */
-/* diagnostics: 1 while the handle replays a captured hipGraph for single-frame host calls (dvs_orb_extract) */
-int32_t dvs_test_graph_active(const dvs_orb* h);
+/* (needs a GPU) hold `stream` for the given time with one idle wavefront (<= 200 000 us): lets a test delay an event */
+dvs_status dvs_test_stream_delay(void* stream, int32_t microseconds);
 dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
                              int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);
 

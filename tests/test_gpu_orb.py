@@ -378,15 +378,14 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
     _lib.stream_destroy(mstream)
 
 
-@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_GRAPH": "1"},
-                                 {"DVS_HOST_POLL": "0"}])
+@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_CASCADE": "1"},
+                                 {"DVS_HOST_POLL": "0"}, {"DVS_OCT_T": "256"}, {"DVS_OCT_T": "512", "DVS_CASCADE": "0"}, {"DVS_NO_OVERLAP": "1"}])
 @pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 500, 8), (720, 1280, 2000, 8), (360, 1000, 700, 6), (250, 332, 200, 4), (200, 136, 150, 3)])
 def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, nf, nl):
-    """the matrix-core blur (k_blur_mfma: int8 band products, LDS-staged) and the dword-aligned FAST tile origin (the default is the
-    byte-aligned one where the LDS-DMA probe passes), the captured-graph replay of single-frame calls and the copy-command
-    result path of the host entry points (the default is k_export_host + a polled sequence number) are selected at
-    handle creation (environment); all must reproduce the oracle bit for bit — blurred levels, candidates and the final result —
-    including widths that are not a multiple of the 32-column strips / 128-column super-strips and rows not a multiple of 32"""
+    """Every switch dvs_orb_create reads from the environment (csrc/orb.hip: the matrix-core blur, the dword-aligned FAST tile origin,
+    the one-launch pyramid cascade on / off, the copy-command result path of the host entry points, the quad-tree workgroup size,
+    no stream overlap) must reproduce the oracle bit for bit — blurred levels, candidates and the final result — including widths
+    that are not a multiple of the 32-column strips / 128-column super-strips and rows not a multiple of 32"""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -410,3 +409,57 @@ def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, 
         assert len(o.candidates(l)) == len(g.candidates(l)) and (g.candidates(l) == o.candidates(l)).all(), f"candidates level {l}"
     _assert_same_result(n, k1, d1, n2, k2, d2)
     g.close()
+
+
+def test_deferred_stage_held_back_two_steps(gpu):
+    """A deferred descriptor stage that is held back (here: its reuse guard completes 50 ms late) while the next calls' FAST and
+    quad-tree run on: what it still reads — its pyramid, the blurred block, ITS level keypoint lists — must not be rewritten under
+    it.  (Round 2 rotated two list sets: the quad-tree of call k + 2 overwrote the lists stage k was still reading.)  Every batch
+    must equal the plain, unpipelined extraction."""
+    import ctypes as C
+    from dvslam_amd import ORBextractor, _lib
+    L = _lib.lib()
+    rows, cols, nf, B, NBATCH = 480, 640, 800, 3, 7
+    frames = [np.stack([synth.make_frame(10 * b + i, cols=cols, rows=rows) for i in range(B)]) for b in range(NBATCH)]
+    d_img = [_lib.DeviceBuffer(f.nbytes).upload(f) for f in frames]
+    plain = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    cap = plain.capacity
+    mk = lambda: (_lib.DeviceBuffer(B * cap * 28), _lib.DeviceBuffer(B * cap * 32), _lib.DeviceBuffer(B * 4))
+    ref = []
+    for b in range(NBATCH):
+        k, d, n = mk()
+        plain.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr); plain.synchronize()
+        ref.append((k.download(np.uint8, B * cap * 28), d.download(np.uint8, B * cap * 32), n.download(np.int32, B)))
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    side = _lib.stream_create(0)
+    ev_out = [_lib.event_create(0) for _ in range(NBATCH)]
+    ev_slow = _lib.event_create(0)
+    outs = [mk() for _ in range(NBATCH)]
+    held = 1                                                      # the call whose descriptor stage is held back
+    for b in range(NBATCH):
+        k, d, n = outs[b]
+        g.set_output_event(ev_out[b], defer=True)
+        if b == held:
+            assert L.dvs_test_stream_delay(side, 50000) == 0      # 50 ms: hundreds of calls of this size
+            assert L.dvs_event_record(ev_slow, side) == 0
+            g.set_reuse_guard_event(ev_slow)
+        if b + 1 < NBATCH:
+            g.hint_next_batch_device(d_img[b + 1].ptr)
+        g.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr)
+        if b == held + 3:
+            done = C.c_int32(-1)
+            assert L.dvs_event_query(ev_out[held], C.byref(done)) == 0
+            assert done.value == 0, "the held-back stage finished before three more calls were enqueued: the test did not delay it"
+    g.synchronize(); _lib.stream_synchronize(side)
+    for b in range(NBATCH):
+        k, d, n = outs[b]
+        n1 = n.download(np.int32, B)
+        assert (n1 == ref[b][2]).all() and n1.min() > 100, b
+        k1 = k.download(np.uint8, B * cap * 28).reshape(B, cap, 28); d1 = d.download(np.uint8, B * cap * 32).reshape(B, cap, 32)
+        k0 = ref[b][0].reshape(B, cap, 28); d0 = ref[b][1].reshape(B, cap, 32)
+        for f in range(B):
+            assert (k1[f, :n1[f]] == k0[f, :n1[f]]).all() and (d1[f, :n1[f]] == d0[f, :n1[f]]).all(), (b, f)
+    g.set_output_event(0, defer=False)
+    for e in ev_out + [ev_slow]:
+        L.dvs_event_destroy(e)
+    _lib.stream_destroy(side)

@@ -1,0 +1,160 @@
+"""The configuration bench.py times, under the oracle.
+
+* test_timed_configuration_against_oracle: dvslam_amd/pipeline.py's step — the one bench.py runs — at BASELINE configs[1] in the
+  bench's own shape: 64 frames of 1280x720 per step, 2000 keypoints, software-pipelined match, deferred descriptor stage, reuse
+  guard, 4 output sets, several steps over distinct batches.  EVERY frame's keypoints / descriptors and EVERY match job are compared
+  with the CPU oracle (bit-exact).
+* test_frame_sharded_loopback_equals_single_rank: BASELINE configs[3] on one GPU — 8 logical ranks x 8 frames, each rank its own
+  extractor / matcher / streams and host thread, dvs_exchange_boundary once per global batch through the loopback communicator
+  (csrc/comm.hip: the multi-rank branches — previous rank's block, wrap-around to the last rank's block of the previous call — run
+  here); the 64 match jobs of every global batch equal the single-rank 64-frame sequence and the oracle.
+"""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+from dvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROWS, COLS, NF = 720, 1280, 2000
+
+
+def _global_batch(g, n=64):
+    """global batch g: n consecutive frames of the synthetic sequence over a scene of its own (bench.py's make_batches)"""
+    out = np.stack([synth.make_frame(i, COLS, ROWS, seed=1234 + 101 * g) for i in range(n)])
+    synth._CANVAS_CACHE.clear()
+    return out
+
+
+def _oracle_extract_all(oracle, frames, threads=8):
+    """oracle results of every frame, one extractor instance per worker thread (ctypes releases the GIL inside the C++ calls)"""
+    local = threading.local()
+
+    def one(img):
+        if not hasattr(local, "o"):
+            local.o = oracle.OracleORB(NF, 1.2, 8, 20, 7)
+        return local.o.extract(img)
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(one, frames))
+
+
+def _assert_frame(got, ref, where):
+    (n, k, d), (n2, k2, d2) = got, ref
+    assert int(n) == n2, (where, int(n), n2)
+    assert k[:n2].tobytes() == k2.tobytes(), where          # all 7 cv::KeyPoint fields, float bit patterns included
+    assert (d[:n2] == d2).all(), where
+
+
+def test_timed_configuration_against_oracle(gpu, oracle):
+    from dvslam_amd import _lib
+    from dvslam_amd.pipeline import StreamingPipeline
+    B, NB, STEPS = 64, 2, 5
+    batches = [_global_batch(g, B) for g in range(NB)]
+    ref = [_oracle_extract_all(oracle, b) for b in batches]              # [batch][frame] = (n, kps, desc)
+    d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in batches]
+    pipe = StreamingPipeline(B, ROWS, COLS, NF, nsets=4, pipelined=True)   # bench.py's construction
+    for i in range(STEPS):
+        pipe.step(d_img[i % NB].ptr, d_img[(i + 1) % NB].ptr)              # bench.py's step()
+    pipe.flush()
+    pipe.synchronize()
+    for i in range(STEPS - pipe.nsets, STEPS):                             # the batches still resident: steps 1 .. 4
+        n, k, d = pipe.outputs(i)
+        for f in range(B):
+            _assert_frame((n[f], k[f], d[f]), ref[i % NB][f], f"step {i} frame {f}")
+    checked = 0
+    for j in range(STEPS - pipe.nsets, STEPS):                             # every match job of those batches, frame 0 against the batch before
+        idx, dist = pipe.matches(j)
+        for f in range(B):
+            q = ref[j % NB][f]
+            t = ref[j % NB][f - 1] if f else ref[(j - 1) % NB][B - 1]
+            i2, d2 = oracle.match(q[2], t[2])
+            assert (idx[f, :q[0]] == i2).all() and (dist[f, :q[0]] == d2).all(), f"match job {f} of batch {j}"
+            checked += 1
+    assert checked == 4 * B
+    pipe.close()
+
+
+def test_serial_schedule_against_oracle(gpu, oracle):
+    """bench.py --serial-match: the same step without the software pipeline (one stream, match behind its own extraction)"""
+    from dvslam_amd import _lib
+    from dvslam_amd.pipeline import StreamingPipeline
+    B = 6
+    frames = _global_batch(3, 2 * B)
+    ref = _oracle_extract_all(oracle, frames)
+    d_img = [_lib.DeviceBuffer(frames[:B].nbytes).upload(frames[:B]), _lib.DeviceBuffer(frames[B:].nbytes).upload(frames[B:])]
+    pipe = StreamingPipeline(B, ROWS, COLS, NF, nsets=2, pipelined=False)
+    pipe.step(d_img[0].ptr); pipe.step(d_img[1].ptr)
+    pipe.synchronize()
+    for i in range(2):
+        n, k, d = pipe.outputs(i)
+        idx, dist = pipe.matches(i)
+        for f in range(B):
+            t = i * B + f
+            _assert_frame((n[f], k[f], d[f]), ref[t], f"frame {t}")
+            if t:
+                i2, d2 = oracle.match(ref[t][2], ref[t - 1][2])
+                assert (idx[f, :ref[t][0]] == i2).all() and (dist[f, :ref[t][0]] == d2).all(), t
+    pipe.close()
+
+
+def test_frame_sharded_loopback_equals_single_rank(gpu, oracle):
+    from dvslam_amd import _lib
+    from dvslam_amd import dist as dvdist
+    from dvslam_amd.pipeline import StreamingPipeline
+    WORLD, B, NG, STEPS = 8, 8, 2, 4                                      # 8 ranks x 8 frames = global batches of 64, 4 of them (2 distinct)
+    G = WORLD * B
+    gb = [_global_batch(10 + g, G) for g in range(NG)]
+    # single rank, 64 frames per step: the unsharded sequence
+    one = StreamingPipeline(G, ROWS, COLS, NF, nsets=STEPS, pipelined=True)
+    d_all = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in gb]
+    for i in range(STEPS):
+        one.step(d_all[i % NG].ptr, d_all[(i + 1) % NG].ptr)
+    one.flush(); one.synchronize()
+    want = [(one.outputs(i), one.matches(i)) for i in range(STEPS)]
+    one.close()
+    # 8 logical ranks, each with its own handles, streams, communicator and host thread
+    pipes = [StreamingPipeline(B, ROWS, COLS, NF, nsets=STEPS, pipelined=True) for _ in range(WORLD)]
+    comms = dvdist.Comm.loopback(0, WORLD)
+    d_rank = [[_lib.DeviceBuffer(gb[g][r * B:(r + 1) * B].nbytes).upload(gb[g][r * B:(r + 1) * B]) for g in range(NG)] for r in range(WORLD)]
+    for r in range(WORLD):
+        assert comms[r].rank == r and comms[r].world == WORLD
+        pipes[r].attach_comm(comms[r])
+    errors = []
+
+    def run(r):
+        try:
+            for i in range(STEPS):
+                pipes[r].step(d_rank[r][i % NG].ptr, d_rank[r][(i + 1) % NG].ptr)
+            pipes[r].flush()
+            pipes[r].synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(WORLD)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    jobs = 0
+    for i in range(STEPS):
+        (n1, k1, d1), (idx1, dist1) = want[i]
+        for r in range(WORLD):
+            n, k, d = pipes[r].outputs(i)
+            idx, dist = pipes[r].matches(i)
+            for f in range(B):
+                gf = r * B + f
+                assert n[f] == n1[gf] and k[f, :n[f]].tobytes() == k1[gf, :n[f]].tobytes() and (d[f, :n[f]] == d1[gf, :n[f]]).all(), (i, r, f)
+                if i == 0 and gf == 0:
+                    continue                                              # the very first frame has no predecessor
+                assert (idx[f, :n[f]] == idx1[gf, :n[f]]).all() and (dist[f, :n[f]] == dist1[gf, :n[f]]).all(), f"match: batch {i} rank {r} frame {f}"
+                # ... and the oracle's matcher on the same descriptors (shard boundaries included: f == 0 reads the exchanged block)
+                t_desc, t_n = (d1[gf - 1], n1[gf - 1]) if gf else (want[i - 1][0][2][G - 1], want[i - 1][0][0][G - 1])
+                i2, d2 = oracle.match(d[f, :n[f]], t_desc[:t_n])
+                assert (idx[f, :n[f]] == i2).all() and (dist[f, :n[f]] == d2).all(), (i, r, f)
+                jobs += 1
+    assert jobs == STEPS * G - 1
+    for p in pipes:
+        p.close()
+    for c in comms:
+        c.close()

@@ -1,4 +1,4 @@
-"""LM solve time on the device (10 KF x 2000 LM), best of a few repeats.  usage: python tools/exp_lm_time.py"""
+"""LM solve time on the device (10 KF x 2000 LM), best of a few repeats.  usage: python tools/time_lm.py"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "dynamic-visual-slam_amd"))
 import dvslam_amd

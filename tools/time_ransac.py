@@ -1,4 +1,4 @@
-"""per-call latency of the tracking stages' C-ABI entry points (host buffers in / out).  usage: python tools/exp_ransac_time.py"""
+"""per-call latency of the tracking stages' C-ABI entry points (host buffers in / out).  usage: python tools/time_ransac.py"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "dynamic-visual-slam_amd"))
 import numpy as np
