@@ -432,6 +432,9 @@ def main():
 
     # checks of what was just timed (outside the timed region)
     match_check = ocheck = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_bindings as ob
+        ob.use_native()   # the CPU baseline below times a -O2 -march=native build made here; it must be selected before the first oracle call
     n_last = pipe.outputs(pipe.i - 1)[0] if pipe.i >= 1 else np.zeros(B, np.int32)
     matched = 0
     if rank == 0 and pipe.i >= 3:
@@ -508,8 +511,6 @@ def main():
             "oracle_check": ocheck,
         }
         if world == 1 and not args.no_cpu_baseline:
-            import oracle_bindings as ob
-            ob.use_native()   # -O2 -march=native, built here on the host that times it
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]
             out["cpu_baseline"] = cpu_baseline(cb_frames, args.nfeatures)
             out["speedup_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1)

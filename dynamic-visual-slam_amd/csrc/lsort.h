@@ -219,4 +219,70 @@ LSORT_HD void sort_ranked(T* a, long n, C comp, int* Lp, int* Rp) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// std::nth_element and std::partition as KeyPointsFilter::retainBest calls them (OpenCV features2d/src/keypoint.cpp, reached from
+// cv::ORB: row N4).  retainBest's result ORDER is whatever these two leave behind, so it is part of "identical rows".
+//   nth_element = __introselect: __unguarded_partition_pivot until <= 3 elements remain around nth (then __insertion_sort), or
+//   __heap_select + iter_swap(first, nth) once the depth limit 2 * floor(lg n) is spent.
+template <class T, class C>
+LSORT_HD void heap_select(T* first, T* middle, T* last, C comp) {
+  const long len = middle - first;
+  if (len >= 2) {  // __make_heap(first, middle)
+    long parent = (len - 2) / 2;
+    while (true) {
+      T value = first[parent];
+      adjust_heap(first, parent, len, value, comp);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  for (T* i = middle; i < last; ++i)
+    if (comp(*i, *first)) {  // __pop_heap(first, middle, i)
+      T value = *i;
+      *i = *first;
+      adjust_heap(first, 0L, len, value, comp);
+    }
+}
+
+template <class T, class C>
+LSORT_HD void nth_element(T* first, T* nth, T* last, C comp) {
+  if (first == last || nth == last) return;
+  int depth = 0;
+  for (long m = last - first; m > 1; m >>= 1) depth++;
+  depth *= 2;
+  while (last - first > 3) {
+    if (depth == 0) {
+      heap_select(first, nth + 1, last, comp);
+      swp(first, nth);
+      return;
+    }
+    --depth;
+    T* mid = first + (last - first) / 2;
+    move_median_to_first(first, first + 1, mid, last - 1, comp);
+    T* cut = unguarded_partition(first + 1, last, first, comp);
+    if (cut <= nth) first = cut; else last = cut;
+  }
+  insertion_sort(first, last, comp);
+}
+
+// std::partition for bidirectional (and random access) iterators: __partition(first, last, pred, bidirectional_iterator_tag)
+template <class T, class P>
+LSORT_HD T* partition(T* first, T* last, P pred) {
+  while (true) {
+    while (true) {
+      if (first == last) return first;
+      else if (pred(*first)) ++first;
+      else break;
+    }
+    --last;
+    while (true) {
+      if (first == last) return first;
+      else if (!pred(*last)) --last;
+      else break;
+    }
+    swp(first, last);
+    ++first;
+  }
+}
+
 }  // namespace lsort

@@ -18,6 +18,7 @@
 #include "glibc_sincosf.h"
 #include "lsort.h"
 #include "orb_geom.h"
+#include "orb_device_common.h"
 
 namespace dvs {
 
@@ -569,11 +570,6 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
 //   * survivors (~17 % of pixels) are compacted IN ORDER by ballots, scored exactly, and the corners
 //     (~3 %) compacted again; NMS and the threshold fallback then touch only that short list.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // start-up probe: does the LDS-DMA take global addresses that are not dword aligned on this device / driver configuration?
 // (it does on gfx950 under ROCm's unaligned-access mode; if it ever masked the low address bits the tiles would be wrong, so
 // k_fast_wave only relies on it when this returned the exact bytes)
@@ -980,47 +976,6 @@ __device__ __forceinline__ int qt_build_expand_list(QtShared& sh, int cur, int T
 constexpr int kSortRanges = 128;  // > kMaxQuota / 17 live ranges of more than 16 elements
 struct SortShared { uint32_t rng[2][kSortRanges]; int cnt[2]; };
 
-__device__ __forceinline__ int qs_wave_partition(unsigned long long* a, int* Lp, int* Rp, int f, int l, int lane) {
-  const lsort::Less<12> less;
-  if (lane == 0) lsort::move_median_to_first(a + f, a + f + 1, a + f + (l - f) / 2, a + l - 1, less);
-  wave_lds_fence();
-  const unsigned long long pk = a[f] >> 12;
-  const unsigned long long ltm = (1ull << lane) - 1ull;
-  int nge = 0, nle = 0;
-  for (int c = f + 1; c < l; c += 64) {
-    const int i = c + lane;
-    const bool v = i < l;
-    const unsigned long long k = v ? a[i] >> 12 : 0ull;
-    const bool ge = v && !(k < pk), le = v && !(pk < k);
-    const unsigned long long mg = __ballot(ge), ml = __ballot(le);
-    if (ge) Lp[f + nge + __popcll(mg & ltm)] = i;
-    if (le) Rp[f + nle + __popcll(ml & ltm)] = i;  // ascending; k-th from the right = Rp[f + nle - 1 - k]
-    nge += __popcll(mg); nle += __popcll(ml);
-  }
-  wave_lds_fence();
-  const int mm = min(nge, nle);
-  int K = 0;
-  for (int c = 0; c < mm; c += 64) {
-    const int k = c + lane;
-    const unsigned long long mk = __ballot(k < mm && Lp[f + k] < Rp[f + nle - 1 - k]);
-    K += __popcll(mk);
-    if (mk != ~0ull) break;  // the pairs that swap are a prefix
-  }
-  for (int c = 0; c < K; c += 64) {
-    const int k = c + lane;
-    if (k < K) {
-      const int i = Lp[f + k], j = Rp[f + nle - 1 - k];
-      const unsigned long long x = a[i], y = a[j];
-      a[i] = y; a[j] = x;
-    }
-  }
-  const int big = 0x7fffffff;
-  const int lK = K < nge ? Lp[f + K] : big;
-  const int rprev = K > 0 ? Rp[f + nle - K] : big;
-  wave_lds_fence();
-  return min(lK, rprev);
-}
-
 __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int* Lp, int* Rp, SortShared& ss) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // leaf descriptor per element, kept in Lp (a finished range's scratch is never used again): first | end << 16
@@ -1050,7 +1005,7 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
         for (int i = f + lane; i < l; i += 64) Lp[i] = i | ((i + 1) << 16);
         continue;
       }
-      const int cut = qs_wave_partition(a, Lp, Rp, f, l, lane);
+      const int cut = wave_partition<12>(a, Lp, Rp, f, l, lane);
       emit(f, cut, d - 1, cur ^ 1);
       emit(cut, l, d - 1, cur ^ 1);
     }
@@ -1395,12 +1350,6 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101 on the level itself — OpenCV's 8-bit fixed-point path:
 // horizontal Q8.8 (exact in u16), vertical Q16.16, (acc + 32768) >> 16.  Tile = 64 x 16 outputs.
 // =============================================================================================
-__device__ __forceinline__ int reflect101(int p, int len) {
-  if (len == 1) return 0;
-  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
-  return p;
-}
-
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, const BlurTile* __restrict__ tiles, ImgSrc src,
                                               u8* __restrict__ blur) {
   __shared__ u8 in[22][72];
@@ -1713,33 +1662,6 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const Geom* __restrict__ g, c
 // =============================================================================================
 // orientation + descriptor + final keypoint record.  One wavefront per keypoint.
 // =============================================================================================
-__constant__ int8_t c_pattern[1024] = {
-#include "brief_pattern.inc"
-};
-
-// cv::fastAtan2 (atan_f32), float32 with individually rounded operations
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
-  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
-  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
-  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-  const float eps = (float)2.2204460492503131e-16;
-  const float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-  } else {
-    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-  }
-  if (x < 0) a = __fsub_rn(180.f, a);
-  if (y < 0) a = __fsub_rn(360.f, a);
-  return a;
-}
-
 // Eight keypoint slots per wavefront (fixed (level, index) slots of the per-level keypoint block).
 //  * slot -> (level, index, output position), the keypoint word and its addresses are resolved by lanes 0..7 in one pass and
 //    broadcast with v_readlane;
