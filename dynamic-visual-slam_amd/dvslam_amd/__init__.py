@@ -10,3 +10,4 @@ from .orb import ORBextractor  # noqa: F401
 from .matcher import BFMatcher  # noqa: F401
 from .ba import BAProblem, SlidingWindowBA  # noqa: F401
 from .glue import FrontendGlue  # noqa: F401
+from .cvorb import CvORB  # noqa: F401

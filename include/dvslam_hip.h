@@ -411,6 +411,35 @@ dvs_status dvs_ba_get_parameters(dvs_ba* h, double* q_wxyz, double* t, double* X
 dvs_status dvs_ba_pose_from_rt(const double* R, const double* t, double* q_wxyz, double* trans);
 dvs_status dvs_ba_pose_to_rt(const double* q_wxyz, const double* trans, double* R, double* t);
 
+/* ============================ cv::ORB-compatible extractor ============================
+ * Replaces cv::ORB::create(...)->detectAndCompute(image, noArray(), keypoints, descriptors)
+ * (/root/reference/dynamic_visual_slam/test/test_dbow2_integration.cpp:19,38; OpenCV 4.x features2d/src/orb.cpp): pyramid from
+ * level 0 with INTER_LINEAR_EXACT, FAST-9/16 with non-max suppression over whole levels, runByImageBorder(edge), retainBest
+ * (std::nth_element + std::partition semantics: ties with the last kept response are all kept, the order is libstdc++'s), HARRIS
+ * responses (7 x 7, k = 0.04), intensity-centroid angle, rBRIEF on the 7 x 7 Gaussian-blurred level.  Keypoints come back in
+ * cv::KeyPoint layout (pt in level-0 coordinates, size = 31 * scale, response = HARRIS value or FAST score, octave = level).
+ * Built: firstLevel = 0, WTA_K = 2, patchSize = 31 (cv::ORB's defaults), edge_threshold >= 19; anything else DVS_ERR_UNSUPPORTED.
+ * Because retainBest keeps ties, the count is data dependent: DVS_ERR_CAPACITY (with *n_out = rows needed) when capacity is
+ * too small; an empty image returns DVS_OK with *n_out = 0 (detectAndCompute returns without detecting). */
+typedef struct dvs_cvorb dvs_cvorb;
+typedef struct dvs_cvorb_params {
+  int32_t nfeatures;       /* 500 */
+  float scale_factor;      /* 1.2f */
+  int32_t nlevels;         /* 8 */
+  int32_t edge_threshold;  /* 31 */
+  int32_t first_level;     /* 0 */
+  int32_t wta_k;           /* 2 */
+  int32_t score_type;      /* 0 = cv::ORB::HARRIS_SCORE, 1 = FAST_SCORE */
+  int32_t patch_size;      /* 31 */
+  int32_t fast_threshold;  /* 20 */
+} dvs_cvorb_params;
+dvs_status dvs_cvorb_create(const dvs_cvorb_params* params, int32_t device, dvs_cvorb** out);
+void dvs_cvorb_destroy(dvs_cvorb* h);
+dvs_status dvs_cvorb_detect_and_compute(dvs_cvorb* h, const uint8_t* gray, int32_t rows, int32_t cols, size_t step_bytes, dvs_keypoint* kps,
+                                        uint8_t* desc /* capacity x 32 */, int32_t capacity, int32_t* n_out);
+/* parity introspection: level `level` of the last call's pyramid (blurred = 1: after the Gaussian), tight rows */
+dvs_status dvs_cvorb_get_level(dvs_cvorb* h, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes, int32_t* w, int32_t* hgt);
+
 /* ======================================= host-logic test hooks ================================= */
 /* (no GPU needed) libstdc++ std::sort replica used by the quad-tree, glibc sinf/cosf restatement, geometry tables */
 void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
@@ -424,6 +453,10 @@ int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, doubl
 int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48);
 /* (needs a GPU) hold `stream` for the given time with one idle wavefront (<= 200 000 us): lets a test delay an event */
 dvs_status dvs_test_stream_delay(void* stream, int32_t microseconds);
+/* KeyPointsFilter::retainBest on bare responses: perm[i] = original index of the i-th survivor.  _host: csrc/lsort.h's sequential
+ * restatement of std::nth_element + std::partition (no GPU); _device: the wavefront routine the cv::ORB kernels run */
+void dvs_test_retain_best_host(const float* responses, int32_t n, int32_t n_points, int32_t* perm, int32_t* n_kept);
+dvs_status dvs_test_retain_best_device(const float* responses, int32_t n, int32_t n_points, int32_t* perm, int32_t* n_kept);
 dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
                              int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);
 

@@ -7,6 +7,7 @@
 #include "dynamic_visual_slam/ORBextractor.hpp"
 #include "dynamic_visual_slam/bundle_adjustment.hpp"
 #include "dvslam/bf_matcher.hpp"
+#include "dvslam/cv_orb.hpp"
 
 int main() {
   if (dvs_device_count() < 1) { std::printf("no device: OpenCV-typed adapters compiled, nothing run\n"); return 3; }
@@ -77,6 +78,24 @@ int main() {
   cv::Mat R2, t2;
   cp.toRt(R2, t2);
   if (std::fabs(t2.at<double>(0) - 0.3) > 1e-12 || std::fabs(R2.at<double>(1, 1) - 1.0) > 1e-12) return 1;
+  {  // test_dbow2_integration.cpp:14-19, 33-43 with cv::ORB -> dvslam::ORB: three filled discs on black, create(100), detectAndCompute
+    cv::Mat dummy_image_(480, 640, CV_8UC1);
+    const int cx[3] = {100, 300, 500}, cy[3] = {100, 200, 300}, rr[3] = {50, 30, 40};
+    for (int y = 0; y < 480; y++)
+      for (int x = 0; x < 640; x++) {
+        uint8_t v = 0;
+        for (int k = 0; k < 3; k++) if ((x - cx[k]) * (x - cx[k]) + (y - cy[k]) * (y - cy[k]) <= rr[k] * rr[k]) v = 255;
+        dummy_image_.at<uint8_t>(y, x) = v;
+      }
+    std::shared_ptr<dvslam::ORB> orb_ = dvslam::ORB::create(100);
+    std::vector<cv::KeyPoint> keypoints;
+    cv::Mat descriptors2;
+    orb_->detectAndCompute(dummy_image_, cv::Mat(), keypoints, descriptors2);
+    if (!(descriptors2.rows > 0) || descriptors2.cols != 32 || (int)keypoints.size() != descriptors2.rows) {   // the reference test's assertions (:41-42)
+      std::printf("dvslam::ORB: %d x %d descriptors\n", descriptors2.rows, descriptors2.cols); return 1;
+    }
+    std::printf("dvslam::ORB on the disc image: %d descriptors\n", descriptors2.rows);
+  }
   std::printf("opencv-typed adapters ok: %d keypoints, BA cost %.3e in %d steps\n", n, result.final_cost, result.iterations_completed);
   return 0;
 }

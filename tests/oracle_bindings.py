@@ -79,6 +79,12 @@ def lib():
     L.orc_match_hamming.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.orc_match_hamming256.argtypes = [vp, i32, vp, i32, vp, vp]
     L.orc_match_hamming_thresh.restype = i32; L.orc_match_hamming_thresh.argtypes = [vp, i32, vp, i32, i32, vp, i32]
+    L.orc_cvorb_create.restype = vp; L.orc_cvorb_create.argtypes = [i32, f32, i32, i32, i32, i32]
+    L.orc_cvorb_destroy.argtypes = [vp]
+    L.orc_cvorb_detect_and_compute.restype = i32; L.orc_cvorb_detect_and_compute.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32]
+    L.orc_cvorb_level.restype = i32; L.orc_cvorb_level.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+    L.orc_resize_linear_exact_u8.argtypes = [vp, i32, i32, sz, vp, i32, i32, sz]
+    L.orc_retain_best.restype = i32; L.orc_retain_best.argtypes = [vp, i32, i32, vp]
     _lib = L
     return L
 
@@ -149,6 +155,50 @@ class OracleORB:
         n = self.L.orc_orb_get_level_keypoints(self.h, l, _p(kps), cap)
         assert n >= 0
         return kps[:n].copy()
+
+
+class OracleCvORB:
+    """oracle/cvorb_oracle.cpp: cv::ORB::create(...)->detectAndCompute as the reference's test uses it (test_dbow2_integration.cpp:19,38)"""
+
+    def __init__(self, nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, scoreType=0, fastThreshold=20):
+        self._L = lib()
+        self._h = self._L.orc_cvorb_create(nfeatures, scaleFactor, nlevels, edgeThreshold, scoreType, fastThreshold)
+        self.nlevels = nlevels
+
+    def __del__(self):
+        try:
+            self._L.orc_cvorb_destroy(self._h)
+        except Exception:
+            pass
+
+    def detectAndCompute(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = 1 << 16
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = self._L.orc_cvorb_detect_and_compute(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc), cap)
+        assert n >= 0, n
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        buf = np.zeros(1 << 24, np.uint8)
+        assert self._L.orc_cvorb_level(self._h, l, int(blurred), _p(buf), buf.size, C.byref(w), C.byref(h)) == 0
+        return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def resize_linear_exact(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_exact_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def retain_best(responses, n_points):
+    """KeyPointsFilter::retainBest with the REAL std::nth_element / std::partition -> surviving original indices in their order"""
+    r = np.ascontiguousarray(responses, np.float32)
+    perm = np.zeros(max(len(r), 1), np.int32)
+    k = lib().orc_retain_best(_p(r), len(r), n_points, _p(perm))
+    return perm[:k].copy()
 
 
 def match(q, t):
