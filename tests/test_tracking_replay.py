@@ -1,7 +1,9 @@
 """The per-frame logic of the two nodes with the tracking stages in place (tools/replay_tracking.py: extraction, depth filter,
 match, fundamental-matrix RANSAC, feature culling, PnP RANSAC + pose accumulation, keyframe decision, Keyframe.msg, backend
-association, sliding-window BA) on the bounded-trajectory synthetic sequence.  The 1000-frame run of BASELINE configs[4] is
-recorded in profiles/r02_replay_1000.json; here a short prefix keeps the suite fast.  Tolerances (floating point, RANSAC):
+association, sliding-window BA) on the bounded-trajectory synthetic sequence (BASELINE configs[4]).  The HIP pipeline runs in two
+phases — extraction + depth filter + match for all frames batched on the device, then the sequential tracking — and is compared
+with the CPU oracle pipeline: live on a 60-frame prefix, and over the whole 1000 frames against the oracle pipeline's recorded run
+(tests/golden/replay_1000_cpu.npz, made by tools/gen_replay_golden.py: 74 s of CPU time that the GPU box does not repeat).  Tolerances (floating point, RANSAC):
 HIP against the CPU oracle pipeline <= 3 mm / 0.1 deg RMS over 60 frames with identical keyframe decisions; either against the
 closed-form ground truth <= 5 cm / 2 deg (frame-to-frame visual odometry on a fronto-parallel plane drifts in tilt)."""
 import os
@@ -49,3 +51,51 @@ def test_hip_pipeline_against_cpu_pipeline_and_ground_truth(gpu, oracle):
     # the extraction / match / glue stages are bit-exact, so both pipelines see the same matches; only the RANSAC stages differ
     assert raw["hip"]["stats"]["matches"] == raw["cpu"]["stats"]["matches"]
     assert raw["hip"]["backend"]["associations"] == raw["cpu"]["backend"]["associations"]
+
+
+@pytest.mark.gpu
+def test_batched_phase_one_equals_per_frame_calls_and_shards(gpu):
+    """phase 1 (64 frames per call, device-resident between extraction, depth filter and match) gives every frame the bytes of the
+    one-frame-per-call host entry points; 8 contiguous shards (each re-extracting the frame before its range) give the same again"""
+    import replay_tracking as rt
+    from dvslam_amd import synth
+    n, cols, rows = 150, 640, 480
+    frames = [synth.make_traj_frame(t, cols, rows) for t in range(n)]
+    depth = np.full((rows, cols), 1500, np.uint16)
+    one = rt.batched_front_end(frames, depth, 1000, shards=1)
+    st = rt.HipStages(1000)
+    prev_d = None
+    for t in range(n):
+        k, d = st.extract(frames[t]); fk, fd = st.filter_depth(k, d, depth)
+        assert fk.tobytes() == one[t][0].tobytes() and (fd == one[t][1]).all(), t
+        if prev_d is not None:
+            idx, dist = st.match(fd, prev_d)
+            assert (idx == one[t][2]).all() and (dist == one[t][3]).all(), t
+        prev_d = fd
+    eight = rt.batched_front_end(frames, depth, 1000, shards=8)
+    assert len(eight) == n
+    for t in range(n):
+        assert eight[t][0].tobytes() == one[t][0].tobytes() and (eight[t][1] == one[t][1]).all(), t
+        if t:
+            assert (eight[t][2] == one[t][2]).all() and (eight[t][3] == one[t][3]).all(), t
+
+
+@pytest.mark.gpu
+def test_thousand_frame_replay_against_the_recorded_cpu_pipeline(gpu):
+    """BASELINE configs[4] at full length: 1000 frames through the HIP pipeline (8 phase-1 shards), compared with the CPU oracle
+    pipeline's recorded run: identical match statistics (the extraction / match stages are bit-exact), the same keyframes, poses within
+    the RANSAC tolerance of the 60-frame test scaled to the longer run (1 cm / 0.3 deg RMS)"""
+    import replay_tracking as rt
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "replay_1000_cpu.npz"))
+    n, cols, rows, nf, ba_every = [int(v) for v in g["config"]]
+    r = rt.run(n_frames=n, cols=cols, rows=rows, nfeatures=nf, ba_every=ba_every, with_cpu=False, batched=True, shards=8)
+    hip = r["_raw"]["hip"]
+    assert hip["stats"]["matches"] == g["matches"].tolist()
+    assert hip["keyframes"] == g["keyframes"].tolist()
+    cpu_poses = list(zip(g["R"], g["t"]))
+    e = rt.rmse(hip["poses"], cpu_poses)
+    assert e["translation_m"] < 0.01 and e["rotation_deg"] < 0.3, e
+    # the poses differ by millimetres (RANSAC), so a handful of the backend's 5-pixel reprojection gates fall the other way
+    assert abs(hip["backend"]["landmarks"] - int(g["landmarks"])) <= 20
+    assert np.abs(np.array(hip["backend"]["associations"]) - g["associations"]).max() <= 20
+    assert r["hip"]["ms_per_frame_in_stages"] < 1.0, r["hip"]

@@ -14,6 +14,13 @@ Backend (Backend::syncCallback / bundleAdjustmentCallback, backend.cpp:709-989):
 database (Hamming < 50, reprojection < 5 px), new landmarks otherwise, and every `ba_every` keyframes SlidingWindowBA over the
 last 5 keyframes (the reference runs it on a 2 s wall timer; a replay has no wall clock).
 
+Two phases.  What does not depend on the pose — gray -> ORB extract -> filterDepth -> match vs the previous frame
+(frontend.cpp:1084-1132) — runs for ALL frames first, 64 frames per call through dvs_orb_extract_batch_device /
+dvs_filter_depth_batch_device / dvs_match_hamming_sequence_device with everything resident in HBM (`BatchedFrontEnd`; frames shard
+contiguously over `--shards` ranks, each re-extracting the one frame before its range, so the shards need no exchange and their
+results are gathered where phase 2 runs).  Phase 2 is the sequential part (:1136-1324): fundamental-matrix gate, feature culling,
+PnP + pose accumulation, the keyframe test against the LAST KEYFRAME (whose identity is only known sequentially) and the backend.
+
 The scene is a fronto-parallel textured plane at Z0 (depth image constant), the camera translates in the image plane and rolls
 (dvslam_amd.synth.traj_state), so ground truth is exact.  RANSAC seeds are the frame index: both pipelines draw the same samples."""
 import argparse
@@ -131,11 +138,75 @@ class CpuStages:
         return s, o.parameters()
 
 
+class BatchedFrontEnd:
+    """phase 1 on the MI355X: extraction + depth filter + match against the previous frame for a run of frames, B per call,
+    device-resident between the three stages; one bulk download per batch.  Returns per frame (keypoints, descriptors, trainIdx, dist)
+    after the depth filter; frame 0 of the run has no match (idx / dist None)."""
+
+    def __init__(self, nfeatures, rows, cols, B=64, device=0):
+        import ctypes as C
+        import dvslam_amd
+        from dvslam_amd import _lib
+        self.C, self._lib, self.L = C, _lib, _lib.lib()
+        self.B, self.rows, self.cols, self.device = B, rows, cols, device
+        self.orb = dvslam_amd.ORBextractor(nfeatures, 1.2, 8, 20, 7, device=device, max_batch=B)
+        self.mat = dvslam_amd.BFMatcher(device=device, stream=self.orb.get_stream())     # one stream: the three stages depend on each other
+        self.cap = cap = self.orb.capacity
+        vp, i32, sz, f32 = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
+        self.L.dvs_filter_depth_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, sz, sz, f32, f32, vp, vp, vp, vp]
+        D = lambda n: _lib.DeviceBuffer(n, device)
+        self.d_img = D(B * rows * cols); self.d_depth = D(rows * cols * 2)
+        self.d_k, self.d_d, self.d_n = D(B * cap * 28), D(B * cap * 32), D(B * 4)
+        # filtered outputs in two sets: the first frame of a batch is matched against the last frame of the batch before
+        self.f_k = [D(B * cap * 28) for _ in range(2)]; self.f_d = [D(B * cap * 32) for _ in range(2)]; self.f_n = [D(B * 4) for _ in range(2)]
+        self.d_idx, self.d_dist = D(B * cap * 4), D(B * cap * 4)
+
+    def run(self, frames, depth):
+        C, B, cap, rows, cols = self.C, self.B, self.cap, self.rows, self.cols
+        self.d_depth.upload(np.ascontiguousarray(depth, np.uint16))
+        out = []
+        for b0 in range(0, len(frames), B):
+            nb = min(B, len(frames) - b0)
+            s, sp = (b0 // B) & 1, ((b0 // B) & 1) ^ 1
+            self.d_img.upload(np.ascontiguousarray(np.stack(frames[b0:b0 + nb])))
+            self.orb.extract_batch_device(self.d_img.ptr, nb, rows, cols, cols, rows * cols, self.d_k.ptr, self.d_d.ptr, cap, self.d_n.ptr)
+            self._lib.check(self.L.dvs_filter_depth_batch_device(self.mat._h, self.d_k.ptr, self.d_d.ptr, self.d_n.ptr, cap, nb, self.d_depth.ptr, rows, cols,
+                                                                 cols * 2, 0, 0.3, 3.0, self.f_k[s].ptr, self.f_d[s].ptr, None, self.f_n[s].ptr))
+            prev = (self.f_d[sp].ptr + (B - 1) * cap * 32, self.f_n[sp].ptr + (B - 1) * 4) if b0 else (0, 0)   # full batches precede b0
+            self.mat.match_sequence_device(self.f_d[s].ptr, self.f_n[s].ptr, cap, nb, prev[0], prev[1], self.d_idx.ptr, self.d_dist.ptr)
+            self.orb.synchronize()
+            n = self.f_n[s].download(np.int32, nb)
+            k = self.f_k[s].download(np.uint8, nb * cap * 28).view(self._lib.KP_DTYPE).reshape(nb, cap)
+            d = self.f_d[s].download(np.uint8, nb * cap * 32).reshape(nb, cap, 32)
+            idx = self.d_idx.download(np.int32, nb * cap).reshape(nb, cap); dist = self.d_dist.download(np.int32, nb * cap).reshape(nb, cap)
+            for f in range(nb):
+                first = b0 + f == 0
+                out.append((k[f, :n[f]].copy(), d[f, :n[f]].copy(), None if first else idx[f, :n[f]].copy(), None if first else dist[f, :n[f]].copy()))
+        return out
+
+
+def batched_front_end(frames, depth, nfeatures, shards=1, B=64):
+    """phase 1 over `shards` contiguous frame ranges (one per rank on a multi-GPU node; here one after the other on the one GPU): shard
+    r runs frames [a_r - 1, b_r) — it re-extracts the frame before its range instead of receiving it — and contributes [a_r, b_r)"""
+    rows, cols = frames[0].shape
+    n = len(frames)
+    fe = BatchedFrontEnd(nfeatures, rows, cols, B)
+    out = []
+    for r in range(shards):
+        a, b = r * n // shards, (r + 1) * n // shards
+        if b <= a:
+            continue
+        lo = max(a - 1, 0)
+        part = fe.run(frames[lo:b], depth)
+        out += part[a - lo:]
+    return out
+
+
 def pts_of(kps, idx):
     return np.stack([kps["x"][idx], kps["y"][idx]], 1).astype(np.float32)
 
 
-def track(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every=10, verbose=False, frames=None):
+def track(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every=10, verbose=False, frames=None, pre=None):
     """runs the sequence through `stages`; returns the per-frame visual-odometry poses (camera-to-world, frame 0 = identity),
     keyframe list, backend results"""
     from dvslam_amd import synth
@@ -153,14 +224,17 @@ def track(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every=10, verbose=F
     for t in range(n_frames):
         gray = frames[t] if frames is not None else synth.make_traj_frame(t, cols, rows)
         t0 = time.perf_counter()
-        k, d = stages.extract(gray)
-        fk, fd = stages.filter_depth(k, d, depth)         # filterDepth (:1100)
+        if pre is not None:                               # phase 1 ran ahead (BatchedFrontEnd): extraction, depth filter, match vs previous
+            fk, fd, pre_idx, pre_dist = pre[t]
+        else:
+            k, d = stages.extract(gray)
+            fk, fd = stages.filter_depth(k, d, depth)     # filterDepth (:1100)
         publish = None
         if prev_k is None:                                # first frame (:1285-1300): becomes the first keyframe
             backend_k, backend_d = fk, fd
             publish = True
         else:
-            idx, dist = stages.match(fd, prev_d)          # :1123
+            idx, dist = (pre_idx, pre_dist) if pre is not None else stages.match(fd, prev_d)   # :1123
             q = np.nonzero(dist < 50)[0]                  # :1126-1132
             tr = idx[q]
             stats["matches"].append(len(q))
@@ -306,15 +380,24 @@ def rmse(a, b):
                 max_translation_m=float(np.max(e)), max_rotation_deg=float(np.max(r)))
 
 
-def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_every=5, with_cpu=True, verbose=False):
+def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_every=5, with_cpu=True, verbose=False, batched=True, shards=1):
     from dvslam_amd import synth
     frames = [synth.make_traj_frame(t, cols, rows) for t in range(n_frames)]
     gt = ground_truth(n_frames, f, z0)
     res = dict(config=dict(frames=n_frames, resolution=[cols, rows], nfeatures=nfeatures, focal_px=f, plane_depth_m=z0, ba_every_keyframes=ba_every,
                            ransac="findFundamentalMat(RANSAC, 2 px, 0.99) / solvePnPRansac(100, 4 px, 0.99), seeds = frame index"))
     t0 = time.perf_counter()
-    hip = track(HipStages(nfeatures), n_frames, cols, rows, f, z0, nfeatures, ba_every, verbose, frames)
+    pre, t_phase1 = None, 0.0
+    if batched:
+        depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+        pre = batched_front_end(frames, depth, nfeatures, shards)
+        t_phase1 = time.perf_counter() - t0
+    hip = track(HipStages(nfeatures), n_frames, cols, rows, f, z0, nfeatures, ba_every, verbose, frames, pre)
+    hip["seconds_in_stages"] += t_phase1
+    res["config"]["phases"] = (f"phase 1 batched on the device ({shards} shard(s), 64 frames per call), phase 2 sequential" if batched
+                               else "one frame per call")
     res["hip"] = dict(wall_s=time.perf_counter() - t0, ms_per_frame_in_stages=1e3 * hip["seconds_in_stages"] / n_frames,
+                      ms_per_frame_phase1=1e3 * t_phase1 / n_frames,
                       keyframes=len(hip["keyframes"]), rmse_vs_ground_truth=rmse(hip["poses"], gt),
                       median_matches=float(np.median(hip["stats"]["matches"])), median_geometric=float(np.median(hip["stats"]["geometric"])),
                       median_pnp_inliers=float(np.median(hip["stats"]["pnp_inliers"])), pose_updates=hip["stats"]["pose_updates"],
@@ -342,10 +425,12 @@ if __name__ == "__main__":
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--per-frame", action="store_true", help="round 2's form: one frame per call through the host entry points")
+    ap.add_argument("--shards", type=int, default=1, help="contiguous frame ranges of phase 1 (one per rank on a multi-GPU node)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch  # noqa: F401  (one ROCm stack per process: tests/conftest.py)
-    r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True)
+    r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True, batched=not a.per_frame, shards=a.shards)
     r.pop("_raw")
     print(json.dumps(r, indent=1))
     if a.out:
