@@ -10,11 +10,10 @@
 //                ceres::QuaternionRotatePoint, x the 4x3 plus-Jacobian of EigenQuaternionManifold on the
 //                raw (w,x,y,z) memory, Huber corrector; per-chunk fixed-order reduction of the camera's
 //                H_pp (21 unique) / g_p (6) / cost through wave shuffles + LDS  -> partials
-//                ... and, chained behind the chunks in the SAME launch by arrival tickets (BaFold): thread per landmark
-//                walks its observations in fixed order (H_ll, g_l) as soon as the chunks holding them are stored; the
-//                camera's chunk partials and the total cost are folded in chunk / camera order by whoever finishes last.
+//   k_ba_reduce  thread per landmark walks its observations in fixed order (H_ll, g_l); further blocks
+//                fold the chunk partials per camera and the total cost in chunk order.
 // Every reduction has a fixed order, so cost / gradient are bit-reproducible run to run.
-// dvs_ba_solve: host LM around that launch (reduced camera system <= 6K x 6K); dvs_ba_solve_device: the k_lm_* kernels.
+// dvs_ba_solve: host LM around the two launches (reduced camera system <= 6K x 6K); dvs_ba_solve_device: the k_lm_* kernels.
 #include <float.h>
 #include <math.h>
 #include <string.h>
@@ -258,111 +257,11 @@ __device__ __forceinline__ void ba_eval_body(const int bid, BaDev P, const BaChu
   if (tid < 28) partial[(size_t)bid * 28 + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
 }
 
-// ---- the reductions of one evaluation, chained behind the evaluation workgroups of the SAME launch --------------------------------
-// A landmark group (256 landmarks) can be folded as soon as every chunk holding one of its observations has stored its records, a
-// camera as soon as its own chunks have, the total cost once every camera has: each evaluation workgroup, done with its chunk, draws
-// a ticket per group / camera it contributed to (agent-scope release -> ticket -> acquire, cdna_hip_programming.md Guideline 16),
-// and whoever draws the last one does that fold — in index order, so the sums do not depend on who arrives when.  No grid-wide
-// barrier, no second launch: round 2's separate k_ba_reduce launch was half of the 13 us of a single-window evaluation, and the
-// one-launch variant with a grid barrier (spinning workgroups) was slower still (17 us).  Counters are zero between launches: the
-// last arrival resets the one it exhausted.
-struct BaFold {
-  int K, L, withLm, costOnly;
-  const int *camChunkStart, *lmStart, *lmObs;
-  const int *chunkGroupStart, *chunkGroups, *groupNeed;   // groups a chunk's observations touch (CSR), chunks per group
-  int *groupCnt, *camCnt, *camsDone;
-  int camsWithChunks;                                     // cameras that have observations (the others' H_pp / g / cost stay zero)
-  double *Hpp, *Hll, *g, *cost, *costCam;
-};
-
-// H_ll and g_l of landmarks [256 group, 256 group + 256): thread per landmark over its observations in camera order
-__device__ __forceinline__ void ba_fold_landmarks(const int group, const BaDev& P, const BaFold& F, const double* __restrict__ res,
-                                                      const double* __restrict__ Jl) {
-  const int l = group * 256 + (int)threadIdx.x;
-  if (l >= F.L) return;
-  double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
-  if (!P.lm_fixed[l]) {
-    auto acc = [&](const double* j, double r0, double r1) {
-      h[0] += j[0] * j[0] + j[3] * j[3]; h[1] += j[0] * j[1] + j[3] * j[4]; h[2] += j[0] * j[2] + j[3] * j[5];
-      h[3] += j[1] * j[1] + j[4] * j[4]; h[4] += j[1] * j[2] + j[4] * j[5]; h[5] += j[2] * j[2] + j[5] * j[5];
-      gl[0] += j[0] * r0 + j[3] * r1; gl[1] += j[1] * r0 + j[4] * r1; gl[2] += j[2] * r0 + j[5] * r1;
-    };
-    // a landmark's observations sit in K different cameras' blocks: every record is its own L2 round trip.  Four records
-    // (index, then 8 doubles each) are requested together instead of one after the other; the sums keep their order.
-    int e = F.lmStart[l];
-    const int e1 = F.lmStart[l + 1];
-    for (; e + 4 <= e1; e += 4) {
-      int pp[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) pp[u] = F.lmObs[e + u];
-      double jj[4][6], rr[4][2];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) jj[u][i] = Jl[6 * (size_t)pp[u] + i];
-        rr[u][0] = res[2 * (size_t)pp[u]]; rr[u][1] = res[2 * (size_t)pp[u] + 1];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) acc(jj[u], rr[u][0], rr[u][1]);
-    }
-    for (; e < e1; e++) {
-      const int p = F.lmObs[e];
-      double j6[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) j6[i] = Jl[6 * (size_t)p + i];
-      acc(j6, res[2 * (size_t)p], res[2 * (size_t)p + 1]);
-    }
-  }
-  double* H = F.Hll + 9 * (size_t)l;
-  H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
-  F.g[6 * F.K + 3 * l] = gl[0]; F.g[6 * F.K + 3 * l + 1] = gl[1]; F.g[6 * F.K + 3 * l + 2] = gl[2];
-}
-
-// camera c: thread k < 28 sums the camera's chunk partials in chunk order (k < 21: H_pp upper triangle, 21..26: g, 27: cost).
-// costOnly (a trust-region candidate's cost, flags == 0): only the cost column — H_pp and g keep the ACCEPTED point's values, which
-// the next trial step needs again if this candidate is rejected
-__device__ __forceinline__ void ba_fold_camera(const int c, const BaFold& F, const double* __restrict__ partial) {
-  const int k = (int)threadIdx.x;
-  if (k >= 28 || (F.costOnly && k != 27)) return;
-  double sacc = 0;
-  for (int ch = F.camChunkStart[c]; ch < F.camChunkStart[c + 1]; ch++) sacc += partial[(size_t)ch * 28 + k];
-  if (k < 21) {
-    int a = 0, rem = k;
-    while (rem >= 6 - a) { rem -= 6 - a; a++; }
-    const int bcol = a + rem;
-    F.Hpp[36 * (size_t)c + 6 * a + bcol] = sacc;
-    F.Hpp[36 * (size_t)c + 6 * bcol + a] = sacc;
-  } else if (k < 27) {
-    F.g[6 * c + (k - 21)] = sacc;
-  } else {
-    F.costCam[c] = sacc;
-  }
-}
-
-// one ticket: every thread's earlier stores are complete and released, thread 0 draws; true on all threads of the workgroup that drew
-// the last of `need` tickets (its later loads are acquired; the counter is reset for the next launch)
-__device__ __forceinline__ bool ba_last_arrival(int* counter, int need) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = ticket == need - 1 ? 1 : 0;
-    if (s_last) {
-      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-
 __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restrict__ chunks, int flags,
                                                  double* __restrict__ res, double* __restrict__ Jp, double* __restrict__ Jl,
                                                  double* __restrict__ W, double* __restrict__ partial,
                                                  double* __restrict__ rawRes, double* __restrict__ rawJq,
-                                                 double* __restrict__ rawJt, double* __restrict__ rawJX, BaFold F) {
+                                                 double* __restrict__ rawJt, double* __restrict__ rawJX) {
   if (P.gate && !*P.gate) return;
   const int nEval = (int)gridDim.x - P.acc_blocks;
   if ((int)blockIdx.x >= nEval) {
@@ -372,33 +271,129 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev P, const BaChunk* __restr
     for (int i = i0; i < 3 * P.acc_L; i += stride) P.acc_X0[i] = P.X[i];
     return;
   }
-  const int bid = (int)blockIdx.x;
-  ba_eval_body(bid, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
-  // landmark groups this chunk contributed to (none for a cost-only evaluation: no derivatives were stored)
-  if (F.withLm)
-    for (int e = F.chunkGroupStart[bid]; e < F.chunkGroupStart[bid + 1]; e++) {
-      const int group = F.chunkGroups[e];
-      if (ba_last_arrival(F.groupCnt + group, F.groupNeed[group])) ba_fold_landmarks(group, P, F, res, Jl);
-    }
-  const int c = chunks[bid].cam;
-  if (!ba_last_arrival(F.camCnt + c, F.camChunkStart[c + 1] - F.camChunkStart[c])) return;
-  ba_fold_camera(c, F, partial);
-  if (!ba_last_arrival(F.camsDone, F.K == 0 ? 1 : F.camsWithChunks)) return;
-  // total cost = sum over cameras in index order (fixed-shape tree: deterministic)
-  __shared__ double s_red[256];
-  const int tid = threadIdx.x;
-  double sacc = 0;
-  const int per = (F.K + 255) / 256;
-  for (int i = tid * per; i < min(F.K, (tid + 1) * per); i++) sacc += __hip_atomic_load(&F.costCam[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  s_red[tid] = sacc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) s_red[tid] += s_red[tid + o];
-    __syncthreads();
-  }
-  if (tid == 0) *F.cost = s_red[0];
+  ba_eval_body((int)blockIdx.x, P, chunks, flags, res, Jp, Jl, W, partial, rawRes, rawJq, rawJt, rawJX);
 }
 
+__device__ __forceinline__ void ba_reduce_body(const int bid, const int nReduce, BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
+                                                   const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
+                                                   const int* __restrict__ lmObs, const double* __restrict__ res,
+                                                   const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
+                                                   int withLm, int costOnly, double* __restrict__ Hpp, double* __restrict__ Hll,
+                                                   double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
+                                                   int* __restrict__ ticketCounter) {
+  const int tid = threadIdx.x;
+  if ((int)bid < lmBlocks) {
+    if (!withLm) return;
+    const int l = bid * 256 + tid;
+    if (l >= L) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+    if (!P.lm_fixed[l]) {
+      auto acc = [&](const double* j, double r0, double r1) {
+        h[0] += j[0] * j[0] + j[3] * j[3]; h[1] += j[0] * j[1] + j[3] * j[4]; h[2] += j[0] * j[2] + j[3] * j[5];
+        h[3] += j[1] * j[1] + j[4] * j[4]; h[4] += j[1] * j[2] + j[4] * j[5]; h[5] += j[2] * j[2] + j[5] * j[5];
+        gl[0] += j[0] * r0 + j[3] * r1; gl[1] += j[1] * r0 + j[4] * r1; gl[2] += j[2] * r0 + j[5] * r1;
+      };
+      // a landmark's observations sit in K different cameras' blocks: every record is its own L2 round trip.  Four records
+      // (index, then 8 doubles each) are requested together instead of one after the other; the sums keep their order.
+      int e = lmStart[l];
+      const int e1 = lmStart[l + 1];
+      for (; e + 4 <= e1; e += 4) {
+        int pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pp[u] = lmObs[e + u];
+        double jj[4][6], rr[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) jj[u][i] = Jl[6 * (size_t)pp[u] + i];
+          rr[u][0] = res[2 * (size_t)pp[u]]; rr[u][1] = res[2 * (size_t)pp[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc(jj[u], rr[u][0], rr[u][1]);
+      }
+      for (; e < e1; e++) {
+        const int p = lmObs[e];
+        double j6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) j6[i] = Jl[6 * (size_t)p + i];
+        acc(j6, res[2 * (size_t)p], res[2 * (size_t)p + 1]);
+      }
+    }
+    double* H = Hll + 9 * (size_t)l;
+    H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
+    g[6 * K + 3 * l] = gl[0]; g[6 * K + 3 * l + 1] = gl[1]; g[6 * K + 3 * l + 2] = gl[2];
+    return;
+  }
+  // camera fold: 8 cameras per workgroup, thread (c, k) sums the camera's chunk partials in chunk order (k = 27: cost)
+  const int cb = (int)bid - lmBlocks;
+  const int c = cb * 8 + (tid >> 5), k = tid & 31;
+  // costOnly (a trust-region candidate's cost, flags == 0): fold only the cost column — H_pp and g keep the ACCEPTED point's
+  // values, which the next trial step needs again if this candidate is rejected
+  if (c < K && k < 28 && (!costOnly || k == 27)) {
+    double sacc = 0;
+    for (int ch = camChunkStart[c]; ch < camChunkStart[c + 1]; ch++) sacc += partial[(size_t)ch * 28 + k];
+    if (k < 21) {
+      int a = 0, rem = k;
+      while (rem >= 6 - a) { rem -= 6 - a; a++; }
+      const int bcol = a + rem;
+      Hpp[36 * (size_t)c + 6 * a + bcol] = sacc;
+      Hpp[36 * (size_t)c + 6 * bcol + a] = sacc;
+    } else if (k < 27) {
+      g[6 * c + (k - 21)] = sacc;
+    } else {
+      costCam[c] = sacc;
+    }
+  }
+  // total cost = sum over cameras in index order, done by whichever camera workgroup arrives last (agent-scope
+  // release -> ticket -> acquire, cdna_hip_programming.md Guideline 16); the ticket counter is reset for the next launch
+  __shared__ int s_last;
+  __shared__ double s_red[256];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nCamBlocks = nReduce - lmBlocks;
+    const int ticket = __hip_atomic_fetch_add(ticketCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == nCamBlocks - 1 ? 1 : 0;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (s_last) {
+    double sacc = 0;
+    const int per = (K + 255) / 256;
+    for (int i = tid * per; i < min(K, (tid + 1) * per); i++) sacc += __hip_atomic_load(&costCam[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_red[tid] = sacc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {  // fixed-shape tree: deterministic
+      if (tid < o) s_red[tid] += s_red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) { *cost = s_red[0]; __hip_atomic_store(ticketCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev P, int K, int L, int nChunks, const BaChunk* __restrict__ chunks,
+                                                   const int* __restrict__ camChunkStart, const int* __restrict__ lmStart,
+                                                   const int* __restrict__ lmObs, const double* __restrict__ res,
+                                                   const double* __restrict__ Jl, const double* __restrict__ partial, int lmBlocks,
+                                                   int withLm, int costOnly, double* __restrict__ Hpp, double* __restrict__ Hll,
+                                                   double* __restrict__ g, double* __restrict__ cost, double* __restrict__ costCam,
+                                                   int* __restrict__ ticketCounter) {
+  if (P.gate && !*P.gate) return;
+  ba_reduce_body((int)blockIdx.x, (int)gridDim.x, P, K, L, nChunks, chunks, camChunkStart, lmStart, lmObs, res, Jl, partial, lmBlocks, withLm, costOnly, Hpp, Hll, g, cost, costCam, ticketCounter);
+}
+
+
+// =============================================================================================================================
+// Device-resident Levenberg-Marquardt step: the linear algebra of dvs_ba_solve — Jacobi scaling, LM
+// diagonal, landmark elimination (Schur complement), the reduced camera system's Cholesky, back-substitution, the model cost
+// change and the candidate point — as kernels over the buffers k_ba_eval / k_ba_reduce leave in HBM.  The host keeps only the
+// trust-region decisions and reads one 64-byte status record per trial step.  All reductions run in a fixed order.
+// =============================================================================================================================
 struct LmStatus { int ok, finite; double model_change, sn, xn, cand_cost, gmax, x_cost; int seq, accept; };   // seq: number of this publication; accept: the trial step's verdict (k_lm_norms)
 
 __device__ __forceinline__ double block_sum_fixed(double v, double* sm) {  // 256 threads, fixed tree
@@ -958,9 +953,7 @@ struct dvs_ba {
   BaChunk* d_chunks = nullptr;
   double *d_res = nullptr, *d_Jp = nullptr, *d_Jl = nullptr, *d_W = nullptr, *d_partial = nullptr;
   double *d_Hpp = nullptr, *d_Hll = nullptr, *d_g = nullptr, *d_cost = nullptr, *d_costCam = nullptr;
-  // chained reductions of k_ba_eval (BaFold): landmark groups per chunk, chunks per group, arrival counters (zero between launches)
-  int *d_chunkGroupStart = nullptr, *d_chunkGroups = nullptr, *d_groupNeed = nullptr, *d_counters = nullptr;   // counters: [groups | K | 1]
-  int camsWithChunks = 0;
+  int* d_ticket = nullptr;   // k_ba_reduce: arrival counter of its camera workgroups (the last one sums the cost)
   double *d_raw = nullptr;  // R*(2+8+6+6)
   // device LM (dvs_ba_solve_device): accepted point, scaling, LM diagonal, step, per-landmark inverses, scaled W, Y = W V^-1,
   // reduced system, observation-of-(landmark, camera) table
@@ -984,7 +977,7 @@ namespace {
 
 void ba_free(dvs_ba* h) {
   void* ptrs[] = {h->d_q, h->d_t, h->d_X, h->d_uv, h->d_cam, h->d_lm, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_pf,
-                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw, h->d_costCam, h->d_chunkGroupStart, h->d_chunkGroups, h->d_groupNeed, h->d_counters};
+                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw, h->d_costCam, h->d_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   void* lmp[] = {h->d_q0, h->d_t0, h->d_X0, h->d_scale, h->d_diag, h->d_step, h->d_Vinv, h->d_Ws, h->d_Y, h->d_S, h->d_rhs, h->d_lmPart,
                  h->d_normPart, h->d_obsOf, h->d_slotCam, h->d_active, h->d_status};
@@ -997,8 +990,7 @@ void ba_free(dvs_ba* h) {
   h->lm_ready = false;
   h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
   h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
-  h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr;
-  h->d_chunkGroupStart = h->d_chunkGroups = h->d_groupNeed = h->d_counters = nullptr;
+  h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr; h->d_ticket = nullptr;
 }
 
 template <class T>
@@ -1024,16 +1016,15 @@ dvs_status enqueue_eval(dvs_ba* h, int flags, bool withLm) {
   if (h->R == 0) return DVS_OK;
   const BaDev P = dev_view(h);
   double* raw = h->d_raw;
-  BaFold F;
-  F.K = h->K; F.L = h->L; F.withLm = withLm ? 1 : 0; F.costOnly = flags == 0 ? 1 : 0;
-  F.camChunkStart = h->d_camChunkStart; F.lmStart = h->d_lmStart; F.lmObs = h->d_lmObs;
-  F.chunkGroupStart = h->d_chunkGroupStart; F.chunkGroups = h->d_chunkGroups; F.groupNeed = h->d_groupNeed;
-  F.groupCnt = h->d_counters; F.camCnt = h->d_counters + h->lmBlocks; F.camsDone = h->d_counters + h->lmBlocks + h->K;
-  F.camsWithChunks = h->camsWithChunks;
-  F.Hpp = h->d_Hpp; F.Hll = h->d_Hll; F.g = h->d_g; F.cost = h->d_cost; F.costCam = h->d_costCam;
   hipLaunchKernelGGL(k_ba_eval, dim3(h->nChunks + P.acc_blocks), dim3(256), 0, h->stream, P, h->d_chunks, flags, h->d_res, h->d_Jp, h->d_Jl, h->d_W,
                      h->d_partial, raw, raw ? raw + 2 * (size_t)h->R : nullptr, raw ? raw + 10 * (size_t)h->R : nullptr,
-                     raw ? raw + 16 * (size_t)h->R : nullptr, F);
+                     raw ? raw + 16 * (size_t)h->R : nullptr);
+  // the reductions need every chunk's records: a second launch.  (Chained into the evaluation launch by arrival tickets they were
+  // bit-identical and SLOWER — 17.2 vs 13.2 us for one window, 6.3 vs 1.33 us per window in a 64-window batch: an agent-scope release
+  // per workgroup writes back the XCD's L2; profiles/r03_ba_chained_reduction_experiment.json.)
+  hipLaunchKernelGGL(k_ba_reduce, dim3(h->lmBlocks + (h->K + 7) / 8), dim3(256), 0, h->stream, P, h->K, h->L, h->nChunks, h->d_chunks,
+                     h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_res, h->d_Jl, h->d_partial, h->lmBlocks, withLm ? 1 : 0,
+                     flags == 0 ? 1 : 0, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_costCam, h->d_ticket);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
@@ -1193,25 +1184,7 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
   DVS_HIP(hipMemset(h->d_Hpp, 0, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMemset(h->d_Hll, 0, (size_t)std::max(L, 1) * 9 * 8));
   DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
   DVS_HIP(hipMalloc((void**)&h->d_costCam, (size_t)std::max(K, 1) * 8)); DVS_HIP(hipMemset(h->d_costCam, 0, (size_t)std::max(K, 1) * 8));
-  {  // chained reductions: the landmark groups (256 landmarks) each chunk's observations touch, and how many chunks touch each group
-    std::vector<int> cgStart(h->nChunks + 1, 0), cg, need(std::max(h->lmBlocks, 1), 0);
-    std::vector<int> stamp(std::max(h->lmBlocks, 1), -1);
-    for (int ch = 0; ch < h->nChunks; ch++) {
-      cgStart[ch] = (int)cg.size();
-      for (int p = chunks[ch].start; p < chunks[ch].start + chunks[ch].count; p++) {
-        const int gr = h->lm[p] >> 8;
-        if (stamp[gr] != ch) { stamp[gr] = ch; cg.push_back(gr); need[gr]++; }
-      }
-      std::sort(cg.begin() + cgStart[ch], cg.end());
-    }
-    cgStart[h->nChunks] = (int)cg.size();
-    h->camsWithChunks = 0;
-    for (int c = 0; c < K; c++) h->camsWithChunks += camChunkStart[c + 1] > camChunkStart[c] ? 1 : 0;
-    DVS_TRY(up(&h->d_chunkGroupStart, cgStart.data(), cgStart.size())); DVS_TRY(up(&h->d_chunkGroups, cg.data(), cg.size()));
-    DVS_TRY(up(&h->d_groupNeed, need.data(), need.size()));
-    const size_t nc = (size_t)h->lmBlocks + K + 1;
-    DVS_HIP(hipMalloc((void**)&h->d_counters, nc * 4)); DVS_HIP(hipMemset(h->d_counters, 0, nc * 4));
-  }
+  DVS_HIP(hipMalloc((void**)&h->d_ticket, 4)); DVS_HIP(hipMemset(h->d_ticket, 0, 4));
   DVS_HIP(hipStreamSynchronize(nullptr));  // the memsets above run on the null stream; the handle's stream is non-blocking
   return DVS_OK;
 }

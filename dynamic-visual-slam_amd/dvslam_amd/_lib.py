@@ -4,7 +4,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO_PATH = os.path.join(_PKG, "lib", "libdvslam_hip.so")
+SO_PATH = os.environ.get("DVSLAM_HIP_SO") or os.path.join(_PKG, "lib", "libdvslam_hip.so")   # (the override: A/B runs of two builds)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])

@@ -208,11 +208,10 @@ def test_device_and_host_schur_agree_through_rejections(gpu):
     assert np.allclose(ta[:, 5], tb[:, 5], rtol=1e-2, atol=0) and abs(sa.final_cost - sb.final_cost) <= 1e-6 * sa.final_cost
 
 
-def test_chained_reductions_do_not_depend_on_arrival_or_observation_order(gpu, oracle):
-    """k_ba_eval folds H_ll / g_l per landmark group, H_pp / g_p per camera and the total cost inside the evaluation launch: whichever
-    workgroup draws the last arrival ticket of a group / camera does the fold, in index order.  With observations in a scrambled order
-    (every chunk touches many landmark groups), partial visibility, a camera without observations and landmarks without any, the
-    result equals the oracle's (1e-12) and is the same bit for bit over repeated launches (arrival order varies, the sums must not)"""
+def test_reductions_do_not_depend_on_observation_order_or_launch(gpu, oracle):
+    """k_ba_reduce folds H_ll / g_l per landmark, H_pp / g_p per camera and the total cost (whichever camera workgroup arrives last
+    sums it) in index order.  With observations in a scrambled order, partial visibility, a camera without observations and landmarks
+    without any, the result equals the oracle's (1e-12) and is the same bit for bit over repeated launches"""
     import oracle_bindings as ob
     from dvslam_amd import BAProblem
     P = synth.make_ba_problem(K=7, L=900, seed=5)
