@@ -42,9 +42,12 @@ inline std::vector<int32_t> associateSequential(dvs_matcher* ctx, const uint8_t*
   std::vector<int64_t> offs((size_t)nobs + 1, 0);
   std::vector<int32_t> cand;
   int64_t total = 0;
+  // one evaluation in the common case: a candidate list sized for 16 landmarks below the Hamming bound per observation; the call is
+  // repeated (threshold match, reprojection kernel, uploads) only when a keyframe has more
+  cand.resize((size_t)nobs * 16 + 64);
   dvs_status st = dvs_associate_candidates(ctx, obs_desc, obs_px, nobs, lm_desc, lm_xyz, nlm, R, t, fx, fy, cx, cy, max_descriptor_distance,
-                                           max_reprojection_distance, best.data(), offs.data(), nullptr, 0, &total);
-  if (st == DVS_OK && total > 0) {
+                                           max_reprojection_distance, best.data(), offs.data(), cand.data(), (int64_t)cand.size(), &total);
+  if (st == DVS_ERR_CAPACITY && total > (int64_t)cand.size()) {
     cand.resize((size_t)total);
     st = dvs_associate_candidates(ctx, obs_desc, obs_px, nobs, lm_desc, lm_xyz, nlm, R, t, fx, fy, cx, cy, max_descriptor_distance,
                                   max_reprojection_distance, best.data(), offs.data(), cand.data(), total, &total);
