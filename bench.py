@@ -393,19 +393,22 @@ def main():
     # synthesis above and runs its first ~25 steps 10-15 % slower, profiles/r03_steps_warmup_sweep.json).  K steps each, hipEvents
     # around every stage launch on the stream it runs on (the events cost ~10 us of stream time per stage, so they never share the
     # whole-job timing below):
-    # (a) the pipelined schedule: what a kernel takes WHILE its neighbours share the machine (= rocprofv3's statistics of this command)
-    K = args.steps
-    orb.enable_stage_timing(True)
-    for k in range(K):
-        pipe.step(img[k % NB], img[(k + 1) % NB], match=False)
-    pipe.synchronize()
-    ov_ms, ov_calls = orb.stage_times()
     # (b) every kernel alone on the stream: the kernel's own duration, which the rooflines below are computed from
+    K = args.steps
     orb.set_overlap(False)
+    orb.enable_stage_timing(True)
     for k in range(K):
         pipe.step(img[k % NB], 0, match=False)
     pipe.synchronize()
     stage_ms, stage_calls = orb.stage_times()
+    orb.set_overlap(True)
+    # (a) the pipelined schedule: what a kernel takes WHILE its neighbours share the machine (= rocprofv3's statistics of this command);
+    #     last, so that the timed region follows work of its own intensity
+    pipe.i = 0
+    for k in range(K):
+        pipe.step(img[k % NB], img[(k + 1) % NB])
+    pipe.synchronize()
+    ov_ms, ov_calls = orb.stage_times()
     orb.enable_stage_timing(False)
     orb.set_overlap(True)
     pipe.i = 0
