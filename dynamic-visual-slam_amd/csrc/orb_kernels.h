@@ -744,10 +744,14 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       const s16x2 r4 = pick(R0, O0, 3), r12 = pick(O0, L0, 1);             // ring 4 ( 3, 0), ring 12 (-3, 0)
       const s16x2 r2 = pick(Rp2, Op2, 2), r14 = pick(Op2, Lp2, 2);         // ring 2 ( 2, 2), ring 14 (-2, 2)
       const s16x2 r6 = pick(Rm2, Om2, 2), r10 = pick(Om2, Lm2, 2);         // ring 6 ( 2,-2), ring 10 (-2,-2)
-      const s16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
-                                                 __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
-      const s16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
-                                                 __builtin_elementwise_min(__builtin_elementwise_max(r2, r10), __builtin_elementwise_max(r6, r14)));
+      // the four pair minima / maxima and their fold on the packed f16 pipe (byte values are f16 denormals: their order is the integer
+      // order and min / max never round — as in the score stage): the 3-operand forms fold four values in two instructions
+      auto f = [](s16x2 a) { return __builtin_bit_cast(f16x2, a); };
+      auto mn2 = [&](s16x2 a, s16x2 b) { return __builtin_elementwise_minimum(f(a), f(b)); };
+      auto mx2 = [&](s16x2 a, s16x2 b) { return __builtin_elementwise_maximum(f(a), f(b)); };
+      const f16x2 mnf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_elementwise_maximum(mn2(r0, r8), mn2(r4, r12)), mn2(r2, r10)), mn2(r6, r14));
+      const f16x2 mxf = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_elementwise_minimum(mx2(r0, r8), mx2(r4, r12)), mx2(r2, r10)), mx2(r6, r14));
+      const s16x2 mn = __builtin_bit_cast(s16x2, mnf), mx = __builtin_bit_cast(s16x2, mxf);
       const s16x2 e1 = (mn + T2) - v2;   // < 0  <=>  mn < v - t
       const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
       sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
