@@ -943,6 +943,11 @@ struct dvs_ba {
   std::vector<int> cam, lm, perm;         // camera-sorted observation arrays, perm[p] = original index
   std::vector<int> lmStart, lmObs;
   std::vector<unsigned char> pose_fixed, lm_fixed;
+  // Device memory of a problem is ONE grow-only arena (dvs_ba_set_problem) and of the LM workspace another (dvs_ba_solve_device); the
+  // host-side tables reach the first through ONE pinned staging block and ONE asynchronous copy on the handle's stream.  A new window
+  // of the same or a smaller shape (SlidingWindowBA::optimize, every 2 s in the reference) allocates nothing.
+  struct Arena { uint8_t* base = nullptr; size_t cap = 0; } prob_arena, lm_arena;
+  uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
   bool lm_poll = true, lm_speculate = true;   // DVS_LM_POLL=0 / DVS_LM_SPECULATE=0 (read once in dvs_ba_create): A/B switches of dvs_ba_solve_device
   bool lm_ready = false;   // dvs_ba_solve_device: structure tables built and uploaded
   int lm_nc = 0;           // ... free cameras
@@ -964,6 +969,7 @@ struct dvs_ba {
   dvs::LmStatus* d_status = nullptr;
   dvs::LmStatus* h_status = nullptr;  // pinned
   double* h_out = nullptr;            // pinned staging of the solved parameters (q, t, X)
+  size_t h_out_cap = 0;
   const int* eval_gate = nullptr;     // see BaDev::gate
   bool eval_accept = false;           // see BaDev::acc_*
   std::vector<double> trace;          // dvs_ba_get_trace: 6 doubles per trust-region iteration of the last solve
@@ -975,28 +981,40 @@ struct dvs_ba {
 
 namespace {
 
-void ba_free(dvs_ba* h) {
-  void* ptrs[] = {h->d_q, h->d_t, h->d_X, h->d_uv, h->d_cam, h->d_lm, h->d_camChunkStart, h->d_lmStart, h->d_lmObs, h->d_pf,
-                  h->d_lf, h->d_chunks, h->d_res, h->d_Jp, h->d_Jl, h->d_W, h->d_partial, h->d_Hpp, h->d_Hll, h->d_g, h->d_cost, h->d_raw, h->d_costCam, h->d_ticket};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
-  void* lmp[] = {h->d_q0, h->d_t0, h->d_X0, h->d_scale, h->d_diag, h->d_step, h->d_Vinv, h->d_Ws, h->d_Y, h->d_S, h->d_rhs, h->d_lmPart,
-                 h->d_normPart, h->d_obsOf, h->d_slotCam, h->d_active, h->d_status};
-  for (void* p : lmp) if (p) (void)hipFree(p);
-  if (h->h_status) (void)hipHostFree(h->h_status);
-  if (h->h_out) (void)hipHostFree(h->h_out);
-  h->h_out = nullptr;
+// forget the current problem (the arenas and pinned blocks stay)
+void ba_reset(dvs_ba* h) {
+  if (h->d_raw) (void)hipFree(h->d_raw);
   h->d_q0 = h->d_t0 = h->d_X0 = h->d_scale = h->d_diag = h->d_step = h->d_Vinv = h->d_Ws = h->d_Y = h->d_S = h->d_rhs = h->d_lmPart = h->d_normPart = nullptr;
-  h->d_obsOf = h->d_slotCam = nullptr; h->d_active = nullptr; h->d_status = nullptr; h->h_status = nullptr;
+  h->d_obsOf = h->d_slotCam = nullptr; h->d_active = nullptr; h->d_status = nullptr;
   h->lm_ready = false;
   h->d_q = h->d_t = h->d_X = h->d_uv = nullptr; h->d_cam = h->d_lm = h->d_camChunkStart = h->d_lmStart = h->d_lmObs = nullptr;
   h->d_pf = h->d_lf = nullptr; h->d_chunks = nullptr; h->d_res = h->d_Jp = h->d_Jl = h->d_W = h->d_partial = nullptr;
   h->d_Hpp = h->d_Hll = h->d_g = h->d_cost = nullptr; h->d_raw = nullptr; h->d_costCam = nullptr; h->d_ticket = nullptr;
 }
 
-template <class T>
-dvs_status up(T** d, const T* src, size_t n) {
-  DVS_HIP(hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)));
-  if (n) DVS_HIP(hipMemcpy(*d, src, n * sizeof(T), hipMemcpyHostToDevice));
+void ba_release(dvs_ba* h) {
+  ba_reset(h);
+  if (h->prob_arena.base) (void)hipFree(h->prob_arena.base);
+  if (h->lm_arena.base) (void)hipFree(h->lm_arena.base);
+  h->prob_arena = dvs_ba::Arena{}; h->lm_arena = dvs_ba::Arena{};
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  if (h->h_status) (void)hipHostFree(h->h_status);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  h->h_stage = nullptr; h->h_stage_cap = 0; h->h_status = nullptr; h->h_out = nullptr; h->h_out_cap = 0;
+}
+
+// layout of an arena: take() hands out 256-byte aligned offsets; bind() resolves them once the arena is large enough
+struct ArenaPlan {
+  size_t used = 0;
+  size_t take(size_t bytes) { const size_t o = used; used += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; }
+};
+dvs_status arena_fit(dvs_ba::Arena& A, size_t need) {
+  if (need <= A.cap) return DVS_OK;
+  if (A.base) DVS_HIP(hipFree(A.base));
+  A.base = nullptr; A.cap = 0;
+  const size_t cap = need + need / 4;
+  DVS_HIP(hipMalloc((void**)&A.base, cap));
+  A.cap = cap;
   return DVS_OK;
 }
 
@@ -1101,7 +1119,7 @@ void dvs_ba_destroy(dvs_ba* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  ba_free(h);
+  ba_release(h);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1133,7 +1151,7 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
   }
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
-  ba_free(h);
+  ba_reset(h);
   h->K = K; h->L = L; h->R = R;
   h->fx = fx; h->fy = fy; h->cx = cx; h->cy = cy; h->sigma = sigma_pixels; h->huber = huber_delta;
   h->q.assign(q_wxyz, q_wxyz + 4 * (size_t)K); h->t.assign(t, t + 3 * (size_t)K); h->X.assign(X, X + 3 * (size_t)L);
@@ -1169,23 +1187,39 @@ dvs_status dvs_ba_set_problem(dvs_ba* h, int32_t K, const double* q_wxyz, const 
     for (int p = 0; p < R; p++) h->lmObs[cur[h->lm[p]]++] = p;
   }
   h->lmBlocks = (L + 255) / 256;
-  DVS_TRY(up(&h->d_q, h->q.data(), h->q.size())); DVS_TRY(up(&h->d_t, h->t.data(), h->t.size())); DVS_TRY(up(&h->d_X, h->X.data(), h->X.size()));
-  DVS_TRY(up(&h->d_uv, uvp.data(), uvp.size()));
-  DVS_TRY(up(&h->d_cam, h->cam.data(), h->cam.size())); DVS_TRY(up(&h->d_lm, h->lm.data(), h->lm.size()));
-  DVS_TRY(up(&h->d_camChunkStart, camChunkStart.data(), camChunkStart.size()));
-  DVS_TRY(up(&h->d_lmStart, h->lmStart.data(), h->lmStart.size())); DVS_TRY(up(&h->d_lmObs, h->lmObs.data(), h->lmObs.size()));
-  DVS_TRY(up(&h->d_pf, h->pose_fixed.data(), h->pose_fixed.size())); DVS_TRY(up(&h->d_lf, h->lm_fixed.data(), h->lm_fixed.size()));
-  DVS_TRY(up(&h->d_chunks, chunks.data(), chunks.size()));
-  const size_t Rz = std::max(R, 1);
-  DVS_HIP(hipMalloc((void**)&h->d_res, Rz * 2 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Jp, Rz * 12 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Jl, Rz * 6 * 8));
-  DVS_HIP(hipMalloc((void**)&h->d_W, Rz * 18 * 8)); DVS_HIP(hipMalloc((void**)&h->d_partial, (size_t)std::max(h->nChunks, 1) * 28 * 8));
-  DVS_HIP(hipMalloc((void**)&h->d_Hpp, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMalloc((void**)&h->d_Hll, (size_t)std::max(L, 1) * 9 * 8));
-  DVS_HIP(hipMalloc((void**)&h->d_g, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMalloc((void**)&h->d_cost, 8));
-  DVS_HIP(hipMemset(h->d_Hpp, 0, (size_t)std::max(K, 1) * 36 * 8)); DVS_HIP(hipMemset(h->d_Hll, 0, (size_t)std::max(L, 1) * 9 * 8));
-  DVS_HIP(hipMemset(h->d_g, 0, (size_t)(6 * K + 3 * L + 1) * 8)); DVS_HIP(hipMemset(h->d_cost, 0, 8));
-  DVS_HIP(hipMalloc((void**)&h->d_costCam, (size_t)std::max(K, 1) * 8)); DVS_HIP(hipMemset(h->d_costCam, 0, (size_t)std::max(K, 1) * 8));
-  DVS_HIP(hipMalloc((void**)&h->d_ticket, 4)); DVS_HIP(hipMemset(h->d_ticket, 0, 4));
-  DVS_HIP(hipStreamSynchronize(nullptr));  // the memsets above run on the null stream; the handle's stream is non-blocking
+  // one arena: [tables uploaded from the host | buffers that start at zero | evaluation outputs]
+  ArenaPlan pl;
+  const size_t Rz = std::max(R, 1), Kz = std::max(K, 1), Lz = std::max(L, 1), Cz = std::max(h->nChunks, 1);
+  const size_t o_q = pl.take(Kz * 32), o_t = pl.take(Kz * 24), o_X = pl.take(Lz * 24), o_uv = pl.take(Rz * 16), o_cam = pl.take(Rz * 4), o_lm = pl.take(Rz * 4),
+               o_ccs = pl.take((size_t)(K + 1) * 4), o_lms = pl.take((size_t)(L + 1) * 4), o_lmo = pl.take(Rz * 4), o_pf = pl.take(Kz), o_lf = pl.take(Lz),
+               o_chunks = pl.take(Cz * sizeof(BaChunk));
+  const size_t uploadBytes = pl.used;
+  const size_t o_Hpp = pl.take(Kz * 36 * 8), o_Hll = pl.take(Lz * 9 * 8), o_g = pl.take((size_t)(6 * K + 3 * L + 1) * 8), o_cost = pl.take(8), o_costCam = pl.take(Kz * 8),
+               o_ticket = pl.take(4);
+  const size_t zeroBytes = pl.used - uploadBytes;
+  const size_t o_res = pl.take(Rz * 2 * 8), o_Jp = pl.take(Rz * 12 * 8), o_Jl = pl.take(Rz * 6 * 8), o_W = pl.take(Rz * 18 * 8), o_partial = pl.take(Cz * 28 * 8);
+  DVS_TRY(arena_fit(h->prob_arena, pl.used));
+  if (uploadBytes > h->h_stage_cap) {
+    if (h->h_stage) DVS_HIP(hipHostFree(h->h_stage));
+    h->h_stage = nullptr; h->h_stage_cap = 0;
+    DVS_HIP(hipHostMalloc((void**)&h->h_stage, uploadBytes + uploadBytes / 4));
+    h->h_stage_cap = uploadBytes + uploadBytes / 4;
+  }
+  uint8_t* B = h->prob_arena.base; uint8_t* S = h->h_stage;
+  auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(S + off, src, bytes); };
+  put(o_q, h->q.data(), h->q.size() * 8); put(o_t, h->t.data(), h->t.size() * 8); put(o_X, h->X.data(), h->X.size() * 8);
+  put(o_uv, uvp.data(), uvp.size() * 8); put(o_cam, h->cam.data(), h->cam.size() * 4); put(o_lm, h->lm.data(), h->lm.size() * 4);
+  put(o_ccs, camChunkStart.data(), camChunkStart.size() * 4); put(o_lms, h->lmStart.data(), h->lmStart.size() * 4); put(o_lmo, h->lmObs.data(), h->lmObs.size() * 4);
+  put(o_pf, h->pose_fixed.data(), h->pose_fixed.size()); put(o_lf, h->lm_fixed.data(), h->lm_fixed.size()); put(o_chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
+  h->d_q = (double*)(B + o_q); h->d_t = (double*)(B + o_t); h->d_X = (double*)(B + o_X); h->d_uv = (double*)(B + o_uv);
+  h->d_cam = (int*)(B + o_cam); h->d_lm = (int*)(B + o_lm); h->d_camChunkStart = (int*)(B + o_ccs); h->d_lmStart = (int*)(B + o_lms); h->d_lmObs = (int*)(B + o_lmo);
+  h->d_pf = B + o_pf; h->d_lf = B + o_lf; h->d_chunks = (BaChunk*)(B + o_chunks);
+  h->d_Hpp = (double*)(B + o_Hpp); h->d_Hll = (double*)(B + o_Hll); h->d_g = (double*)(B + o_g); h->d_cost = (double*)(B + o_cost);
+  h->d_costCam = (double*)(B + o_costCam); h->d_ticket = (int*)(B + o_ticket);
+  h->d_res = (double*)(B + o_res); h->d_Jp = (double*)(B + o_Jp); h->d_Jl = (double*)(B + o_Jl); h->d_W = (double*)(B + o_W); h->d_partial = (double*)(B + o_partial);
+  // one copy, one fill, both on the handle's stream: whatever the caller enqueues next on it is ordered behind them
+  DVS_HIP(hipMemcpyAsync(B, S, uploadBytes, hipMemcpyHostToDevice, h->stream));
+  DVS_HIP(hipMemsetAsync(B + uploadBytes, 0, zeroBytes, h->stream));
   return DVS_OK;
 }
 
@@ -1499,26 +1533,46 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
         slot = p;
       }
     hipStream_t st = h->stream;
-    if (!h->d_status) {
-      const size_t Rz = std::max(R, 1);
-      DVS_HIP(hipMalloc((void**)&h->d_q0, (size_t)std::max(K, 1) * 32)); DVS_HIP(hipMalloc((void**)&h->d_t0, (size_t)std::max(K, 1) * 24));
-      DVS_HIP(hipMalloc((void**)&h->d_X0, (size_t)std::max(L, 1) * 24));
-      DVS_HIP(hipMalloc((void**)&h->d_scale, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_diag, (size_t)NT * 8));
-      DVS_HIP(hipMalloc((void**)&h->d_step, (size_t)NT * 8)); DVS_HIP(hipMalloc((void**)&h->d_Vinv, (size_t)std::max(L, 1) * 72));
-      DVS_HIP(hipMalloc((void**)&h->d_Ws, Rz * 144)); DVS_HIP(hipMalloc((void**)&h->d_Y, Rz * 144));
-      DVS_HIP(hipMalloc((void**)&h->d_S, (size_t)(1 + kSchurSplit) * 96 * 96 * 8)); DVS_HIP(hipMalloc((void**)&h->d_rhs, (1 + kSchurSplit) * 96 * 8));
-      DVS_HIP(hipMalloc((void**)&h->d_lmPart, (size_t)std::max(L, 1) * 16));
-      DVS_HIP(hipMalloc((void**)&h->d_normPart, (size_t)((K + L + 255) / 256 + 1) * 16));
-      DVS_HIP(hipMalloc((void**)&h->d_obsOf, obsOf.size() * 4 + 4)); DVS_HIP(hipMalloc((void**)&h->d_slotCam, 64 * 4));
-      DVS_HIP(hipMalloc((void**)&h->d_active, (size_t)NT + 1)); DVS_HIP(hipMalloc((void**)&h->d_status, sizeof(LmStatus)));
-      DVS_HIP(hipHostMalloc((void**)&h->h_status, 2 * sizeof(LmStatus)));   // [0]: the trial's record (k_lm_norms), [1]: the point's (k_lm_gmax)
-      DVS_HIP(hipHostMalloc((void**)&h->h_out, ((size_t)7 * std::max(K, 1) + 3 * (size_t)std::max(L, 1)) * 8));
-      DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
+    {
+      ArenaPlan pl;
+      const size_t Rz = std::max(R, 1), Kz = std::max(K, 1), Lz = std::max(L, 1);
+      const size_t o_obsOf = pl.take(obsOf.size() * 4 + 4), o_slot = pl.take(64 * 4), o_active = pl.take((size_t)NT + 1);
+      const size_t uploadBytes = pl.used;
+      const size_t o_q0 = pl.take(Kz * 32), o_t0 = pl.take(Kz * 24), o_X0 = pl.take(Lz * 24), o_scale = pl.take((size_t)NT * 8), o_diag = pl.take((size_t)NT * 8),
+                   o_step = pl.take((size_t)NT * 8), o_Vinv = pl.take(Lz * 72), o_Ws = pl.take(Rz * 144), o_Y = pl.take(Rz * 144),
+                   o_S = pl.take((size_t)(1 + kSchurSplit) * 96 * 96 * 8), o_rhs = pl.take((size_t)(1 + kSchurSplit) * 96 * 8), o_lmPart = pl.take(Lz * 16),
+                   o_normPart = pl.take((size_t)((K + L + 255) / 256 + 1) * 16), o_status = pl.take(sizeof(LmStatus));
+      DVS_TRY(arena_fit(h->lm_arena, pl.used));
+      if (uploadBytes > h->h_stage_cap) {
+        DVS_HIP(hipStreamSynchronize(st));   // an upload of dvs_ba_set_problem may still be reading the block
+        if (h->h_stage) DVS_HIP(hipHostFree(h->h_stage));
+        h->h_stage = nullptr; h->h_stage_cap = 0;
+        DVS_HIP(hipHostMalloc((void**)&h->h_stage, uploadBytes + uploadBytes / 4));
+        h->h_stage_cap = uploadBytes + uploadBytes / 4;
+      }
+      uint8_t* B = h->lm_arena.base;
+      h->d_obsOf = (int*)(B + o_obsOf); h->d_slotCam = (int*)(B + o_slot); h->d_active = B + o_active;
+      h->d_q0 = (double*)(B + o_q0); h->d_t0 = (double*)(B + o_t0); h->d_X0 = (double*)(B + o_X0); h->d_scale = (double*)(B + o_scale);
+      h->d_diag = (double*)(B + o_diag); h->d_step = (double*)(B + o_step); h->d_Vinv = (double*)(B + o_Vinv); h->d_Ws = (double*)(B + o_Ws); h->d_Y = (double*)(B + o_Y);
+      h->d_S = (double*)(B + o_S); h->d_rhs = (double*)(B + o_rhs); h->d_lmPart = (double*)(B + o_lmPart); h->d_normPart = (double*)(B + o_normPart);
+      h->d_status = (LmStatus*)(B + o_status);
+      if (!h->h_status) {
+        DVS_HIP(hipHostMalloc((void**)&h->h_status, 2 * sizeof(LmStatus)));   // [0]: the trial's record (k_lm_norms), [1]: the point's (k_lm_gmax)
+        DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
+      }
+      const size_t outBytes = ((size_t)7 * Kz + 3 * Lz) * 8;
+      if (outBytes > h->h_out_cap) {
+        if (h->h_out) DVS_HIP(hipHostFree(h->h_out));
+        h->h_out = nullptr; h->h_out_cap = 0;
+        DVS_HIP(hipHostMalloc((void**)&h->h_out, outBytes + outBytes / 4));
+        h->h_out_cap = outBytes + outBytes / 4;
+      }
+      DVS_HIP(hipStreamSynchronize(st));     // the staging block is free (dvs_ba_set_problem's upload has completed)
+      memcpy(h->h_stage + o_obsOf, obsOf.data(), obsOf.size() * 4);
+      memcpy(h->h_stage + o_slot, slotCam.data(), (size_t)nc * 4);
+      memcpy(h->h_stage + o_active, active.data(), (size_t)NT);
+      DVS_HIP(hipMemcpyAsync(B, h->h_stage, uploadBytes, hipMemcpyHostToDevice, st));
     }
-    DVS_HIP(hipMemcpyAsync(h->d_obsOf, obsOf.data(), obsOf.size() * 4, hipMemcpyHostToDevice, st));
-    DVS_HIP(hipMemcpyAsync(h->d_slotCam, slotCam.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
-    DVS_HIP(hipMemcpyAsync(h->d_active, active.data(), (size_t)NT, hipMemcpyHostToDevice, st));
-    DVS_HIP(hipStreamSynchronize(st));   // the host vectors go out of scope
     h->lm_nc = nc;
     h->lm_ready = true;
   }

@@ -13,6 +13,10 @@ class BAProblem:
         h = C.c_void_p()
         check(self._L.dvs_ba_create(device, C.byref(h)))
         self._h = h
+        self.set_problem(prob)
+
+    def set_problem(self, prob):
+        """a new window on the same handle (what SlidingWindowBA::optimize does per call): device memory is reused when it fits"""
         self.K, self.L, self.R = int(prob["K"]), int(prob["L"]), len(prob["cam_idx"])
         a = lambda k, dt: np.ascontiguousarray(prob[k], dt)
         self._keep = [a("q", np.float64), a("t", np.float64), a("X", np.float64), a("cam_idx", np.int32), a("lm_idx", np.int32),

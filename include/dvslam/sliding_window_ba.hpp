@@ -10,8 +10,9 @@
 //   ::SlidingWindowBA, ::KeyframeData… the reference's own global-namespace types with cv::Mat / cv::Point3d / rclcpp::Time,
 //                                      in include/dynamic_visual_slam/bundle_adjustment.hpp — the same include path as the
 //                                      reference header, so backend.cpp:180, 661, 908-973, 1356-1392 compile unchanged.
-// One dvs_ba handle (HIP stream, pinned status / result blocks) lives as long as the adapter object; the per-window device buffers
-// are re-created by dvs_ba_set_problem on every optimize() (a window is a new problem: ~40 allocations, about a millisecond).
+// One dvs_ba handle (HIP stream, pinned blocks, two grow-only device arenas) lives as long as the adapter object: a window whose
+// shape fits the arenas allocates nothing — dvs_ba_set_problem is one pinned staging copy + one fill on the handle's stream
+// (0.11 ms for 10 keyframes x 2000 landmarks, tools/time_ba_setup.py).
 #pragma once
 #include <array>
 #include <chrono>
