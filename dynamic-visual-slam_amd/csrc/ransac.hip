@@ -40,6 +40,10 @@ __host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long 
   return z ^ (z >> 31);
 }
 
+// One RANSAC problem of a batch (blockIdx.y of every kernel below): its correspondences are rows [off, off + n) of the point arrays,
+// its hypotheses / counts / results slot `b` of the per-problem arrays.  The single-problem entry points are batches of one.
+struct RansacProb { int off, n; unsigned long long seed; };
+
 // k distinct indices out of n (k <= 8), uniform without replacement, in draw order
 template <int KS>
 __device__ __forceinline__ void sample_distinct(unsigned long long seed, int h, int n, int* idx) {
@@ -82,12 +86,17 @@ __device__ __forceinline__ void smallest_eigvec3(const double* S, double* v) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // fundamental matrix: one thread = one hypothesis from 8 correspondences (x2^T F x1 = 0)
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_f_hypotheses(const float* __restrict__ p1, const float* __restrict__ p2, int n, int H,
-                                                     unsigned long long seed, double* __restrict__ Fout, int* __restrict__ valid) {
+__global__ __launch_bounds__(64) void k_f_hypotheses(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
+                                                     double* __restrict__ Fout, int* __restrict__ valid) {
   const int h = blockIdx.x * 64 + threadIdx.x;
   if (h >= H) return;
+  const RansacProb pb = probs[blockIdx.y];
+  const int n = pb.n;
+  p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off;
+  Fout += 9 * (size_t)H * blockIdx.y; valid += (size_t)H * blockIdx.y;
+  if (n < 8) { valid[h] = 0; return; }
   int idx[8];
-  sample_distinct<8>(seed, h, n, idx);
+  sample_distinct<8>(pb.seed, h, n, idx);
   double x1[8], y1[8], x2[8], y2[8];
   double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
   for (int i = 0; i < 8; i++) {
@@ -224,9 +233,13 @@ __device__ __forceinline__ int block_count256(bool pred) {  // number of threads
 }
 
 // one workgroup per hypothesis: inlier count over all correspondences
-__global__ __launch_bounds__(256) void k_f_score(const float* __restrict__ p1, const float* __restrict__ p2, int n, const double* __restrict__ Fall,
-                                                 const int* __restrict__ valid, double thr2, int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_f_score(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
+                                                 const double* __restrict__ Fall, const int* __restrict__ valid, double thr2, int* __restrict__ counts) {
   const int h = blockIdx.x;
+  const RansacProb pb = probs[blockIdx.y];
+  const int n = pb.n;
+  p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off;
+  Fall += 9 * (size_t)H * blockIdx.y; valid += (size_t)H * blockIdx.y; counts += (size_t)H * blockIdx.y;
   if (!valid[h]) { if (threadIdx.x == 0) counts[h] = 0; return; }
   double F[9];
   for (int k = 0; k < 9; k++) F[k] = Fall[9 * (size_t)h + k];
@@ -254,9 +267,11 @@ __device__ __forceinline__ int ransac_update_iters(double p, double ep, int mode
 
 // the sequential RANSAC loop replayed over the hypothesis counts (RANSACPointSetRegistrator::run): hypothesis h is iteration h,
 // a strictly better count replaces the best and shortens the loop.  sel[0] = best hypothesis (-1: none), sel[1] = iterations used.
-__global__ void k_ransac_select(const int* __restrict__ counts, int H, int n, int modelPoints, double confidence, int group,
+__global__ void k_ransac_select(const int* __restrict__ counts, int H, const RansacProb* __restrict__ probs, int modelPoints, double confidence, int group,
                                 int* __restrict__ sel) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0) return;
+  const int n = probs[blockIdx.x].n;
+  counts += (size_t)H * blockIdx.x; sel += 4 * (size_t)blockIdx.x;
   int niters = H / group, best = -1, bestCount = 0, it = 0;
   const int maxIters = niters;
   for (; it < niters; it++) {
@@ -272,8 +287,13 @@ __global__ void k_ransac_select(const int* __restrict__ counts, int H, int n, in
   sel[0] = best; sel[1] = it; sel[2] = bestCount;
 }
 
-__global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, const float* __restrict__ p2, int n, const double* __restrict__ Fall,
-                                                const int* __restrict__ sel, double thr2, unsigned char* __restrict__ mask, double* __restrict__ Fbest) {
+__global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
+                                                const double* __restrict__ Fall, const int* __restrict__ sel, double thr2, unsigned char* __restrict__ mask,
+                                                double* __restrict__ Fbest) {
+  const RansacProb pb = probs[blockIdx.y];
+  const int n = pb.n;
+  p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off; mask += pb.off;
+  Fall += 9 * (size_t)H * blockIdx.y; sel += 4 * (size_t)blockIdx.y; Fbest += 9 * (size_t)blockIdx.y;
   const int best = sel[0];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (best < 0) { if (i < n) mask[i] = 0; if (i < 9) Fbest[i] = 0.0; return; }
@@ -410,13 +430,17 @@ __host__ __device__ __forceinline__ int p3p_solve(const double P[3][3], const do
 }
 
 // one thread = one sample of 3 correspondences -> up to 4 poses; unused slots are marked invalid
-__global__ __launch_bounds__(64) void k_p3p_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, int n, int H,
-                                                       double fx, double fy, double cx, double cy, unsigned long long seed,
-                                                       double* __restrict__ poses, int* __restrict__ valid) {
+__global__ __launch_bounds__(64) void k_p3p_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs, int H,
+                                                       double fx, double fy, double cx, double cy, double* __restrict__ poses, int* __restrict__ valid) {
   const int h = blockIdx.x * 64 + threadIdx.x;
   if (h >= H) return;
+  const RansacProb pb = probs[blockIdx.y];
+  const int n = pb.n;
+  obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off;
+  poses += 12 * (size_t)4 * H * blockIdx.y; valid += (size_t)4 * H * blockIdx.y;
+  if (n < 4) { for (int s = 0; s < 4; s++) valid[4 * h + s] = 0; return; }
   int idx[3];
-  sample_distinct<3>(seed, h, n, idx);
+  sample_distinct<3>(pb.seed, h, n, idx);
   double P[3][3], j[3][3];
   for (int i = 0; i < 3; i++) {
     for (int k = 0; k < 3; k++) P[i][k] = obj[3 * idx[i] + k];
@@ -437,10 +461,14 @@ __device__ __forceinline__ double reproj_err2(const double* R, const double* t, 
   return du * du + dv * dv;
 }
 
-__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ poses,
-                                                   const int* __restrict__ valid, double fx, double fy, double cx, double cy, double thr2,
-                                                   int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs, int H4,
+                                                   const double* __restrict__ poses, const int* __restrict__ valid, double fx, double fy, double cx, double cy,
+                                                   double thr2, int* __restrict__ counts) {
   const int h = blockIdx.x;
+  const RansacProb pb = probs[blockIdx.y];
+  const int n = pb.n;
+  obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off;
+  poses += 12 * (size_t)H4 * blockIdx.y; valid += (size_t)H4 * blockIdx.y; counts += (size_t)H4 * blockIdx.y;
   if (!valid[h]) { if (threadIdx.x == 0) counts[h] = 0; return; }
   double Rt[12];
   for (int k = 0; k < 12; k++) Rt[k] = poses[12 * (size_t)h + k];
@@ -479,9 +507,17 @@ __device__ __forceinline__ void exp_so3(const double* w, double* E) {
 
 // inlier mask of the selected pose, then Levenberg-Marquardt on the reprojection error over the inliers (what
 // SOLVEPNP_ITERATIVE does), one workgroup.  out: rvec (Rodrigues) + tvec; inliers as ascending indices.
-__global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ poses,
-                                                    const int* __restrict__ sel, double fx, double fy, double cx, double cy, double thr2,
-                                                    int* __restrict__ inliers, int* __restrict__ nin, double* __restrict__ rt, int* __restrict__ success) {
+// Per problem (blockIdx.x): results record `res` = {nin, success, pad, pad (16 B) | rvec, tvec (48 B)}, inlier list at inliers + off.
+__global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs, int H4,
+                                                    const double* __restrict__ poses, const int* __restrict__ sel, double fx, double fy, double cx, double cy,
+                                                    double thr2, int* __restrict__ inliers, unsigned char* __restrict__ resAll) {
+  const RansacProb pb = probs[blockIdx.x];
+  const int n = pb.n;
+  obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off; inliers += pb.off;
+  poses += 12 * (size_t)H4 * blockIdx.x; sel += 4 * (size_t)blockIdx.x;
+  int* nin = reinterpret_cast<int*>(resAll + 64 * (size_t)blockIdx.x);
+  int* success = nin + 1;
+  double* rt = reinterpret_cast<double*>(resAll + 64 * (size_t)blockIdx.x + 16);
   __shared__ double sm[256];
   __shared__ double sm27[27][256];   // 54 KB: all normal-equation sums of an iteration in one reduction tree
   __shared__ double sR[9], st[3], sRn[9], stn[3], sH[36], sg[6], sd[6];
@@ -689,99 +725,146 @@ int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48) {
   return p3p_solve(P, j, poses48);
 }
 
-dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
-                                       int32_t max_iters, uint64_t seed, double* F9, uint8_t* inlier_mask, int32_t* n_inliers) {
-  DVS_ARG(ctx && n >= 0 && max_iters >= 1 && max_iters <= 4096 && (inlier_mask || n == 0) && threshold > 0);
-  if (n_inliers) *n_inliers = 0;
-  if (F9) memset(F9, 0, 72);
-  if (n < 8) {  // cv::findFundamentalMat needs >= 7 points for FM_RANSAC (8 for our kernel): empty F, mask of zeros
-    if (inlier_mask) memset(inlier_mask, 0, (size_t)n);
-    return DVS_OK;
-  }
-  DVS_ARG(pts1 && pts2);
+// ---- batches of independent RANSAC problems (one launch sequence for all of them; the single-problem entry points are batches of one) ----
+// problem b = correspondences [offsets[b], offsets[b + 1]) of the concatenated point arrays, sampler seed seeds[b]
+dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
+                                             double confidence, int32_t max_iters, const uint64_t* seeds, double* F9, uint8_t* inlier_mask,
+                                             int32_t* n_inliers) {
+  DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096 && threshold > 0);
+  if (nprob == 0) return DVS_OK;
+  DVS_ARG(offsets && seeds && offsets[0] == 0);
+  int maxn = 0;
+  for (int b = 0; b < nprob; b++) { DVS_ARG(offsets[b + 1] >= offsets[b]); maxn = std::max(maxn, offsets[b + 1] - offsets[b]); }
+  const int total = offsets[nprob];
+  DVS_ARG(total == 0 || (pts1 && pts2 && inlier_mask));
+  if (n_inliers) memset(n_inliers, 0, (size_t)nprob * 4);
+  if (F9) memset(F9, 0, (size_t)nprob * 72);
+  if (total) memset(inlier_mask, 0, (size_t)total);
+  if (maxn < 8) return DVS_OK;   // cv::findFundamentalMat needs >= 7 points for FM_RANSAC (8 for our kernel): empty F, masks of zeros
   DVS_HIP(hipSetDevice(matcher_device(ctx)));
   hipStream_t st = matcher_stream(ctx);
   const int H = max_iters;
-  const size_t pb = ((size_t)n * 8 + 15) & ~(size_t)15;
+  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, pb = ((size_t)total * 8 + 15) & ~(size_t)15;
+  const size_t inb = hb + 2 * pb;
+  const size_t fb = (size_t)nprob * H * 72, vb = (size_t)nprob * H * 4;
+  const size_t outb = ((size_t)nprob * (16 + 72) + (size_t)total + 3) & ~(size_t)3;
   uint8_t* base;
-  DVS_TRY(matcher_scratch(ctx, 0, 2 * pb + (size_t)H * 72 + (size_t)H * 8 + 64 + 80 + (size_t)n + 32, (void**)&base));
-  float* d_p1 = (float*)base; float* d_p2 = (float*)(base + pb);
-  double* d_F = (double*)(base + 2 * pb);
-  int* d_valid = (int*)(d_F + 9 * (size_t)H); int* d_counts = d_valid + H;
-  int* d_sel = d_counts + H;                       // 4 ints
-  double* d_Fb = (double*)(((uintptr_t)(d_sel + 4) + 15) & ~(uintptr_t)15);
-  unsigned char* d_mask = (unsigned char*)(d_Fb + 9);
-  // pinned block: [pts1 | pts2] in, [sel (16) | Fb (72) | mask (n)] out — the device lays the results out the same way
-  const size_t outb = ((size_t)(16 + 72 + n) + 3) & ~(size_t)3;
+  DVS_TRY(matcher_scratch(ctx, 0, inb + fb + 2 * vb + outb + 64, (void**)&base));
+  const RansacProb* d_probs = (const RansacProb*)base;
+  float* d_p1 = (float*)(base + hb); float* d_p2 = (float*)(base + hb + pb);
+  double* d_F = (double*)(base + inb);
+  int* d_valid = (int*)(base + inb + fb); int* d_counts = (int*)(base + inb + fb + vb);
+  uint8_t* d_out = base + inb + fb + 2 * vb;                       // [sel 16 x nprob | Fb 72 x nprob | mask total]: the pinned block's layout
+  int* d_sel = (int*)d_out; double* d_Fb = (double*)(d_out + (size_t)nprob * 16); unsigned char* d_mask = d_out + (size_t)nprob * 88;
   uint8_t* hio; int *hseq, *counter;
-  DVS_TRY(matcher_pinned(ctx, 2 * pb + outb, (void**)&hio, &hseq, &counter));
-  memcpy(hio, pts1, (size_t)n * 8); memcpy(hio + pb, pts2, (size_t)n * 8);
-  const int ndw_in = (int)(2 * pb / 4);
+  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
+  RansacProb* hp = (RansacProb*)hio;
+  for (int b = 0; b < nprob; b++) hp[b] = RansacProb{offsets[b], offsets[b + 1] - offsets[b], (unsigned long long)seeds[b]};
+  memcpy(hio + hb, pts1, (size_t)total * 8); memcpy(hio + hb + pb, pts2, (size_t)total * 8);
+  const int ndw_in = (int)(inb / 4);
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
-  hipLaunchKernelGGL(k_f_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_p1, d_p2, n, H, (unsigned long long)seed, d_F, d_valid);
-  hipLaunchKernelGGL(k_f_score, dim3(H), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_valid, threshold * threshold, d_counts);
-  hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, H, n, 8, confidence, 1, d_sel);
-  hipLaunchKernelGGL(k_f_mask, dim3((std::max(n, 9) + 255) / 256), dim3(256), 0, st, d_p1, d_p2, n, d_F, d_sel, threshold * threshold, d_mask, d_Fb);
-  if ((const uint8_t*)d_Fb - (const uint8_t*)d_sel != 16) { set_error("fundamental result layout"); return DVS_ERR_HIP; }
-  const int seq = ++*counter;
-  hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_sel, (uint32_t*)(hio + 2 * pb), (int)(outb / 4), hseq, seq);
-  DVS_HIP(hipGetLastError());
-  DVS_TRY(io_wait(hseq, seq, st));
-  int sel[4];
-  double Fb[9];
-  memcpy(sel, hio + 2 * pb, 16); memcpy(Fb, hio + 2 * pb + 16, 72); memcpy(inlier_mask, hio + 2 * pb + 88, (size_t)n);
-  if (F9) memcpy(F9, Fb, 72);
-  if (n_inliers) *n_inliers = sel[0] >= 0 ? sel[2] : 0;
+  hipLaunchKernelGGL(k_f_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, H, d_F, d_valid);
+  hipLaunchKernelGGL(k_f_score, dim3(H, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_valid, threshold * threshold, d_counts);
+  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H, d_probs, 8, confidence, 1, d_sel);
+  hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_sel, threshold * threshold, d_mask, d_Fb);
+  uint8_t* hout = hio + inb;
+  if (outb <= 65536) {   // small results leave through the export kernel + a polled sequence number (no copy command, no wake-up)
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, st));
+  } else {
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+  }
+  const int* sel = (const int*)hout;
+  for (int b = 0; b < nprob; b++) {
+    if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
+    if (F9) memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
+  }
+  if (total) memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
+  return DVS_OK;
+}
+
+dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
+                                       int32_t max_iters, uint64_t seed, double* F9, uint8_t* inlier_mask, int32_t* n_inliers) {
+  DVS_ARG(ctx && n >= 0 && (inlier_mask || n == 0));
+  const int32_t offsets[2] = {0, n};
+  return dvs_find_fundamental_ransac_batch(ctx, 1, offsets, pts1, pts2, threshold, confidence, max_iters, &seed, F9, inlier_mask, n_inliers);
+}
+
+// inliers: concatenated like the points (problem b's ascending inlier indices at inliers + offsets[b], n_inliers[b] of them)
+dvs_status dvs_solve_pnp_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts3d, const float* pts2d, const double* K4,
+                                      int32_t iterations, double reproj_err, double confidence, const uint64_t* seeds, double* rvec3, double* tvec3,
+                                      int32_t* inliers, int32_t* n_inliers, int32_t* success) {
+  DVS_ARG(ctx && nprob >= 0 && iterations >= 1 && iterations <= 1024 && K4 && reproj_err > 0);
+  if (nprob == 0) return DVS_OK;
+  DVS_ARG(offsets && seeds && rvec3 && tvec3 && success && offsets[0] == 0);
+  int maxn = 0;
+  for (int b = 0; b < nprob; b++) { DVS_ARG(offsets[b + 1] >= offsets[b]); maxn = std::max(maxn, offsets[b + 1] - offsets[b]); }
+  const int total = offsets[nprob];
+  DVS_ARG(total == 0 || (pts3d && pts2d));
+  memset(success, 0, (size_t)nprob * 4);
+  if (n_inliers) memset(n_inliers, 0, (size_t)nprob * 4);
+  memset(rvec3, 0, (size_t)nprob * 24); memset(tvec3, 0, (size_t)nprob * 24);
+  if (maxn < 4) return DVS_OK;   // cv::solvePnPRansac: "npoints >= 4"
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const int H = iterations, H4 = 4 * H;
+  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, ob = ((size_t)total * 12 + 15) & ~(size_t)15, ib = ((size_t)total * 8 + 15) & ~(size_t)15;
+  const size_t inb = hb + ob + ib;
+  const size_t posb = (size_t)nprob * H4 * 96, vb = (size_t)nprob * H4 * 4, selb = (size_t)nprob * 16;
+  const size_t outb = (size_t)nprob * 64 + (size_t)total * 4;      // [result records 64 x nprob | inlier lists 4 x total]
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, inb + posb + 2 * vb + selb + outb + 64, (void**)&base));
+  const RansacProb* d_probs = (const RansacProb*)base;
+  float* d_obj = (float*)(base + hb); float* d_img = (float*)(base + hb + ob);
+  double* d_poses = (double*)(base + inb);
+  int* d_valid = (int*)(base + inb + posb); int* d_counts = (int*)(base + inb + posb + vb);
+  int* d_sel = (int*)(base + inb + posb + 2 * vb);
+  uint8_t* d_out = base + inb + posb + 2 * vb + selb;
+  int* d_inl = (int*)(d_out + (size_t)nprob * 64);
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
+  RansacProb* hp = (RansacProb*)hio;
+  for (int b = 0; b < nprob; b++) hp[b] = RansacProb{offsets[b], offsets[b + 1] - offsets[b], (unsigned long long)seeds[b]};
+  memcpy(hio + hb, pts3d, (size_t)total * 12); memcpy(hio + hb + ob, pts2d, (size_t)total * 8);
+  const int ndw_in = (int)(inb / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
+  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], thr2 = reproj_err * reproj_err;
+  hipLaunchKernelGGL(k_p3p_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_obj, d_img, d_probs, H, fx, fy, cx, cy, d_poses, d_valid);
+  hipLaunchKernelGGL(k_pnp_score, dim3(H4, nprob), dim3(256), 0, st, d_obj, d_img, d_probs, H4, d_poses, d_valid, fx, fy, cx, cy, thr2, d_counts);
+  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H4, d_probs, 3, confidence, 4, d_sel);
+  hipLaunchKernelGGL(k_pnp_refine, dim3(nprob), dim3(256), 0, st, d_obj, d_img, d_probs, H4, d_poses, d_sel, fx, fy, cx, cy, thr2, d_inl, d_out);
+  uint8_t* hout = hio + inb;
+  if (outb <= 65536) {
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, st));
+  } else {
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+  }
+  for (int b = 0; b < nprob; b++) {
+    int nin = 0, succ = 0;
+    memcpy(&nin, hout + 64 * (size_t)b, 4); memcpy(&succ, hout + 64 * (size_t)b + 4, 4);
+    if (n_inliers) n_inliers[b] = nin;
+    success[b] = succ;
+    if (succ) { memcpy(rvec3 + 3 * (size_t)b, hout + 64 * (size_t)b + 16, 24); memcpy(tvec3 + 3 * (size_t)b, hout + 64 * (size_t)b + 40, 24); }
+    if (inliers && nin > 0) memcpy(inliers + offsets[b], hout + (size_t)nprob * 64 + 4 * (size_t)offsets[b], (size_t)nin * 4);
+  }
   return DVS_OK;
 }
 
 dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
                                 double reproj_err, double confidence, uint64_t seed, double* rvec3, double* tvec3, int32_t* inliers,
                                 int32_t* n_inliers, int32_t* success) {
-  DVS_ARG(ctx && n >= 0 && iterations >= 1 && iterations <= 1024 && K4 && rvec3 && tvec3 && success && reproj_err > 0);
-  *success = 0;
-  if (n_inliers) *n_inliers = 0;
-  memset(rvec3, 0, 24); memset(tvec3, 0, 24);
-  if (n < 4) return DVS_OK;   // cv::solvePnPRansac: "npoints >= 4"
-  DVS_ARG(pts3d && pts2d);
-  DVS_HIP(hipSetDevice(matcher_device(ctx)));
-  hipStream_t st = matcher_stream(ctx);
-  const int H = iterations;
-  const size_t ob = ((size_t)n * 12 + 15) & ~(size_t)15, ib = ((size_t)n * 8 + 15) & ~(size_t)15;
-  uint8_t* base;
-  DVS_TRY(matcher_scratch(ctx, 0, ob + ib + (size_t)4 * H * 96 + (size_t)4 * H * 8 + 64 + 48 + (size_t)n * 4 + 64, (void**)&base));
-  float* d_obj = (float*)base; float* d_img = (float*)(base + ob);
-  double* d_poses = (double*)(base + ob + ib);
-  int* d_valid = (int*)(d_poses + 12 * (size_t)4 * H); int* d_counts = d_valid + 4 * H;
-  int* d_sel = d_counts + 4 * H;                  // 4 ints
-  int* d_nin = d_sel + 4; int* d_succ = d_nin + 1;
-  double* d_rt = (double*)(((uintptr_t)(d_succ + 1) + 15) & ~(uintptr_t)15);
-  int* d_inl = (int*)(d_rt + 6);
-  // pinned block: [pts3d | pts2d] in, [nin, succ (8 + 8 pad) | rt (48) | inliers (4 n)] out — the device's own layout from d_nin on
-  const size_t outb = 16 + 48 + (size_t)n * 4;
-  uint8_t* hio; int *hseq, *counter;
-  DVS_TRY(matcher_pinned(ctx, ob + ib + outb, (void**)&hio, &hseq, &counter));
-  memcpy(hio, pts3d, (size_t)n * 12); memcpy(hio + ob, pts2d, (size_t)n * 8);
-  const int ndw_in = (int)((ob + ib) / 4);
-  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
-  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], thr2 = reproj_err * reproj_err;
-  hipLaunchKernelGGL(k_p3p_hypotheses, dim3((H + 63) / 64), dim3(64), 0, st, d_obj, d_img, n, H, fx, fy, cx, cy, (unsigned long long)seed, d_poses, d_valid);
-  hipLaunchKernelGGL(k_pnp_score, dim3(4 * H), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_valid, fx, fy, cx, cy, thr2, d_counts);
-  hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(1), 0, st, d_counts, 4 * H, n, 3, confidence, 4, d_sel);
-  hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(256), 0, st, d_obj, d_img, n, d_poses, d_sel, fx, fy, cx, cy, thr2, d_inl, d_nin, d_rt, d_succ);
-  if ((const uint8_t*)d_rt - (const uint8_t*)d_nin != 16 || (const uint8_t*)d_inl - (const uint8_t*)d_rt != 48) { set_error("pnp result layout"); return DVS_ERR_HIP; }
-  const int seq = ++*counter;
-  hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_nin, (uint32_t*)(hio + ob + ib), (int)(outb / 4), hseq, seq);
-  DVS_HIP(hipGetLastError());
-  DVS_TRY(io_wait(hseq, seq, st));
-  int nin = 0, succ = 0;
-  double rt[6];
-  memcpy(&nin, hio + ob + ib, 4); memcpy(&succ, hio + ob + ib + 4, 4); memcpy(rt, hio + ob + ib + 16, 48);
-  if (inliers && nin > 0) memcpy(inliers, hio + ob + ib + 64, (size_t)nin * 4);
-  if (n_inliers) *n_inliers = nin;
-  *success = succ;
-  if (succ) { memcpy(rvec3, rt, 24); memcpy(tvec3, rt + 3, 24); }
-  return DVS_OK;
+  DVS_ARG(ctx && n >= 0 && rvec3 && tvec3 && success);
+  const int32_t offsets[2] = {0, n};
+  return dvs_solve_pnp_ransac_batch(ctx, 1, offsets, pts3d, pts2d, K4, iterations, reproj_err, confidence, &seed, rvec3, tvec3, inliers, n_inliers, success);
 }
 
 }  // extern "C"

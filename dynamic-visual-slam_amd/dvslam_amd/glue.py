@@ -40,6 +40,40 @@ class FrontendGlue:
                                            ptr(inl), C.byref(nin), C.byref(ok)))
         return bool(ok.value), rvec, tvec, inl[:nin.value].copy()
 
+    def find_fundamental_ransac_batch(self, pts1_list, pts2_list, seeds, threshold=2.0, confidence=0.99, max_iters=1000):
+        """many independent problems in one launch sequence -> list of (mask uint8[n_b], inliers of the model)"""
+        nprob = len(pts1_list)
+        off = np.zeros(nprob + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in pts1_list])
+        cat = lambda ps: (np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in ps]), np.float32) if off[-1]
+                          else np.zeros((1, 2), np.float32))
+        p1, p2 = cat(pts1_list), cat(pts2_list)
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        mask = np.zeros(max(int(off[-1]), 1), np.uint8); nin = np.zeros(max(nprob, 1), np.int32)
+        self._L.dvs_find_fundamental_ransac_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.dvs_find_fundamental_ransac_batch(self._h, nprob, ptr(off), ptr(p1), ptr(p2), threshold, confidence, max_iters, ptr(sd), None,
+                                                        ptr(mask), ptr(nin)))
+        return [(mask[off[b]:off[b + 1]].copy(), int(nin[b])) for b in range(nprob)]
+
+    def solve_pnp_ransac_batch(self, pts3d_list, pts2d_list, K4, seeds, iterations=100, reproj_err=4.0, confidence=0.99):
+        """-> list of (success, rvec, tvec, inlier indices)"""
+        nprob = len(pts3d_list)
+        off = np.zeros(nprob + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in pts3d_list])
+        o = (np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 3) for p in pts3d_list]), np.float32) if off[-1]
+             else np.zeros((1, 3), np.float32))
+        i2 = (np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in pts2d_list]), np.float32) if off[-1]
+              else np.zeros((1, 2), np.float32))
+        K = np.ascontiguousarray(K4, np.float64); sd = np.ascontiguousarray(seeds, np.uint64)
+        rv = np.zeros((max(nprob, 1), 3)); tv = np.zeros((max(nprob, 1), 3)); inl = np.zeros(max(int(off[-1]), 1), np.int32)
+        nin = np.zeros(max(nprob, 1), np.int32); ok = np.zeros(max(nprob, 1), np.int32)
+        self._L.dvs_solve_pnp_ransac_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.dvs_solve_pnp_ransac_batch(self._h, nprob, ptr(off), ptr(o), ptr(i2), ptr(K), iterations, reproj_err, confidence, ptr(sd), ptr(rv), ptr(tv),
+                                                 ptr(inl), ptr(nin), ptr(ok)))
+        return [(bool(ok[b]), rv[b].copy(), tv[b].copy(), inl[off[b]:off[b] + nin[b]].copy()) for b in range(nprob)]
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.dvs_matcher_destroy(self._h)

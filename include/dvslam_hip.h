@@ -318,6 +318,12 @@ dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_
 dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
                                        int32_t max_iters /* OpenCV default 1000 */, uint64_t seed, double* F9, uint8_t* inlier_mask,
                                        int32_t* n_inliers);
+/* nprob independent problems in ONE launch sequence (the replay's per-frame gates are pose-independent: tools/replay_tracking.py
+ * runs them for all frames at once): problem b = correspondences [offsets[b], offsets[b + 1]) of the concatenated arrays, sampler
+ * seed seeds[b]; outputs concatenated / indexed the same way.  Every problem gets exactly what the single call gives it. */
+dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets /* nprob + 1, offsets[0] = 0 */, const float* pts1,
+                                             const float* pts2, double threshold, double confidence, int32_t max_iters, const uint64_t* seeds,
+                                             double* F9 /* nprob x 9 or NULL */, uint8_t* inlier_mask /* offsets[nprob] */, int32_t* n_inliers /* nprob or NULL */);
 /* cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations = 100, reproj_err = 4.0, confidence = 0.99, inliers)
  * (frontend.cpp:911-921; zero distortion): obj n x 3 float (camera frame of the previous image), img n x 2 float,
  * K4 = {fx, fy, cx, cy}.  P3P hypotheses, best by inlier count, Levenberg-Marquardt refinement on the inliers (the
@@ -326,6 +332,10 @@ dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, cons
 dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
                                 double reproj_err, double confidence, uint64_t seed, double* rvec3, double* tvec3, int32_t* inliers,
                                 int32_t* n_inliers, int32_t* success);
+/* batch form: inliers concatenated like the points (problem b's ascending indices at inliers + offsets[b]); rvec3 / tvec3 nprob x 3 */
+dvs_status dvs_solve_pnp_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts3d, const float* pts2d, const double* K4,
+                                      int32_t iterations, double reproj_err, double confidence, const uint64_t* seeds, double* rvec3, double* tvec3,
+                                      int32_t* inliers /* offsets[nprob] or NULL */, int32_t* n_inliers /* nprob or NULL */, int32_t* success /* nprob */);
 
 /* Harris corner measure as cv::ORB scores keypoints (ORB::HARRIS_SCORE, the mode test_dbow2_integration.cpp:19 runs with:
  * OpenCV features2d orb.cpp HarrisResponses — integer 3x3 gradients over a block_size^2 window, response = (ab - c^2 - k(a+b)^2)

@@ -185,3 +185,27 @@ def test_gpu_ransac_degenerate_inputs(gpu):
     rng = np.random.Generator(np.random.PCG64(1))                                          # pure noise: no consistent pose
     ok, rvec, tvec, inl = g.solve_pnp_ransac(rng.uniform(-1, 1, (50, 3)) + [0, 0, 2], rng.uniform(0, 640, (50, 2)), [600, 600, 320, 240])
     assert inl.size < 15
+
+
+@pytest.mark.gpu
+def test_gpu_ransac_batches_equal_the_single_calls(gpu):
+    """dvs_find_fundamental_ransac_batch / dvs_solve_pnp_ransac_batch: many independent problems (ragged sizes, one too small, one
+    empty) in one launch sequence; every problem gets bit for bit what its single call gives (mask, inlier count; pose, inlier list)"""
+    from dvslam_amd import FrontendGlue
+    g = FrontendGlue()
+    sizes = [600, 9, 0, 250, 5, 1200, 64, 8]
+    scenes = [rs.two_view(n=max(n, 1), outlier_frac=0.3, noise=0.5, seed=10 + i, planar=(i % 2 == 1)) for i, n in enumerate(sizes)]
+    p1 = [sc["pts1"][:n] for sc, n in zip(scenes, sizes)]; p2 = [sc["pts2"][:n] for sc, n in zip(scenes, sizes)]
+    X = [sc["X"][:n] for sc, n in zip(scenes, sizes)]
+    seeds = [101 + 7 * i for i in range(len(sizes))]
+    fb = g.find_fundamental_ransac_batch(p1, p2, seeds, 2.0, 0.99, 1000)
+    pb = g.solve_pnp_ransac_batch(X, p2, scenes[0]["K4"], seeds, 100, 4.0, 0.99)
+    for i, n in enumerate(sizes):
+        F, mask, nin = g.find_fundamental_ransac(p1[i], p2[i], 2.0, 0.99, 1000, seed=seeds[i])
+        assert (fb[i][0] == mask).all() and fb[i][1] == nin, i
+        ok, rvec, tvec, inl = g.solve_pnp_ransac(X[i], p2[i], scenes[0]["K4"], 100, 4.0, 0.99, seed=seeds[i])
+        assert pb[i][0] == ok and (pb[i][3] == inl).all(), i
+        assert (pb[i][1].view(np.uint64) == rvec.view(np.uint64)).all() and (pb[i][2].view(np.uint64) == tvec.view(np.uint64)).all(), i
+    big = g.find_fundamental_ransac_batch([p1[0]] * 200, [p2[0]] * 200, list(range(200)), 2.0, 0.99, 1000)   # results leave by a copy command
+    F, mask, nin = g.find_fundamental_ransac(p1[0], p2[0], 2.0, 0.99, 1000, seed=137)
+    assert (big[137][0] == mask).all() and big[137][1] == nin
