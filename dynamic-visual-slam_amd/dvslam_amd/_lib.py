@@ -156,15 +156,17 @@ def device_count():
     return lib().dvs_device_count()
 
 
+PROFILED_SOURCES = ("orb.hip", "orb_kernels.h", "orb_geom.h", "orb_device_common.h", "lsort.h", "glibc_sincosf.h", "brief_pattern.inc", "match.hip",
+                    "common.h")
+
+
 def kernel_source_digest():
-    """sha256 (first 16 hex digits) over the kernel sources csrc/*.hip, *.h, *.inc — stamps profile data (profiles/pmc_traffic.json)
-    with the code it was collected on"""
-    import glob
+    """sha256 (first 16 hex digits) over the sources of the kernels bench.py times and tools/collect_profiles.sh counts (extractor and
+    matcher) — stamps profile data (profiles/pmc_traffic.json) with the code it was collected on"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(_PKG, "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".inc")):
-            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    for name in PROFILED_SOURCES:
+        h.update(name.encode()); h.update(open(os.path.join(_PKG, "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
