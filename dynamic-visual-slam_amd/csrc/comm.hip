@@ -8,6 +8,7 @@
 // carries an RCCL (PyTorch bundles one under the same SONAME librccl.so.1) shares that copy instead of loading a second.
 #include <dlfcn.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -89,7 +90,7 @@ struct LoopGroup {
   const void* send[DVS_COMM_MAX_LOOPBACK] = {};
   hipEvent_t ev_sent[DVS_COMM_MAX_LOOPBACK] = {};     // rank's send block is complete (its stream)
   hipEvent_t ev_pulled[DVS_COMM_MAX_LOOPBACK] = {};   // rank has pulled every peer's block of its latest call (its stream)
-  bool pulled_once = false;
+  std::atomic<bool> pulled_once{false};   // set by every rank behind the second rendezvous of the first gather
   // every rank arrives; false when the group is broken (a peer timed out or failed)
   bool barrier() {
     std::unique_lock<std::mutex> lk(mu);

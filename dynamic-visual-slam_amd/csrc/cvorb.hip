@@ -129,15 +129,12 @@ template <int EMIT>
 __global__ __launch_bounds__(256) void k_cv_nms(CvGeom G, const u8* __restrict__ score, int* __restrict__ rowCount, const int* __restrict__ rowBase,
                                                 unsigned long long* __restrict__ keys) {
   __shared__ int wsum[4];
-  __shared__ int base;
   const CvLevel& L = G.lv[blockIdx.y];
   const int e = G.edge, y = blockIdx.x;
   const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
   const bool live = y >= e && y < L.h - e && L.w > 2 * e && L.h > 2 * e && y < L.h;
   if (y >= L.h) return;
   int total = 0;
-  if (tid == 0) base = 0;
-  __syncthreads();
   if (live) {
     const u8* row = score + L.off + (uint64_t)y * L.pitch;
     const int P = L.pitch;
