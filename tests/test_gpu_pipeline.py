@@ -75,6 +75,35 @@ def test_timed_configuration_against_oracle(gpu, oracle):
     pipe.close()
 
 
+@pytest.mark.parametrize("B,rows,cols,nf,nsets,steps", [(5, 480, 640, 800, 3, 8), (33, 360, 1000, 700, 2, 5), (1, 720, 1280, 2000, 4, 9), (9, 250, 332, 200, 5, 6)])
+def test_other_shapes_of_the_pipelined_step(gpu, oracle, B, rows, cols, nf, nsets, steps):
+    """the same step at other batch sizes (1 and 33: the small-batch kernel variants and the 256-thread quad-tree on either side of
+    their thresholds), resolutions (widths that are not multiples of 4 take the generic kernels) and output-set counts: the resident
+    batches and their match jobs against the oracle"""
+    from dvslam_amd import _lib
+    from dvslam_amd.pipeline import StreamingPipeline
+    NB = 3
+    frames = [np.stack([synth.make_frame(7 * g + i, cols, rows, seed=77 + g) for i in range(B)]) for g in range(NB)]
+    o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
+    ref = [[o.extract(f) for f in batch] for batch in frames]
+    d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True)
+    for i in range(steps):
+        pipe.step(d_img[i % NB].ptr, d_img[(i + 1) % NB].ptr)
+    pipe.flush(); pipe.synchronize()
+    for i in range(steps - nsets, steps):
+        n, k, d = pipe.outputs(i)
+        idx, dist = pipe.matches(i)
+        for f in range(B):
+            _assert_frame((n[f], k[f], d[f]), ref[i % NB][f], f"step {i} frame {f}")
+            if i == 0 and f == 0:
+                continue
+            t = ref[i % NB][f - 1] if f else ref[(i - 1) % NB][B - 1]
+            i2, d2 = oracle.match(ref[i % NB][f][2], t[2])
+            assert (idx[f, :n[f]] == i2).all() and (dist[f, :n[f]] == d2).all(), (i, f)
+    pipe.close()
+
+
 def test_serial_schedule_against_oracle(gpu, oracle):
     """bench.py --serial-match: the same step without the software pipeline (one stream, match behind its own extraction)"""
     from dvslam_amd import _lib
