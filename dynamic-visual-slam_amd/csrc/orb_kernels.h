@@ -1820,16 +1820,21 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
     wave_lds_fence();
     const float a = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, cosK), kCsLane * i));
     const float b = __builtin_bit_cast(float, DVS_RL(__builtin_bit_cast(int, sinK), kCsLane * i));
-    const u8* bc = wl + kWinR * kWinPitch + wxi;
+    // cvRound of the steered coordinates without a conversion: fl(t + (2^23 + 32)) IS 2^23 + 32 + rint(t) (one ulp = 1 there, ties to
+    // even, and 2^23 + 32 is even), so the low 24 bits of its encoding are 32 + cvRound(t) > 0 and v_mad_i32_i24 — which reads exactly
+    // those bits of its two factors and ALL 32 bits of its addend — forms (32 + row) * pitch + (0x4B000020 + col) from the two sums
+    // directly; the constant comes off the base.  (v_rndne + v_cvt per coordinate before: 16 instructions per keypoint and lane.)
+    const int bco = kWinR * kWinPitch + wxi - 32 * kWinPitch - 0x4B000020;
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
-      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
-      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
-      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
-      const int t0 = bc[mad_i24(r0, kWinPitch, c0)];  // 24-bit multiply-add: the plain product compiles to a quarter-rate v_mul_lo_u32
-      const int t1 = bc[mad_i24(r1, kWinPitch, c1)];
+      constexpr float kRound = 8388640.0f;   // 2^23 + 32
+      const int r0 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)), kRound));
+      const int c0 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)), kRound));
+      const int r1 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)), kRound));
+      const int c1 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)), kRound));
+      const int t0 = wl[mad_i24(r0, kWinPitch, c0) + bco];
+      const int t1 = wl[mad_i24(r1, kWinPitch, c1) + bco];
       words[r] = __ballot(t0 < t1);
     }
     if ((vmask >> i) & 1u) {
