@@ -548,11 +548,16 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
     const int spitch = l == 1 ? (int)src.step0 : S.pitch;
     dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
     const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
-    if (aligned && D.gtab >= 0)
-      hipLaunchKernelGGL(k_resize4, dim3(grid.x, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), nimg), block, 0, pst,
+    if (aligned && D.gtab >= 0) {
+      const uint32_t tx = grid.x, ty = (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), tiles = tx * ty;
+      // n / d == umulhi(n, 2^32 / d + 1) for every n with n * d < 2^32
+      auto magic = [](uint64_t nmax, uint32_t d) -> uint32_t { return d > 1 && nmax * d < (1ull << 32) ? (uint32_t)((1ull << 32) / d + 1) : 0u; };
+      hipLaunchKernelGGL(k_resize4, dim3(tiles, nimg), block, 0, pst,
                          sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab,
-                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off ? nimg - 1 : -1);   // caller's buffer: no slack behind its last row
+                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off ? nimg - 1 : -1,   // caller's buffer: no slack behind its last row
+                         (int)tx, magic((uint64_t)tiles * nimg, tiles), magic(tiles, tx));
+    }
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, D.w, D.h,
                          D.pitch, h->d_xofs + D.xtab, h->d_alpha + D.xtab, h->d_yofs + D.ytab, h->d_beta + D.ytab);

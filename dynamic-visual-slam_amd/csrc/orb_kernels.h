@@ -206,14 +206,22 @@ constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x 
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
-                                                 const int* __restrict__ beta, int guardFrame) {
+                                                 const int* __restrict__ beta, int guardFrame, int tilesX, uint32_t magicTiles, uint32_t magicX) {
   // (raising these waves' issue priority over the FAST waves they run beside, s_setprio, was measured: 3 % slower overall)
-  const int gx = blockIdx.x * 64 + threadIdx.x;
+  // grid = (tiles of a frame, frames), workgroups dealt to the XCDs frame by frame (xcd_contiguous_id): the source rows and the
+  // 128-byte lines neighbouring tiles share then meet in ONE L2 (round 2's (x, y, frame) grid spread a frame's tiles over all eight:
+  // 1.32x the algorithmic bytes fetched).  The two divisions are by host-made reciprocals on the scalar unit (exact: the host checks
+  // the ranges and passes magic = 0 otherwise).
+  const uint32_t wg = (uint32_t)xcd_contiguous_id(), tiles = gridDim.x;
+  const uint32_t f = magicTiles ? __umulhi(wg, magicTiles) : wg / tiles;
+  const uint32_t tile = wg - f * tiles;
+  const uint32_t by = magicX ? __umulhi(tile, magicX) : tile / (uint32_t)tilesX;
+  const uint32_t bx = tile - by * (uint32_t)tilesX;
+  const int gx = (int)bx * 64 + threadIdx.x;
   const int x4 = gx * 4;
   // a wavefront is one threadIdx.y row of the (64, 4) block: everything that depends on y only is wave-uniform, and saying so
   // (v_readfirstlane) moves the row table lookups and the 64-bit row address arithmetic to the scalar unit
-  const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kResizeRows;
-  const int f = blockIdx.z;
+  const int y0 = ((int)by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kResizeRows;
   if (x4 >= dw || y0 >= dh) return;
   const ResizeGroup t = xt[gx];
   // uniform frame bases + 32-bit per-lane offsets (a level is far smaller than 4 GB): no 64-bit vector multiply-adds
