@@ -68,6 +68,12 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// ... with a wave-uniform second factor taken straight from its SGPR (the "v" form costs a v_mov per use site)
+__device__ __forceinline__ uint32_t mad_u24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+  return d;
+}
 __device__ __forceinline__ int mad_i24(int a, int b, int c) {
   int d;
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -1478,6 +1484,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   typedef unsigned short us2v __attribute__((ext_vector_type(2)));
   const us2v k01 = {(unsigned short)kv[0], (unsigned short)kv[1]}, k23 = {(unsigned short)kv[2], (unsigned short)kv[3]},
              k45 = {(unsigned short)kv[4], (unsigned short)kv[5]};
+  const uint32_t kv6s = __builtin_amdgcn_readfirstlane(kv[6]);   // the column filter's last weight, pinned to an SGPR (mad_u24_s)
   uint32_t ring[7][4], hprev[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int a = 0; a < 7; a++)
@@ -1499,8 +1506,9 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
         const uint32_t own = cur[kk];
         // neighbour words by DPP whole-wave shifts (wave_shr:1 / wave_shl:1: one VALU move each, no LDS crossbar trip;
         // semantics checked on gfx950: lane i receives lane i-1 / i+1, the open end keeps `old` = 0)
-        uint32_t left = __builtin_amdgcn_update_dpp(0u, own, 0x138, 0xf, 0xf, false);
-        uint32_t right = __builtin_amdgcn_update_dpp(0u, own, 0x130, 0xf, 0xf, false);
+        // bound_ctrl: the lane at the open end reads 0 without a destination initialised first (one v_mov per shift less)
+        uint32_t left = __builtin_amdgcn_update_dpp(0u, own, 0x138, 0xf, 0xf, true);
+        uint32_t right = __builtin_amdgcn_update_dpp(0u, own, 0x130, 0xf, 0xf, true);
         // px -3,-2,-1 = px 3,2,1 ; px W,W+1,W+2 = px W-2,W-3,W-4
         // px x+j takes bytes x+j-3 .. x+j+3 of the 12-byte window (left | own | right): instead of shifting the DATA to a common
         // alignment (six v_alignbyte per row) the WEIGHTS are kept in the ten alignments the four pixels need (scalar constants):
@@ -1518,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
           uint32_t acc[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            acc[j] = mad_u24(hc[j], kv[6], 32768u);
+            acc[j] = mad_u24_s(hc[j], kv6s, 32768u);
             acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 2) % 7][j]), k01, acc[j], false);  // rows k-6, k-5
             acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 4) % 7][j]), k23, acc[j], false);  // rows k-4, k-3
             acc[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, ring[(kk + 6) % 7][j]), k45, acc[j], false);  // rows k-2, k-1
