@@ -255,12 +255,14 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
       w0[r][0] = a.x; w0[r][1] = a.y; w0[r][2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
       w1[r][0] = c.x; w1[r][1] = c.y; w1[r][2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
     } else {  // row tail: bytewise, never past the last valid pixel
+      int lastpx = sw - 1 - t.base;
+      asm volatile("" : "+v"(lastpx));   // defined HERE: the compiler otherwise hoists the twelve clamps below into the path every wavefront takes
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         uint32_t u = 0, v = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int o = min(4 * k + i, sw - 1 - t.base);
+          const int o = min(4 * k + i, lastpx);
           u |= (uint32_t)p0[o] << (8 * i);
           v |= (uint32_t)p1[o] << (8 * i);
         }
