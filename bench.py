@@ -395,13 +395,14 @@ def main():
     # whole-job timing below):
     # (b) every kernel alone on the stream: the kernel's own duration, which the rooflines below are computed from
     K = args.steps
+    overlap_default = os.environ.get("DVS_NO_OVERLAP") != "1"   # tools/collect_profiles.sh serialises the WHOLE run for its per-kernel passes
     orb.set_overlap(False)
     orb.enable_stage_timing(True)
     for k in range(K):
         pipe.step(img[k % NB], 0, match=False)
     pipe.synchronize()
     stage_ms, stage_calls = orb.stage_times()
-    orb.set_overlap(True)
+    orb.set_overlap(overlap_default)
     # (a) the pipelined schedule: what a kernel takes WHILE its neighbours share the machine (= rocprofv3's statistics of this command);
     #     last, so that the timed region follows work of its own intensity
     pipe.i = 0
@@ -410,7 +411,6 @@ def main():
     pipe.synchronize()
     ov_ms, ov_calls = orb.stage_times()
     orb.enable_stage_timing(False)
-    orb.set_overlap(True)
     pipe.i = 0
 
     for _ in range(args.warmup):
