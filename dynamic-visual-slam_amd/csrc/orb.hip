@@ -256,9 +256,14 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
         if (iniX >= maxBX - 6) continue;
         if (maxX > maxBX) maxX = (float)maxBX;
         Cell c;
-        c.level = (int16_t)l; c.i = (int16_t)i; c.j = (int16_t)j; c.pad = 0;
+        c.level = (int16_t)l; c.i = (int16_t)i; c.j = (int16_t)j;
         c.x0 = (int16_t)(int)iniX; c.y0 = (int16_t)(int)iniY;
         c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
+        {  // k_fast_wave's lane mapping of the rejection loop (same arithmetic as the kernel's: tile origin, interior column groups)
+          const int ox = h->fast_byte_dma ? 1 : (c.x0 & 3), cx0 = ox + 3, cx1 = ox + c.cw - 3;
+          const int ng = std::max(((cx1 - 1) >> 2) - (cx0 >> 2) + 1, 1);
+          c.rpt = (int16_t)(64 / ng); c.inv_ng = 1.0f / (float)ng;
+        }
         c.slot = slot++;
         cells.push_back(c);
       }

@@ -60,9 +60,11 @@ struct Geom {
 };
 
 struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
-  int16_t level, i, j, pad;
+  int16_t level, i, j;
+  int16_t rpt;             // k_fast_wave: rows per trip of the rejection loop = 64 / ng (ng = 4-pixel column groups of the interior)
   int16_t x0, y0, cw, ch;  // sub-image origin and size in level pixels (rowRange/colRange)
   int32_t slot;            // index among the level's cells (candidate order)
+  float inv_ng;            // 1.0f / ng — host-made: the two divisions were ~12 vector instructions per cell on the device
 };
 
 struct BlurTile { int16_t level, tx, ty, pad; };

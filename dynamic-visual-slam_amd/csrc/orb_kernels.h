@@ -727,8 +727,8 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   //    index arithmetic (round 2a derived row and column from a flat index each trip: ~11 of its 122 instructions)
   const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
   const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
-  const int rpt = 64 / ng;                    // rows per trip (ng <= 19 for cells up to 76 pixels)
-  const int rsub = (int)(((float)lane + 0.5f) * (1.0f / (float)ng)), gi = lane - rsub * ng;
+  const int rpt = cell.rpt;                   // rows per trip = 64 / ng (ng <= 19 for cells up to 76 pixels), host-made with 1 / ng
+  const int rsub = (int)(((float)lane + 0.5f) * cell.inv_ng), gi = lane - rsub * ng;
   // column mask of this lane's group: bit j = pixel j of the group is an interior column (first / last group only partly)
   uint32_t cmLane = rsub < rpt ? 0xFu : 0u;
   if (gi == 0) cmLane &= (0xFu << (cx0 & 3)) & 0xFu;
