@@ -262,7 +262,9 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
         {  // k_fast_wave's lane mapping of the rejection loop (same arithmetic as the kernel's: tile origin, interior column groups)
           const int ox = h->fast_byte_dma ? 1 : (c.x0 & 3), cx0 = ox + 3, cx1 = ox + c.cw - 3;
           const int ng = std::max(((cx1 - 1) >> 2) - (cx0 >> 2) + 1, 1);
-          c.rpt = (int16_t)(64 / ng); c.inv_ng = 1.0f / (float)ng;
+          const int rpt = 64 / ng, ih = c.ch - 6;
+          const int tail = ih > 0 ? ih - (ih - 1) / rpt * rpt : 0;   // rows of the loop's last trip
+          c.rpt = (int16_t)(rpt | (tail << 8)); c.inv_ng = 1.0f / (float)ng;
         }
         c.slot = slot++;
         cells.push_back(c);

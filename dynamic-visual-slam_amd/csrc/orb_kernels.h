@@ -727,16 +727,25 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   //    index arithmetic (round 2a derived row and column from a flat index each trip: ~11 of its 122 instructions)
   const int cx0 = ox + 3, cx1 = ox + cw - 3;  // interior columns in tile coordinates
   const int g0 = cx0 >> 2, ng = ((cx1 - 1) >> 2) - g0 + 1;
-  const int rpt = cell.rpt;                   // rows per trip = 64 / ng (ng <= 19 for cells up to 76 pixels), host-made with 1 / ng
+  const int rpt = cell.rpt & 0xFF;            // rows per trip = 64 / ng (ng <= 19 for cells up to 76 pixels), host-made with 1 / ng
+  const int tailRows = cell.rpt >> 8;         // ... and the rows of the last trip
   const int rsub = (int)(((float)lane + 0.5f) * cell.inv_ng), gi = lane - rsub * ng;
   // column mask of this lane's group: bit j = pixel j of the group is an interior column (first / last group only partly)
-  uint32_t cmLane = rsub < rpt ? 0xFu : 0u;
-  if (gi == 0) cmLane &= (0xFu << (cx0 & 3)) & 0xFu;
-  if (gi == ng - 1) cmLane &= 0xFu >> (3 - ((cx1 - 1) & 3));
+  // — as the sign bit of one byte per pixel, the form the loop's test results arrive in
+  uint32_t cmLane = rsub < rpt ? 0x80808080u : 0u;
+  if (gi == 0) cmLane &= 0x80808080u << (8 * (cx0 & 3));
+  if (gi == ng - 1) cmLane &= 0x80808080u >> (8 * (3 - ((cx1 - 1) & 3)));
+  const uint32_t cmTail = rsub < tailRows ? cmLane : 0u;   // the last trip's mask: only the rows that exist
   int nwork = 0;
   const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile) + mad_i24(rsub + 3, P / 4, g0 + gi);   // centre word of the lane's first row
-  int cbase = mad_i24(rsub, P, (g0 + gi) * 4 - 3);   // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left
-  for (int row0 = 0; row0 < ih; row0 += rpt, rp += rpt * (P / 4), cbase += rpt * P) {
+  // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left; the lane's four candidates entries ride in the
+  // halves of two registers (ds_write_b16 / ds_write_b16_d16_hi store either half), advanced by one packed add each per trip
+  const int cbase0 = mad_i24(rsub, P, (g0 + gi) * 4 - 3);
+  u16x2 c01 = {(uint16_t)cbase0, (uint16_t)(cbase0 + 1)}, c23 = {(uint16_t)(cbase0 + 2), (uint16_t)(cbase0 + 3)};
+  const uint16_t cstep = (uint16_t)(rpt * P);
+  const u16x2 cstep2 = {cstep, cstep};
+  const uint32_t workLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)work;
+  for (int row0 = 0; row0 < ih; row0 += rpt, rp += rpt * (P / 4), c01 += cstep2, c23 += cstep2) {
     const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
     const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
     const uint32_t L0 = rp[-1], O0 = rp[0], R0 = rp[1];
@@ -772,16 +781,41 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
       sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
     }
-    // sign bits 15 / 31 of the two halves -> one 4-bit mask (bit j = pixel j passes), gated by the lane's column mask and the
-    // cell's last row
-    uint32_t m4 = ((sgn[0] >> 15) & 0x00010001u) | ((sgn[1] >> 13) & 0x00040004u);  // bits 0, 16 | 2, 18
-    m4 = (m4 | (m4 >> 15)) & (row0 + rsub < ih ? cmLane : 0u);
+    // the four sign bytes (bytes 1 and 3 of either half) side by side: bit 8 j + 7 = pixel j passes; gated by the lane's column
+    // mask (the cell's last trip: cut down to the rows that exist)
+    const uint32_t m4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (row0 + rpt >= ih ? cmTail : cmLane);
     const int cnt = __popc(m4);
     const int incl = wave_incl_scan_dpp(cnt);
-    int pos = nwork + incl - cnt;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (m4 & (1u << j)) work[pos++] = (uint16_t)(cbase + j);
+    // the four conditional stores, by hand: per pixel ONE compare (SDWA picks the pixel's byte) and ONE add — the running address,
+    // which starts one slot before the lane's first and is advanced under the store's own execution mask.  (The compiler's form of
+    // the same: mask + compare + address add + copy + entry add per pixel.)  LDS operations of a wave complete in order, so the
+    // loads the compiler schedules around this block are unaffected.
+    uint32_t wa = workLds + 2u * (uint32_t)(nwork + incl - cnt) - 2u;
+    unsigned long long sv;
+    asm volatile(
+        "v_cmp_ne_u32_sdwa vcc, %[m], %[z] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "v_add_u32_e32 %[a], 2, %[a]\n\t"
+        "ds_write_b16 %[a], %[c01]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmp_ne_u32_sdwa vcc, %[m], %[z] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "v_add_u32_e32 %[a], 2, %[a]\n\t"
+        "ds_write_b16_d16_hi %[a], %[c01]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmp_ne_u32_sdwa vcc, %[m], %[z] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "v_add_u32_e32 %[a], 2, %[a]\n\t"
+        "ds_write_b16 %[a], %[c23]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmp_ne_u32_sdwa vcc, %[m], %[z] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "v_add_u32_e32 %[a], 2, %[a]\n\t"
+        "ds_write_b16_d16_hi %[a], %[c23]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a] "+v"(wa), [sv] "=&s"(sv)
+        : [m] "v"(m4), [z] "s"(0), [c01] "v"(c01), [c23] "v"(c23)
+        : "vcc", "memory");
     nwork += __builtin_amdgcn_readlane(incl, 63);
   }
   wave_lds_fence();
