@@ -379,11 +379,13 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
   {  // wave-per-cell FAST: LDS tile geometry (pitch keeps the <= 3 byte phase of the aligned staging)
     int maxw = 0, maxh = 0;
     for (const Cell& c : cells) { maxw = std::max<int>(maxw, c.cw); maxh = std::max<int>(maxh, c.ch); }
-    G.fastP = maxw + 3 <= 48 ? 48 : (maxw + 3 <= 64 ? 64 : 80);
+    const int need = std::max(maxw + 3, maxh - 4);   // tile pitch: the widest cell at any byte phase; tile rows: <= pitch + 4 (fast_tile_bytes)
+    G.fastP = need <= 48 ? 48 : (need <= 64 ? 64 : 80);
     G.fastRows = maxh;
     const int listBytes = (int)align_up(2 * (size_t)std::max(1, (maxw - 6) * (maxh - 6)), 16);   // worst case: every interior pixel survives
     G.fastByteDma = h->fast_byte_dma;
-    G.fastTile = (int)align_up((size_t)G.fastRows * G.fastP, 256);  // k_fast_wave stages whole 256-byte LDS-DMA pieces
+    G.fastTile = fast_tile_bytes(G.fastP);
+    // tile (fast_tile_bytes) + score tile (rows of the tallest cell) + work list
     G.fastWaveLds = (int)align_up((size_t)G.fastTile + (size_t)G.fastRows * G.fastP + listBytes, 16);
   }
   return DVS_OK;

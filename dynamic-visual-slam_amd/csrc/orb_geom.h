@@ -43,9 +43,9 @@ struct Geom {
   int32_t pyrTiles;     // workgroups of the pyramid cascade
   int32_t pyrLds;       // bytes of ONE of its two LDS buffers
   int32_t fastP;        // LDS tile pitch of the wave-per-cell FAST kernel (48 / 64 / 80)
-  int32_t fastRows;     // max cell height (rows of the LDS tile)
-  int32_t fastWaveLds;  // LDS bytes per wave: tile + score tile + work list
-  int32_t fastTile;     // bytes of the staged tile, a multiple of 256 (whole LDS-DMA wave-instructions)
+  int32_t fastRows;     // max cell height (rows of the LDS tile; <= fastP + 4)
+  int32_t fastWaveLds;  // LDS bytes per wave: tile (fast_tile_bytes(fastP)) + score tile (fastRows * fastP) + work list
+  int32_t fastTile;     // = fast_tile_bytes(fastP)
   int32_t fastByteDma;  // 1: the LDS-DMA takes byte-aligned global addresses here (checked at start-up): tiles start 1 column left of the cell
   int32_t iniTh, minTh;
   int32_t maxN;         // max quota over levels
@@ -58,6 +58,10 @@ struct Geom {
   uint64_t candPerFrame, ptsPerFrame;  // uint32 elements per frame
   LevelGeom lv[DVS_MAX_LEVELS];
 };
+
+// bytes of k_fast_wave<P>'s tile: up to P + 4 rows of P bytes (1280x720: cells of up to 44 x 49 at pitch 48), a multiple of 256
+// (whole LDS-DMA wave-instructions)
+constexpr int fast_tile_bytes(int P) { return ((P + 4) * P + 255) & ~255; }
 
 struct Cell {       // one FAST cell (ORBextractor.cpp:805-827)
   int16_t level, i, j;

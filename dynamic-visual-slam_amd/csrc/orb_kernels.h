@@ -661,7 +661,7 @@ __device__ __forceinline__ i16x2 fast_corner_score2(const u8* ta, const u8* tb) 
 
 // inclusive prefix sum over the wavefront by DPP row shifts / broadcasts (six v_add_u32_dpp)
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1 (zero fill: one v_add_u32_dpp, no separate move)
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
@@ -685,8 +685,9 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
   unsigned char* base = fsm + wvi * g->fastWaveLds;
   u8* tile = base;
-  u8* score = base + g->fastTile;
-  uint16_t* work = reinterpret_cast<uint16_t*>(base + g->fastTile + g->fastRows * P);
+  constexpr int T = fast_tile_bytes(P);   // tile and score tile: a compile-time distance apart, so a pixel's score is an immediate offset
+  u8* score = base + T;                   // from its tile address
+  uint16_t* work = reinterpret_cast<uint16_t*>(base + T + g->fastRows * P);   // the score tile is only as tall as the tallest cell
   const Cell cell = cells[ci];
   const LevelGeom& L = g->lv[cell.level];
   int pitch;
@@ -721,7 +722,6 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   }
   wave_lds_fence();
   const int tmin = g->minTh, tini = g->iniTh;
-  const unsigned long long ltmask = (1ull << lane) - 1ull;
   // 2. rejection test, 4 pixels per lane.  Lane = (row of the trip, dword column): the column group, its border mask and the
   //    lane's offsets are fixed for the whole cell, a trip advances every lane by the same number of rows, so the loop carries no
   //    index arithmetic (round 2a derived row and column from a flat index each trip: ~11 of its 122 instructions)
@@ -777,9 +777,8 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
       const f16x2 mnf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_elementwise_maximum(mn2(r0, r8), mn2(r4, r12)), mn2(r2, r10)), mn2(r6, r14));
       const f16x2 mxf = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_elementwise_minimum(mx2(r0, r8), mx2(r4, r12)), mx2(r2, r10)), mx2(r6, r14));
       const s16x2 mn = __builtin_bit_cast(s16x2, mnf), mx = __builtin_bit_cast(s16x2, mxf);
-      const s16x2 e1 = (mn + T2) - v2;   // < 0  <=>  mn < v - t
-      const s16x2 e2 = (v2 + T2) - mx;   // < 0  <=>  mx > v + t
-      sgn[hh] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);
+      // mn < v - t or mx > v + t  <=>  max(v - mn, mx - v) > t: the sign of t - max(...)
+      sgn[hh] = __builtin_bit_cast(uint32_t, T2 - __builtin_elementwise_max(v2 - mn, mx - v2));
     }
     // the four sign bytes (bytes 1 and 3 of either half) side by side: bit 8 j + 7 = pixel j passes; gated by the lane's column
     // mask (the cell's last trip: cut down to the rows that exist)
@@ -790,7 +789,9 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     // which starts one slot before the lane's first and is advanced under the store's own execution mask.  (The compiler's form of
     // the same: mask + compare + address add + copy + entry add per pixel.)  LDS operations of a wave complete in order, so the
     // loads the compiler schedules around this block are unaffected.
-    uint32_t wa = workLds + 2u * (uint32_t)(nwork + incl - cnt) - 2u;
+    uint32_t waS = workLds - 2u + 2u * (uint32_t)nwork;   // scalar part (kept apart: two vector instructions for the address, not three)
+    asm volatile("" : "+s"(waS));
+    uint32_t wa = waS + 2u * (uint32_t)(incl - cnt);
     unsigned long long sv;
     asm volatile(
         "v_cmp_ne_u32_sdwa vcc, %[m], %[z] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
@@ -822,22 +823,39 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   // 3. exact score for the survivors, two per lane (2 lane, 2 lane + 1); corners (score >= minTh) are re-compacted in place, row-major
   int ncorner = 0;
   const uint32_t* work32 = reinterpret_cast<const uint32_t*>(work);
+  const uint32_t tileLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u8*)tile;
   for (int e0 = 0; e0 < nwork; e0 += 128) {
     const int ea = e0 + 2 * lane;
-    const bool va = ea < nwork, vb = ea + 1 < nwork;
-    const uint32_t cc = va ? work32[(e0 >> 1) + lane] : 0u;
-    const int ca = va ? (int)(cc & 0xFFFFu) : 0, cb = vb ? (int)(cc >> 16) : 0;   // idle halves read a harmless in-tile pixel
+    // idle halves read ONE harmless pixel (offset 0: a broadcast; stale entries would scatter over the banks)
+    const uint32_t cc = ea < nwork ? work32[(e0 >> 1) + lane] : 0u;
+    const uint32_t ca = cc & 0xFFFFu, cb = ea < nwork - 1 ? cc >> 16 : 0u;
     const i16x2 sc2 = fast_corner_score2<P>(tile + ca, tile + cb);
-    const int sa = sc2.x, sb = sc2.y;
-    const bool isa = va && sa >= tmin, isb = vb && sb >= tmin;
-    u8* scoreC = score + (3 * P + 3);
-    if (isa) scoreC[ca] = (u8)sa;
-    if (isb) scoreC[cb] = (u8)sb;
-    const unsigned long long ba = __ballot(isa), bb = __ballot(isb);
-    wave_lds_fence();
-    const int rank = ncorner + __popcll(ba & ltmask) + __popcll(bb & ltmask);
-    if (isa) work[rank] = (uint16_t)(ca + (3 * P + 3));   // from here on the list holds the pixels' own offsets
-    if (isb) work[rank + (isa ? 1 : 0)] = (uint16_t)(cb + (3 * P + 3));
+    // corners: list entry in range and score >= minTh.  The compare builtins ARE the ballots (a ballot of a combined predicate is
+    // re-made by two more vector instructions), combined on the scalar unit
+    const unsigned long long ba = __builtin_amdgcn_sicmp(ea, nwork, 40 /* < */) & __builtin_amdgcn_sicmp((int)sc2.x, tmin, 39 /* >= */);
+    const unsigned long long bb = __builtin_amdgcn_sicmp(ea, nwork - 1, 40) & __builtin_amdgcn_sicmp((int)sc2.y, tmin, 39);
+    // corners before this lane's: four v_mbcnt; the list keeps the survivors' form of the offset (3 rows and 3 columns up-left)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba,
+                          __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u))));
+    uint32_t la = 2u * rank + (workLds + 2u * (uint32_t)ncorner);
+    const uint32_t pa = tileLds + ca, pb = tileLds + cb;
+    unsigned long long sv;
+    // both stores of either pixel under ITS ballot as the execution mask: score byte (the pixel's own byte of the score tile: an
+    // immediate offset from its tile address; pixel b's score is the register's high half), list entry at the running address
+    asm volatile(
+        "s_and_saveexec_b64 %[sv], %[ba]\n\t"
+        "ds_write_b8 %[pa], %[sc] offset:%[K]\n\t"
+        "ds_write_b16 %[la], %[ca]\n\t"
+        "v_add_u32_e32 %[la], 2, %[la]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_and_saveexec_b64 %[sv], %[bb]\n\t"
+        "ds_write_b8_d16_hi %[pb], %[sc] offset:%[K]\n\t"
+        "ds_write_b16 %[la], %[cb]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [la] "+v"(la), [sv] "=&s"(sv)
+        : [ba] "s"(ba), [bb] "s"(bb), [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(__builtin_bit_cast(uint32_t, sc2)), [ca] "v"(ca), [cb] "v"(cb),
+          [K] "n"(T + 3 * P + 3)
+        : "memory");
     ncorner += __popcll(ba) + __popcll(bb);
   }
   wave_lds_fence();
@@ -848,9 +866,11 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     bool hi = false;
     if (e < ncorner) {
       const int c = work[e];
-      const int sc = score[c];
-      const bool ismax = sc > score[c - 1] && sc > score[c + 1] && sc > score[c - P - 1] && sc > score[c - P] && sc > score[c - P + 1] &&
-                         sc > score[c + P - 1] && sc > score[c + P] && sc > score[c + P + 1];
+      const u8* sp = score + c + (3 * P + 3);   // the corner's own byte
+      const int sc = sp[0];
+      // all eight neighbours read at once (a short-circuit chain is eight dependent LDS round trips), folded by four 3-operand maxima
+      const int n0 = sp[-1], n1 = sp[1], n2 = sp[-P - 1], n3 = sp[-P], n4 = sp[-P + 1], n5 = sp[P - 1], n6 = sp[P], n7 = sp[P + 1];
+      const bool ismax = sc > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
       hi = ismax && sc >= tini;
       work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0) | (hi ? 0x8000 : 0));
     }
@@ -868,10 +888,10 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     const bool sel = (w & selbit) != 0;
     const unsigned long long b = __ballot(sel);
     if (sel) {
-      const int c = w & 0x3fff;
-      const int yy = c / P, xx = c - yy * P - ox;  // sub-image coordinates
-      const int rank = nout + __popcll(b & ltmask);
-      if (rank < cap) out[rank] = pack_pt(xx + cell.j * L.wCell, yy + cell.i * L.hCell, score[c]);
+      const int c = w & 0x3fff;                    // offset of the pixel 3 rows and 3 columns up-left of the corner
+      const int y3 = c / P, xx = c - y3 * P + 3 - ox, yy = y3 + 3;  // sub-image coordinates (the column never carries: x - 3 + 3 < P)
+      const int rank = nout + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      if (rank < cap) out[rank] = pack_pt(xx + cell.j * L.wCell, yy + cell.i * L.hCell, score[c + (3 * P + 3)]);
     }
     nout += __popcll(b);
   }
