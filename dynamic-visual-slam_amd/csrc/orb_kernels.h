@@ -709,12 +709,18 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     const int wpr = (ox + cw + 3) >> 2;  // dwords per row the cell needs (<= W)
     const int lr = lane / W, lc = lane - lr * W;
     const uint32_t off = (uint32_t)mad_i24(lr, pitch, min(lc, wpr - 1) * 4);
-    const bool lane_on = lane < RP * W;
     const u8* rb = img + (uint64_t)cell.y0 * pitch + xa;
-    for (int r0 = 0; r0 < ch; r0 += RP) {
-      if (lane_on && r0 + lr < ch)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (uint64_t)r0 * pitch + off),
-                                         (__attribute__((address_space(3))) void*)(tile + r0 * P), 4, 0, 0);
+    const uint32_t tileLds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u8*)tile;
+    // the piece's global address as SCALAR base + the lane's 32-bit offset, its LDS base in M0: no vector instruction per piece (the
+    // builtin's form added the 64-bit base to a register pair and compared the row per piece)
+    auto piece = [&](int r0) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                   :: "s"(tileLds0 + (uint32_t)(r0 * P)), "v"(off), "s"(rb + (uint64_t)r0 * pitch) : "memory", "m0");
+    };
+    if (lane < RP * W) {
+      int r0 = 0;
+      for (; r0 + RP <= ch; r0 += RP) piece(r0);
+      if (r0 + lr < ch) piece(r0);   // the last rows
     }
     uint4* s128 = reinterpret_cast<uint4*>(score);
     for (int i = lane; i < (ch * P) >> 4; i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
