@@ -587,9 +587,11 @@ void launch_fast(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t fs, int c0
   }
   const dim3 grid((c1 - c0 + 3) / 4, nimg);
   const size_t lds = 4 * (size_t)G.fastWaveLds;
-  if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-  else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
-  else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1);
+  // n / grid.x == umulhi(n, 2^32 / grid.x + 1) for every workgroup id n of this grid (n * grid.x < 2^32), else 0: the kernel divides
+  const uint32_t magic = grid.x > 1 && (uint64_t)grid.x * grid.x * nimg < (1ull << 32) ? (uint32_t)((1ull << 32) / grid.x + 1) : 0u;
+  if (G.fastP == 48) hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1, magic);
+  else if (G.fastP == 64) hipLaunchKernelGGL(k_fast_wave<64>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1, magic);
+  else hipLaunchKernelGGL(k_fast_wave<80>, grid, dim3(256), lds, fs, h->d_geom, h->d_cells, src, h->d_cand, h->d_cellcount, c0, c1, magic);
 }
 
 // The announced next batch's level chain on pf_stream into d_pyr_alt, beside THIS batch's FAST: the chain is latency-bound, FAST is

@@ -672,16 +672,19 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 
 template <int P>
 __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, const Cell* __restrict__ cells, ImgSrc src,
-                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1) {
+                                                   uint32_t* __restrict__ cand, int* __restrict__ cellCount, int cell0, int cell1,
+                                                   uint32_t magicGX) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int lane = lane_id();
   const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as an SGPR: the cell, its level geometry and
   // frames -> XCDs contiguously (xcd_contiguous_id): the workgroups of one frame — whose cells share halo rows and 128-byte lines —
   // then meet in ONE L2 instead of eight (HBM fetch 2.1x -> see profiles of the algorithmic bytes; FAST is not fetch-bound, the
   // time is unchanged)
-  const int xid = xcd_contiguous_id();
-  const int f = xid / (int)gridDim.x;
-  const int ci = cell0 + (xid - f * (int)gridDim.x) * 4 + wvi;       // every size derived from them stay on the scalar unit
+  const uint32_t xid = (uint32_t)xcd_contiguous_id();
+  // frame = xid / gridDim.x by the host's reciprocal (exact for this grid; 0 = not representable): the division proper is ~25 scalar and
+  // 4 vector instructions at the head of every wavefront, before its first load can leave
+  const int f = (int)(magicGX ? __umulhi(xid, magicGX) : xid / gridDim.x);
+  const int ci = cell0 + (int)(xid - (uint32_t)f * gridDim.x) * 4 + wvi;       // every size derived from them stay on the scalar unit
   if (ci >= cell1) return;                                           // cells [cell0, cell1) of the level-major cell table
   unsigned char* base = fsm + wvi * g->fastWaveLds;
   u8* tile = base;
