@@ -949,24 +949,35 @@ struct QtShared {
   unsigned long long* sortbuf;
 };
 
-// counts children of every multi-point node of the current list
-__device__ __forceinline__ void qt_count_children(const QNode* nodes, int S, int* childCnt, const uint32_t* pts,
+// What a point needs of its node to find its quadrant: the split point, both coordinates in one word.  The point loops of a sweep
+// are bound by the workgroup's LDS traffic (level 0: ~4000 points x 4 passes per sweep), so they read this word — and, in
+// qt_rebuild, one 8-byte record — instead of the 16-byte node and its four child counters (44 -> 16 bytes per point).
+__device__ __forceinline__ uint32_t qt_mid(const QNode& nd) {
+  const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);   // as qt_quadrant / qt_child
+  return (uint32_t)mx | ((uint32_t)my << 16);
+}
+__device__ __forceinline__ int qt_quadrant_mid(uint32_t mid, int x, int y) {
+  return (x < (int)(mid & 0xFFFFu) ? 0 : 1) | (y < (int)(mid >> 16) ? 0 : 2);
+}
+
+// counts children of every multi-point node of the current list; `mids` = S words of scratch (posArr: dead between two rebuilds)
+__device__ __forceinline__ void qt_count_children(const QNode* nodes, int S, int* childCnt, uint32_t* mids, const uint32_t* pts,
                                                   const int* nodeOf, int n) {
   for (int k = threadIdx.x; k < 4 * S; k += OCT_T) childCnt[k] = 0;
+  for (int k = threadIdx.x; k < S; k += OCT_T) mids[k] = qt_mid(nodes[k]);
   __syncthreads();
   // four points per thread and trip: the dependent LDS chain (node-of-point -> node -> counter) of one point is ~400 cycles of latency
   // and a thread of the level-0 workgroup walks ~24 points; with the loads of four points issued together a trip costs one chain
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * OCT_T) {
     int k[4];
-    uint32_t p[4];
-    QNode nd[4];
+    uint32_t p[4], md[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; k[u] = i < n ? nodeOf[i] : -1; p[u] = i < n ? pts[i] : 0u; }
 #pragma unroll
-    for (int u = 0; u < 4; u++) nd[u] = nodes[max(k[u], 0)];
+    for (int u = 0; u < 4; u++) md[u] = mids[max(k[u], 0)];
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (k[u] >= 0) atomicAdd(&childCnt[4 * k[u] + qt_quadrant(nd[u], pt_x(p[u]), pt_y(p[u]))], 1);
+      if (k[u] >= 0) atomicAdd(&childCnt[4 * k[u] + qt_quadrant_mid(md[u], pt_x(p[u]), pt_y(p[u]))], 1);
   }
   __syncthreads();
 }
@@ -993,42 +1004,46 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
     carry += tot;
   }
   __syncthreads();
+  // per node: its successors in the new list, and the 8-byte record its points read below (the sort buffer is dead here):
+  //   low word = split point; high word = first child's position | non-empty children << 16 | single-point children << 20 | 1 << 24
+  //   (split node), or the node's own new position (unsplit)
+  unsigned long long* rec = sh.sortbuf;
   for (int k = threadIdx.x; k < S; k += OCT_T) {
     const QNode nd = old[k];
     if (sh.flag[k]) {
       const int base = sh.posArr[k];
-      const int mask = qt_mask(sh.childCnt, k);
+      const int c0 = sh.childCnt[4 * k], c1 = sh.childCnt[4 * k + 1], c2 = sh.childCnt[4 * k + 2], c3 = sh.childCnt[4 * k + 3];
+      const int mask = (c0 > 0 ? 1 : 0) | (c1 > 0 ? 2 : 0) | (c2 > 0 ? 4 : 0) | (c3 > 0 ? 8 : 0);
+      const int single = (c0 == 1 ? 1 : 0) | (c1 == 1 ? 2 : 0) | (c2 == 1 ? 4 : 0) | (c3 == 1 ? 8 : 0);
+      const int cc[4] = {c0, c1, c2, c3};
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (mask & (1 << q)) nw[base + __popc(mask >> (q + 1))] = qt_child(nd, q, sh.childCnt[4 * k + q]);
+        if (mask & (1 << q)) nw[base + __popc(mask >> (q + 1))] = qt_child(nd, q, cc[q]);
+      rec[k] = (unsigned long long)qt_mid(nd) | ((unsigned long long)((uint32_t)base | (uint32_t)mask << 16 | (uint32_t)single << 20 | 1u << 24) << 32);
     } else {
-      nw[-(sh.posArr[k] + 1)] = nd;
+      const int np = -(sh.posArr[k] + 1);
+      nw[np] = nd;
+      rec[k] = (unsigned long long)(uint32_t)np << 32;
     }
   }
   __syncthreads();
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * OCT_T) {   // four points per trip, loads first (see qt_count_children)
-    int k[4], pa[4], c4[4][4];
+    int k[4];
     uint32_t p[4];
-    QNode nd[4];
+    unsigned long long rc[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; k[u] = i < n ? nodeOf[i] : -1; p[u] = i < n ? pts[i] : 0u; }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int kk = max(k[u], 0);
-      pa[u] = sh.posArr[kk];
-      nd[u] = old[kk];
-#pragma unroll
-      for (int q = 0; q < 4; q++) c4[u][q] = sh.childCnt[4 * kk + q];
-    }
+    for (int u = 0; u < 4; u++) rc[u] = rec[max(k[u], 0)];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * OCT_T;
       if (k[u] < 0) continue;
-      if (pa[u] < 0) { nodeOf[i] = -(pa[u] + 1); continue; }
-      const int q = qt_quadrant(nd[u], pt_x(p[u]), pt_y(p[u]));
-      const int mask = (c4[u][0] > 0 ? 1 : 0) | (c4[u][1] > 0 ? 2 : 0) | (c4[u][2] > 0 ? 4 : 0) | (c4[u][3] > 0 ? 8 : 0);
-      const int np = pa[u] + __popc(mask >> (q + 1));
-      if (c4[u][q] == 1) { nw[np].pt = i; nodeOf[i] = -1; }
+      const uint32_t hi = (uint32_t)(rc[u] >> 32);
+      if (!(hi & (1u << 24))) { nodeOf[i] = (int)hi; continue; }
+      const int q = qt_quadrant_mid((uint32_t)rc[u], pt_x(p[u]), pt_y(p[u]));
+      const int np = (int)(hi & 0xFFFFu) + __popc(((hi >> 16) & 15u) >> (q + 1));
+      if ((hi >> (20 + q)) & 1u) { nw[np].pt = i; nodeOf[i] = -1; }
       else nodeOf[i] = np;
     }
   }
@@ -1299,7 +1314,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   while (!finish) {
     const int S = s_S;
     // full sweep: split every multi-point node (:622-681)
-    qt_count_children(sh.nodes_(cur), S, sh.childCnt, pts, nodeOf, n);
+    qt_count_children(sh.nodes_(cur), S, sh.childCnt, (uint32_t*)sh.posArr, pts, nodeOf, n);
     int nExpandLocal = 0;
     {
       // children block: node k's children sit in front of the children of all earlier nodes
@@ -1354,7 +1369,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     while (!finish) {
       const int Sb = s_S;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
-      qt_count_children(sh.nodes_(cur), Sb, sh.childCnt, pts, nodeOf, n);
+      qt_count_children(sh.nodes_(cur), Sb, sh.childCnt, (uint32_t*)sh.posArr, pts, nodeOf, n);
       for (int r = tid; r < m; r += OCT_T) {
         const QNode& nd = sh.nodes_(cur)[sh.expl[r]];
         sh.sortbuf[r] = ((unsigned long long)(uint32_t)nd.cnt << 28) | ((unsigned long long)(uint16_t)nd.ulx << 12) |
