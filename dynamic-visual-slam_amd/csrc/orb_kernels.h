@@ -1192,9 +1192,11 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     int* coL = sh.childCnt;
     const bool coLds = L.nCells <= 4 * nmax;
     int carry = 0;
+    int vnext = tid < L.nCells ? cc[tid] : 0;   // the next trip's count is requested before this trip's scan: one exposed global round trip, not one per trip
     for (int b = 0; b < L.nCells; b += OCT_T) {
       const int c = b + tid;
-      const int v = c < L.nCells ? cc[c] : 0;
+      const int v = vnext;
+      vnext = c + OCT_T < L.nCells ? cc[c + OCT_T] : 0;
       int tot;
       const int ex = block_excl_scan_rt(v, wsum, tot);
       if (c < L.nCells) {
@@ -1213,23 +1215,25 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     int* cellOf = inLds ? ldsNodeOf : nodeOf;
     const int total = s_n;
     for (int c = tid; c < L.nCells; c += OCT_T) {
-      const int b0 = coLds ? coL[c] : co[c], cn = cc[c];
-      for (int k = 0; k < cn; k++) cellOf[b0 + k] = c;
+      // a cell's count = the next cell's offset - its own (LDS) where the offsets are there: no second trip to the counts in HBM
+      const int b0 = coLds ? coL[c] : co[c], b1 = coLds ? (c + 1 < L.nCells ? coL[c + 1] : total) : b0 + cc[c];
+      for (int k = b0; k < b1; k++) cellOf[k] = c;
     }
     __syncthreads();
-    // four candidates per thread and trip: their loads are independent, so the global latency is paid once per trip (the level-0
-    // workgroup walks ~6000 candidates with 256 threads: 24 dependent round trips before, 6 now)
-    for (int i0 = tid; i0 < total; i0 += 4 * OCT_T) {
-      int cidx[4], off[4];
-      uint32_t v[4];
+    // eight candidates per thread and trip: their loads are independent, so the global latency is paid once per trip (the level-0
+    // workgroup walks 4000-6000 candidates with 256 threads: 16-24 dependent round trips one by one, 2-3 now)
+    constexpr int kG = 8;
+    for (int i0 = tid; i0 < total; i0 += kG * OCT_T) {
+      int cidx[kG], off[kG];
+      uint32_t v[kG];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; cidx[u] = i < total ? cellOf[i] : 0; }
+      for (int u = 0; u < kG; u++) { const int i = i0 + u * OCT_T; cidx[u] = i < total ? cellOf[i] : 0; }
 #pragma unroll
-      for (int u = 0; u < 4; u++) off[u] = coLds ? coL[cidx[u]] : co[cidx[u]];
+      for (int u = 0; u < kG; u++) off[u] = coLds ? coL[cidx[u]] : co[cidx[u]];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int i = i0 + u * OCT_T; v[u] = i < total ? cnd[(uint64_t)cidx[u] * L.cellCap + (i - off[u])] : 0u; }
+      for (int u = 0; u < kG; u++) { const int i = i0 + u * OCT_T; v[u] = i < total ? cnd[(uint64_t)cidx[u] * L.cellCap + (i - off[u])] : 0u; }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kG; u++) {
         const int i = i0 + u * OCT_T;
         if (i < total) {
           gpts[i] = v[u];                 // kept in HBM too: dvs_orb_get_candidates reads it
