@@ -238,22 +238,33 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
   // the LAST frame of a caller's buffer (guardFrame).  Round 2a sent every row-end lane — and with it its whole wavefront, one in
   // five at level 1, one in two at level 7 — through the bytewise path.
   const bool tailLane = t.base + 12 > sw;
+  // Consecutive output rows share source rows (scale 1.2: the upper source row of output row y + 1 is the lower one of row y five times
+  // out of six): a wavefront's rows are uniform, so whether row r's upper source row is row r - 1's lower one is a scalar condition —
+  // then it is neither loaded nor filtered horizontally again (3 of the 8 row windows and horizontal passes of a thread, typically)
   uint32_t w0[kResizeRows][3], w1[kResizeRows][3];
   int bb[kResizeRows];
+  bool shared[kResizeRows];
+  int prevLower = -1;
 #pragma unroll
   for (int r = 0; r < kResizeRows; r++) {
     const int y = min(y0 + r, dh - 1);
     const int sy = yofs[y];
     bb[r] = beta[y];
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+    shared[r] = r0 == prevLower;
+    prevLower = r1;
     const u8* p0 = s + (uint32_t)(r0 * sp + t.base);
     const u8* p1 = s + (uint32_t)(r1 * sp + t.base);
     const bool fastw = !(tailLane && f == guardFrame && r1 == sh - 1);
     if (fastw) {
-      const uint2 a = *reinterpret_cast<const uint2*>(p0);
       const uint2 c = *reinterpret_cast<const uint2*>(p1);
-      w0[r][0] = a.x; w0[r][1] = a.y; w0[r][2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
       w1[r][0] = c.x; w1[r][1] = c.y; w1[r][2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
+      if (!shared[r]) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p0);
+        w0[r][0] = a.x; w0[r][1] = a.y; w0[r][2] = *reinterpret_cast<const uint32_t*>(p0 + 8);
+      } else {
+        w0[r][0] = w0[r][1] = w0[r][2] = 0u;
+      }
     } else {  // row tail: bytewise, never past the last valid pixel
       int lastpx = sw - 1 - t.base;
       asm volatile("" : "+v"(lastpx));   // defined HERE: the compiler otherwise hoists the twelve clamps below into the path every wavefront takes
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     }
   }
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  uint32_t hlow[4] = {0u, 0u, 0u, 0u};   // the horizontal sums of the previous output row's lower source row
 #pragma unroll
   for (int r = 0; r < kResizeRows; r++) {
     if (y0 + r >= dh) break;
@@ -279,15 +291,23 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     // vertical term in two instructions (and, mul_hi) instead of three (shift, mul, shift)
     const uint32_t b0 = (uint32_t)(bb[r] & 0xffff) << 12, b1 = (uint32_t)(bb[r] >> 16) << 12;
     // 8-byte window starting at the group's first tap
-    const uint32_t lo0 = __builtin_amdgcn_alignbit(w0[r][1], w0[r][0], t.shift), hi0 = __builtin_amdgcn_alignbit(w0[r][2], w0[r][1], t.shift);
+    uint32_t hup[4];
+    if (shared[r]) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) hup[i] = hlow[i];
+    } else {
+      const uint32_t lo0 = __builtin_amdgcn_alignbit(w0[r][1], w0[r][0], t.shift), hi0 = __builtin_amdgcn_alignbit(w0[r][2], w0[r][1], t.shift);
+#pragma unroll
+      for (int i = 0; i < 4; i++)   // (left tap, right tap) as two u16 halves, then a0 * left + a1 * right in one v_dot2_u32_u16
+        hup[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false);
+    }
     const uint32_t lo1 = __builtin_amdgcn_alignbit(w1[r][1], w1[r][0], t.shift), hi1 = __builtin_amdgcn_alignbit(w1[r][2], w1[r][1], t.shift);
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      // (left tap, right tap) as two u16 halves, then a0 * left + a1 * right in one v_dot2_u32_u16
-      const us2 al = __builtin_bit_cast(us2, t.alpha[i]);
-      const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), al, 0u, false);
-      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), al, 0u, false);
+      const uint32_t h0 = hup[i];
+      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false);
+      hlow[i] = h1;
       const uint32_t v = (mulhi_u24(b0, h0 & ~15u) + mulhi_u24(b1, h1 & ~15u) + 2u) >> 2;   // <= 255: a convex combination of bytes
       out |= v << (8 * i);
     }
