@@ -10,7 +10,9 @@ pipelined over two streams:
   * the match of batch i - 1 runs on the match stream, released by the extractor behind batch i's FAST (`set_after_fast_event`) so
     that the matrix-core match runs beside the quad-tree / blur phase;
   * `nsets` output sets rotate: step i writes set i % nsets; its last reader is the match of batch i + 1 (frame 0 of batch i + 1
-    against the last frame of batch i), handed to the extractor as the reuse guard of step i + nsets.
+    against the last frame of batch i), handed to the extractor as the reuse guard of step i + nsets.  That match is enqueued in
+    step i + 2, so the pipelined schedule needs nsets >= 3: with two sets step i + 2 would overwrite the set the match enqueued
+    BEHIND it still reads (no event of that match exists yet when the extraction is enqueued) — refused in the constructor.
 
 With a communicator (frames sharded contiguously over ranks) the frame before this rank's first frame comes
 from `comm.exchange_boundary` (csrc/comm.hip: one all-gather of every rank's last frame per global batch) instead of the previous
@@ -27,6 +29,9 @@ from .orb import ORBextractor
 
 class StreamingPipeline:
     def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=4, pipelined=True, params=(1.2, 8, 20, 7)):
+        if pipelined and nsets < 3:
+            raise ValueError("the pipelined schedule rotates at least 3 output sets (the match of batch i + 1 reads batch i's last frame "
+                             "and is enqueued in step i + 2)")
         self.L = _lib.lib()
         self.B, self.rows, self.cols, self.device, self.nsets, self.pipelined = B, rows, cols, device, nsets, pipelined
         self.orb = ORBextractor(nfeatures, *params, device=device, max_batch=B)

@@ -116,3 +116,11 @@ def test_geometry_rejects_sizes_the_reference_divides_by_zero_on(hiplib):
     from dvslam_amd._lib import OrbParams
     p = OrbParams(500, 1.2, 8, 20, 7, (C.c_int32 * 7)(*([0] * 7)), 1)
     assert hiplib.dvs_test_geometry(C.byref(p), 120, 160, None, None, None, None, None, None) == -2
+
+
+def test_pipelined_schedule_refuses_two_output_sets():
+    """the match of batch i + 1 reads batch i's last frame and is enqueued in step i + 2: with two output sets step i + 2 would
+    overwrite that set with no event to wait for (dvslam_amd/pipeline.py)"""
+    from dvslam_amd.pipeline import StreamingPipeline
+    with pytest.raises(ValueError):
+        StreamingPipeline(4, 480, 640, nsets=2, pipelined=True)
