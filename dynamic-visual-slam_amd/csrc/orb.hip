@@ -81,7 +81,7 @@ struct dvs_orb {
   // switches read ONCE at creation (dvs_orb_create); each is covered by tests/test_gpu_orb.py::test_opt_in_kernel_variants_are_bit_identical
   int env_cascade = -1;            // DVS_CASCADE=1 / 0: all-levels-in-one-launch pyramid always / never (-1 = automatic: <= 8 frames)
   int fast_byte_dma = 0;           // LDS-DMA with byte-aligned global addresses probed exact (DVS_FAST_BYTE_DMA=0 turns it off)
-  int env_blur_mfma = 0;           // DVS_BLUR_MFMA=1: the matrix-core blur (k_blur_mfma); measured slower (memory side), DESIGN.md 4b
+  int env_blur_mfma = 0;           // DVS_BLUR_MFMA=1: the matrix-core blur (k_blur_mfma), 2: its LDS-free form; measured slower in the step, DESIGN.md 4b
   int env_oct_threads = 0;         // DVS_OCT_T=256 / 512: quad-tree workgroup size for every batch size (0 = by batch size)
   int env_host_poll = 1;           // DVS_HOST_POLL=0: three device-to-host copy commands and a stream wait instead of k_export_host
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
@@ -637,7 +637,10 @@ void launch_blur(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t bst, bool 
   // matrix-core blur: 16-byte aligned rows (the pyramid block always is; a caller's level 0 when its pointer and strides are)
   const bool mfma_ok = h->env_blur_mfma && h->blur_mfma_ok && stream_ok &&
                        (((uintptr_t)src.img0 | src.step0 | src.fstride0) % 16 == 0) && src.step0 >= 16;
-  if (mfma_ok)
+  if (mfma_ok && h->env_blur_mfma == 2)
+    hipLaunchKernelGGL(k_blur_mfma_direct, dim3(h->n_blurcols, nimg), dim3(256), 0, bst, h->d_geom, h->d_blurcols, h->n_blurcols, src, h->d_blur,
+                       h->d_blurtab, h->blur_avt);
+  else if (mfma_ok)
     hipLaunchKernelGGL(k_blur_mfma, dim3(h->n_blurcols, nimg), dim3(256), 0, bst, h->d_geom, h->d_blurcols, h->n_blurcols, src, h->d_blur,
                        h->d_blurtab, h->blur_avt);
   else if (stream_ok)

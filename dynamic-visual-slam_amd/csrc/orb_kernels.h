@@ -1783,6 +1783,105 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const Geom* __restrict__ g, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The matrix-core blur WITHOUT LDS (round 3, DVS_BLUR_MFMA=2): every wavefront filters its own 32-column strip, operand fragments
+// come straight from global memory (a lane = one row: 16-byte pieces of 32 different rows per load instruction) and the output
+// leaves as one 16-byte store per lane (two v_permlane32_swap put a lane's 4 x 4 columns side by side).  No barriers, no LDS: the
+// kernel can share a CU with FAST or the quad-tree, whose workgroups take all of its LDS.  Same tables, same arithmetic, same
+// results as k_blur_mfma.  Alone 0.115 ms per 64 frames (k_blur_stream 0.081, k_blur_mfma 0.118); in the step it LOSES in either
+// place — beside the quad-tree 0.511 against 0.482 ms (the quad-tree stretches 0.099 -> 0.141), started ahead of FAST 0.497 against
+// 0.473 (FAST 0.352 -> 0.340, but the level chain 0.213 -> 0.292 and the quad-tree 0.098 -> 0.119): DESIGN.md 4b.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_mfma_direct(const Geom* __restrict__ g, const BlurCol* __restrict__ items, int nitems, ImgSrc src,
+                                                          u8* __restrict__ blur, const uint4* __restrict__ tab, int avt) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xid = xcd_contiguous_id();
+  const int f = xid / (int)gridDim.x;
+  const BlurCol it = items[xid - f * (int)gridDim.x];
+  if (!((src.levelMask >> it.level) & 1u)) return;
+  const int lane = lane_id(), m = lane & 31, half = lane >> 5;
+  const LevelGeom& L = g->lv[it.level];
+  int pitch;
+  const u8* img = level_ptr(g, src, f, it.level, pitch);
+  u8* dst = blur + (uint64_t)f * g->frameBytes + L.off;
+  const int W = L.w, H = L.h, dp = L.pitch;
+  const int c0 = it.strip * 128 + 32 * wv;        // this wavefront's strip
+  if (c0 >= W) return;
+  const int ti = (it.tab + wv) * 2;
+  const bv4i Bh1 = __builtin_bit_cast(bv4i, tab[(ti + 0) * 64 + lane]), Bh2 = __builtin_bit_cast(bv4i, tab[(ti + 1) * 64 + lane]);
+  const bv4i Av0 = __builtin_bit_cast(bv4i, tab[(avt * 2 + 0) * 64 + lane]), Av1 = __builtin_bit_cast(bv4i, tab[(avt * 2 + 1) * 64 + lane]);
+  const bv4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+  const bv16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr uint32_t kC = 65536u + (32768u << 8);
+  // source pieces of this lane: columns c0 - 16 + 16 half and 32 further; pieces outside the row carry zero weights and are fetched from inside it
+  const uint32_t col1 = (uint32_t)min(max(c0 - 16 + 16 * half, 0), pitch - 16), col2 = (uint32_t)min(max(c0 + 16 + 16 * half, 0), pitch - 16);
+  auto row_off = [&](int vr) -> uint32_t {
+    int r = vr < 0 ? -vr : vr;
+    r = r >= H ? 2 * H - 2 - r : r;
+    r = min(max(r, 0), H - 1);
+    return (uint32_t)r * (uint32_t)pitch;
+  };
+  bv4i r1, r2;
+  auto issue = [&](int b) {   // h-block b = source rows 32 b - 3 .. 32 b + 28
+    const uint32_t ro = row_off(32 * b - 3 + m);
+    r1 = *reinterpret_cast<const bv4i*>(img + ro + col1);
+    r2 = *reinterpret_cast<const bv4i*>(img + ro + col2);
+  };
+  auto hcomp = [&](const bv4i& x1, const bv4i& x2, bv4i& hi, bv4i& lo) {
+    bv16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1 ^ bias, Bh1, zero, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x2 ^ bias, Bh2, acc, 0, 0, 0);
+    uint32_t P[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) P[q] = __builtin_amdgcn_perm((uint32_t)acc[2 * q + 1], (uint32_t)acc[2 * q], 0x05040100u);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      hi[d] = (int)__builtin_amdgcn_perm(P[2 * d + 1], P[2 * d], 0x07050301u);
+      lo[d] = (int)(__builtin_amdgcn_perm(P[2 * d + 1], P[2 * d], 0x06040200u) ^ 0x80808080u);
+    }
+  };
+  const int ocol = c0 + 16 * half;
+  uint32_t so = (uint32_t)(32 * it.t0 + m) * (uint32_t)dp + (uint32_t)ocol;
+  auto vtile = [&](int t, const bv4i& chi, const bv4i& clo, const bv4i& nhi, const bv4i& nlo) {
+    bv16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(clo, Av0, zero, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(nlo, Av1, lo, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo[k] = (int)(((uint32_t)lo[k] + kC) >> 8);
+    bv16i u = __builtin_amdgcn_mfma_i32_32x32x32_i8(chi, Av0, lo, 0, 0, 0);
+    u = __builtin_amdgcn_mfma_i32_32x32x32_i8(nhi, Av1, u, 0, 0, 0);
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)u[4 * d + 1], (uint32_t)u[4 * d], 0x0c0c0501u);
+      const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)u[4 * d + 3], (uint32_t)u[4 * d + 2], 0x0c0c0501u);
+      o[d] = p01 | (p23 << 16);   // columns c0 + 4 half + 8 d .. + 3 of row m
+    }
+    // lower lanes hold columns {0, 8, 16, 24}, upper lanes {4, 12, 20, 28} (+ 0..3): after exchanging the upper half of o[0] / o[1] with the
+    // lower half of o[2] / o[3], (o0, o2, o1, o3) are 16 consecutive columns — 0..15 in the lower lanes, 16..31 in the upper ones
+    const auto s02 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+    if (32 * t + m < H && ocol < W) *reinterpret_cast<uint4*>(dst + so) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+    so += 32u * (uint32_t)dp;
+  };
+  bv4i hiA, loA, hiB, loB;
+  issue(it.t0);
+  bv4i x1 = r1, x2 = r2;
+  issue(it.t0 + 1);
+  hcomp(x1, x2, hiA, loA);
+  const int tend = it.t0 + it.nt;
+  for (int t = it.t0; t < tend; t += 2) {
+    x1 = r1; x2 = r2;
+    if (t + 1 < tend) issue(t + 2);
+    hcomp(x1, x2, hiB, loB);                // block t + 1
+    vtile(t, hiA, loA, hiB, loB);
+    if (t + 1 < tend) {
+      x1 = r1; x2 = r2;
+      if (t + 2 < tend) issue(t + 3);
+      hcomp(x1, x2, hiA, loA);              // block t + 2
+      vtile(t + 1, hiB, loB, hiA, loA);
+    }
+  }
+}
+
 // =============================================================================================
 // orientation + descriptor + final keypoint record.  One wavefront per keypoint.
 // =============================================================================================

@@ -378,7 +378,7 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
     _lib.stream_destroy(mstream)
 
 
-@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_CASCADE": "1"},
+@pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_BLUR_MFMA": "2"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_CASCADE": "1"},
                                  {"DVS_HOST_POLL": "0"}, {"DVS_OCT_T": "256"}, {"DVS_OCT_T": "512", "DVS_CASCADE": "0"}, {"DVS_NO_OVERLAP": "1"}])
 @pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 500, 8), (720, 1280, 2000, 8), (360, 1000, 700, 6), (250, 332, 200, 4), (200, 136, 150, 3)])
 def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, nf, nl):

@@ -80,6 +80,16 @@ def test_other_shapes_of_the_pipelined_step(gpu, oracle, B, rows, cols, nf, nset
     """the same step at other batch sizes (1 and 33: the small-batch kernel variants and the 256-thread quad-tree on either side of
     their thresholds), resolutions (widths that are not multiples of 4 take the generic kernels) and output-set counts: the resident
     batches and their match jobs against the oracle"""
+    _run_shape(oracle, B, rows, cols, nf, nsets, steps)
+
+
+def test_pipelined_step_with_the_lds_free_matrix_core_blur(gpu, oracle, monkeypatch):
+    """DVS_BLUR_MFMA=2 (k_blur_mfma_direct) in the pipelined schedule"""
+    monkeypatch.setenv("DVS_BLUR_MFMA", "2")
+    _run_shape(oracle, 5, 480, 640, 800, 3, 8)
+
+
+def _run_shape(oracle, B, rows, cols, nf, nsets, steps):
     from dvslam_amd import _lib
     from dvslam_amd.pipeline import StreamingPipeline
     NB = 3
