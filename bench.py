@@ -166,6 +166,25 @@ def ba_bench(dvslam_amd, synth, device, iters=200, W=64):
     return out
 
 
+_RESULT_FD = None
+
+
+def _stdout_to_stderr():
+    """Everything a rank writes to file descriptor 1 from here on goes to stderr — RCCL prints a version banner ("RCCL version : ...")
+    on stdout when a communicator comes up — and the ONE JSON line leaves through the saved descriptor (_emit)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    sys.stdout.flush()
+    line = (json.dumps(obj) + "\n").encode()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -261,7 +280,7 @@ def level_sharded_bench(args, world, rank, local, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        _emit({
             "metric": "frames/sec ORB+match @1280x720x2000kp", "value": round(B * args.steps / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -269,7 +288,7 @@ def level_sharded_bench(args, world, rank, local, dev):
                                    "small batch", "frames_per_step_total": B, "frames_distinct": frames_distinct,
                        "parallelism": f"level-sharded x{world}: masks {[hex(m) for m in lx.masks]}, all_gather of {lx.block_bytes} B blocks, merge on "
                                       f"every rank", "keypoints_frame0": int(n[0].item())},
-            "rccl": None if comm is None else {"nranks": world, "version": comm.rccl_version}}), flush=True)
+            "rccl": None if comm is None else {"nranks": world, "version": comm.rccl_version}})
     if comm is not None:
         torch.cuda.synchronize()
         comm.close()
@@ -336,6 +355,7 @@ def main():
         print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local, "pid": os.getpid()}), flush=True)
         return
 
+    _stdout_to_stderr()
     import torch
     import torch.distributed as dist
     import dvslam_amd
@@ -521,7 +541,7 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cb_frames, args.nfeatures, nthr)
             out["speedup_vs_cpu_all_cores"] = round(fps / out["cpu_baseline_all_cores"]["value"], 1)
             out["ba"] = ba_bench(dvslam_amd, synth, local)
-        print(json.dumps(out), flush=True)
+        _emit(out)
     pipe.close()
     if comm is not None:
         torch.cuda.synchronize()

@@ -558,14 +558,20 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
     dim3 grid((D.w + 8 + 255) / 256, (D.h + 3) / 4, nimg), block(64, 4, 1);
     const bool aligned = (((uintptr_t)sp) | sfs | (uint64_t)spitch) % 4 == 0;
     if (aligned && D.gtab >= 0) {
-      const uint32_t tx = grid.x, ty = (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), tiles = tx * ty;
+      // the x axis runs over the 4-pixel groups of fpg consecutive frames (k_resize4): whole multiples of 8 frames are dealt to the XCDs
+      // as 8 groups; the frames of a group must stay within 32-bit offsets of its first one
+      const int dwp = (D.w + 8) & ~3, ngx = dwp / 4;
+      int fpg = nimg >= 16 && nimg % 8 == 0 ? nimg / 8 : 1;
+      if ((uint64_t)fpg * std::max<uint64_t>(sfs, G.frameBytes) >= (1ull << 31)) fpg = 1;
+      const int ngroups = nimg / fpg;
+      const uint32_t tx = (uint32_t)(fpg * ngx + 63) / 64, ty = (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), tiles = tx * ty;
       // n / d == umulhi(n, 2^32 / d + 1) for every n with n * d < 2^32
       auto magic = [](uint64_t nmax, uint32_t d) -> uint32_t { return d > 1 && nmax * d < (1ull << 32) ? (uint32_t)((1ull << 32) / d + 1) : 0u; };
-      hipLaunchKernelGGL(k_resize4, dim3(tiles, nimg), block, 0, pst,
-                         sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, (D.w + 8) & ~3, D.h, D.pitch,
+      hipLaunchKernelGGL(k_resize4, dim3(tiles, ngroups), block, 0, pst,
+                         sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, dwp, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab,
                          l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off ? nimg - 1 : -1,   // caller's buffer: no slack behind its last row
-                         (int)tx, magic((uint64_t)tiles * nimg, tiles), magic(tiles, tx));
+                         (int)tx, magic((uint64_t)tiles * ngroups, tiles), magic(tiles, tx), ngx, fpg, magic((uint64_t)tx * 64, (uint32_t)ngx), nimg);
     }
     else
       hipLaunchKernelGGL(k_resize, grid, block, 0, pst, sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, D.w, D.h,

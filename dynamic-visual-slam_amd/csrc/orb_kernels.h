@@ -212,27 +212,37 @@ constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x 
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
-                                                 const int* __restrict__ beta, int guardFrame, int tilesX, uint32_t magicTiles, uint32_t magicX) {
+                                                 const int* __restrict__ beta, int guardFrame, int tilesX, uint32_t magicTiles, uint32_t magicX,
+                                                 int ngx, int fpg, uint32_t magicNgx, int nimg) {
   // (raising these waves' issue priority over the FAST waves they run beside, s_setprio, was measured: 3 % slower overall)
   // grid = (tiles of a frame, frames), workgroups dealt to the XCDs frame by frame (xcd_contiguous_id): the source rows and the
   // 128-byte lines neighbouring tiles share then meet in ONE L2 (round 2's (x, y, frame) grid spread a frame's tiles over all eight:
   // 1.32x the algorithmic bytes fetched).  The two divisions are by host-made reciprocals on the scalar unit (exact: the host checks
   // the ranges and passes magic = 0 otherwise).
+  // The x axis of the grid runs over the 4-pixel groups of `fpg` consecutive frames, one row of groups behind the other (ngx = dw / 4
+  // groups per frame): level widths are no multiples of a wavefront's 256 pixels — 130 groups at level 5 filled 3 wavefronts to two
+  // thirds, one lane in six of the whole chain idled — while 8 x 130 groups fill 17 wavefronts.  Rows stay wave-uniform; the frame is a
+  // per-lane offset.  fpg = frames / 8 for batches of whole multiples of 8 (a group is what one XCD receives), else 1.
   const uint32_t wg = (uint32_t)xcd_contiguous_id(), tiles = gridDim.x;
-  const uint32_t f = magicTiles ? __umulhi(wg, magicTiles) : wg / tiles;
-  const uint32_t tile = wg - f * tiles;
+  const uint32_t grp = magicTiles ? __umulhi(wg, magicTiles) : wg / tiles;
+  const uint32_t tile = wg - grp * tiles;
   const uint32_t by = magicX ? __umulhi(tile, magicX) : tile / (uint32_t)tilesX;
   const uint32_t bx = tile - by * (uint32_t)tilesX;
-  const int gx = (int)bx * 64 + threadIdx.x;
+  const uint32_t q = bx * 64u + threadIdx.x;
+  const uint32_t fl = magicNgx ? __umulhi(q, magicNgx) : q / (uint32_t)ngx;   // frame within the group
+  const int gx = (int)(q - fl * (uint32_t)ngx);
   const int x4 = gx * 4;
+  const uint32_t f = grp * (uint32_t)fpg + fl;
   // a wavefront is one threadIdx.y row of the (64, 4) block: everything that depends on y only is wave-uniform, and saying so
   // (v_readfirstlane) moves the row table lookups and the 64-bit row address arithmetic to the scalar unit
   const int y0 = ((int)by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kResizeRows;
-  if (x4 >= dw || y0 >= dh) return;
+  if (fl >= (uint32_t)fpg || f >= (uint32_t)nimg || y0 >= dh) return;
   const ResizeGroup t = xt[gx];
-  // uniform frame bases + 32-bit per-lane offsets (a level is far smaller than 4 GB): no 64-bit vector multiply-adds
-  const u8* s = src + (uint64_t)f * sfs;
-  u8* d = dst + (uint64_t)f * dfs;
+  // uniform group bases + 32-bit per-lane offsets (the frames of a group span far less than 4 GB: checked on the host): no 64-bit
+  // vector multiply-adds.  The lane's frame rides in its column offsets.
+  const u8* s = src + (uint64_t)(grp * (uint32_t)fpg) * sfs;
+  u8* d = dst + (uint64_t)(grp * (uint32_t)fpg) * dfs;
+  const uint32_t fos = fl * (uint32_t)sfs, fod = fl * (uint32_t)dfs + (uint32_t)x4;
   // the 12-byte windows of a row's last group run up to 11 bytes past the row: harmless everywhere (the bytes past the last tap carry
   // zero weights, and what follows a row is the next row, the next level or the allocation's slack) except behind the LAST row of
   // the LAST frame of a caller's buffer (guardFrame).  Round 2a sent every row-end lane — and with it its whole wavefront, one in
@@ -253,9 +263,9 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
     shared[r] = r0 == prevLower;
     prevLower = r1;
-    const u8* p0 = s + (uint32_t)(r0 * sp + t.base);
-    const u8* p1 = s + (uint32_t)(r1 * sp + t.base);
-    const bool fastw = !(tailLane && f == guardFrame && r1 == sh - 1);
+    const u8* p0 = s + ((uint32_t)(r0 * sp) + ((uint32_t)t.base + fos));
+    const u8* p1 = s + ((uint32_t)(r1 * sp) + ((uint32_t)t.base + fos));
+    const bool fastw = !(tailLane && (int)f == guardFrame && r1 == sh - 1);
     if (fastw) {
       const uint2 c = *reinterpret_cast<const uint2*>(p1);
       w1[r][0] = c.x; w1[r][1] = c.y; w1[r][2] = *reinterpret_cast<const uint32_t*>(p1 + 8);
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
     }
   }
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  uint32_t hlow[4] = {0u, 0u, 0u, 0u};   // the horizontal sums of the previous output row's lower source row
+  uint32_t hlow[4] = {0u, 0u, 0u, 0u};   // the horizontal sums (h >> 4 << 4: what the vertical term uses) of the previous output row's lower source row
 #pragma unroll
   for (int r = 0; r < kResizeRows; r++) {
     if (y0 + r >= dh) break;
@@ -299,20 +309,23 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
       const uint32_t lo0 = __builtin_amdgcn_alignbit(w0[r][1], w0[r][0], t.shift), hi0 = __builtin_amdgcn_alignbit(w0[r][2], w0[r][1], t.shift);
 #pragma unroll
       for (int i = 0; i < 4; i++)   // (left tap, right tap) as two u16 halves, then a0 * left + a1 * right in one v_dot2_u32_u16
-        hup[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false);
+        hup[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false) & ~15u;
     }
     const uint32_t lo1 = __builtin_amdgcn_alignbit(w1[r][1], w1[r][0], t.shift), hi1 = __builtin_amdgcn_alignbit(w1[r][2], w1[r][1], t.shift);
-    uint32_t out = 0;
+    uint32_t sum[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t h0 = hup[i];
-      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false);
+      const uint32_t h0 = hup[i];   // already without its low four bits (both branches above)
+      const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, t.sel[i])), __builtin_bit_cast(us2, t.alpha[i]), 0u, false) & ~15u;
       hlow[i] = h1;
-      const uint32_t v = (mulhi_u24(b0, h0 & ~15u) + mulhi_u24(b1, h1 & ~15u) + 2u) >> 2;   // <= 255: a convex combination of bytes
-      out |= v << (8 * i);
+      sum[i] = mulhi_u24(b0, h0) + mulhi_u24(b1, h1) + 2u;   // the pixel is sum >> 2 (<= 255: a convex combination of bytes), sum < 1024
     }
+    // four sums -> four bytes in five instructions: the sums of a pixel pair side by side in 16-bit halves, ONE shift for both (the
+    // neighbour's two low bits land in byte 1, which nobody reads), one permute picks bytes 0 and 2 of either pair
+    const uint32_t p01 = (sum[0] | (sum[1] << 16)) >> 2, p23 = (sum[2] | (sum[3] << 16)) >> 2;
+    const uint32_t out = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
     // dw is the padded width (multiple of 4, <= pitch): mirrored columns included
-    *reinterpret_cast<uint32_t*>(d + (uint32_t)((y0 + r) * dp + x4)) = out;
+    *reinterpret_cast<uint32_t*>(d + ((uint32_t)((y0 + r) * dp) + fod)) = out;
   }
 }
 

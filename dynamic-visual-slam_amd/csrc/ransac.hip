@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
   __shared__ double sm27[27][256];   // 54 KB: all normal-equation sums of an iteration in one reduction tree
   __shared__ double sR[9], st[3], sRn[9], stn[3], sH[36], sg[6], sd[6];
   __shared__ int s_cnt, s_wsum[5];
-  __shared__ double s_lambda, s_cost;
+  __shared__ double s_lambda;
   __shared__ int s_stop;
   const int tid = threadIdx.x;
   const int best = sel[0];
