@@ -7,9 +7,9 @@
 // replays the sequential loop over the counts — RANSACUpdateNumIters's adaptive stopping rule included — so the result is what
 // the sequential loop with the same samples would return.
 //
-// What can NOT be reproduced is OpenCV's sample sequence (cv::RNG state threaded through the whole process) and with it the
-// bit pattern of the result; the reference only consumes the inlier SET (frontend.cpp:640-644, 1149-1153) and the refined pose.
-// So the sampler is our own, stated here and in DESIGN.md: sample j of hypothesis h draws r = splitmix64(seed + 0x9E3779B97F4A7C15
+// Two forms of the fundamental-matrix stage: dvs_find_fundamental_cv follows OpenCV's own procedure (cv::RNG sample sequence, 7-point
+// solver: see k_f7_hypotheses below); dvs_find_fundamental_ransac and the PnP stage are the library's own estimators — the reference
+// only consumes the inlier SET (frontend.cpp:640-644, 1149-1153) and the refined pose — over a sampler stated here and in DESIGN.md: sample j of hypothesis h draws r = splitmix64(seed + 0x9E3779B97F4A7C15
 // * (h * 16 + j + 1)) mod (n - j) and takes the r-th index not drawn before (ascending), i.e. a uniform draw without
 // replacement; parity is a tolerance on the inlier set and the pose (tests/test_gpu_ransac.py), not bit equality.
 // Minimal solvers: normalised 8-point (null vector by complete-pivoting elimination, rank 2 enforced through the smallest
@@ -234,7 +234,7 @@ __device__ __forceinline__ int block_count256(bool pred) {  // number of threads
 
 // one workgroup per hypothesis: inlier count over all correspondences
 __global__ __launch_bounds__(256) void k_f_score(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
-                                                 const double* __restrict__ Fall, const int* __restrict__ valid, double thr2, int* __restrict__ counts) {
+                                                 const double* __restrict__ Fall, const int* __restrict__ valid, double thr2, int* __restrict__ counts, int fcmp) {
   const int h = blockIdx.x;
   const RansacProb pb = probs[blockIdx.y];
   const int n = pb.n;
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256) void k_f_score(const float* __restrict__ p1, c
   for (int i0 = 0; i0 < n; i0 += 256) {
     const int i = i0 + threadIdx.x;
     bool in = false;
-    if (i < n) in = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr2;
+    if (i < n) {
+      const double e = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+      in = fcmp ? (float)e <= (float)thr2 : e <= thr2;   // OpenCV stores the error and the squared threshold as floats (findInliers)
+    }
     total += block_count256(in);
   }
   if (threadIdx.x == 0) counts[h] = total;
@@ -268,12 +271,13 @@ __device__ __forceinline__ int ransac_update_iters(double p, double ep, int mode
 // the sequential RANSAC loop replayed over the hypothesis counts (RANSACPointSetRegistrator::run): hypothesis h is iteration h,
 // a strictly better count replaces the best and shortens the loop.  sel[0] = best hypothesis (-1: none), sel[1] = iterations used.
 __global__ void k_ransac_select(const int* __restrict__ counts, int H, const RansacProb* __restrict__ probs, int modelPoints, double confidence, int group,
-                                int* __restrict__ sel) {
+                                int* __restrict__ sel, int capInSeed = 0) {
   if (threadIdx.x != 0) return;
   const int n = probs[blockIdx.x].n;
   counts += (size_t)H * blockIdx.x; sel += 4 * (size_t)blockIdx.x;
   int niters = H / group, best = -1, bestCount = 0, it = 0;
   const int maxIters = niters;
+  if (capInSeed) niters = min(niters, (int)probs[blockIdx.x].seed);   // cv mode: the iterations getSubset found a sample for
   for (; it < niters; it++) {
     for (int s = 0; s < group; s++) {   // `group` candidate models per iteration (P3P: up to 4 poses per sample), in order
       const int h = it * group + s;
@@ -289,7 +293,7 @@ __global__ void k_ransac_select(const int* __restrict__ counts, int H, const Ran
 
 __global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
                                                 const double* __restrict__ Fall, const int* __restrict__ sel, double thr2, unsigned char* __restrict__ mask,
-                                                double* __restrict__ Fbest) {
+                                                double* __restrict__ Fbest, int fcmp) {
   const RansacProb pb = probs[blockIdx.y];
   const int n = pb.n;
   p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off; mask += pb.off;
@@ -300,7 +304,236 @@ __global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, co
   double F[9];
   for (int k = 0; k < 9; k++) F[k] = Fall[9 * (size_t)best + k];
   if (i < 9) Fbest[i] = F[i];
-  if (i < n) mask[i] = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr2 ? 1 : 0;
+  if (i < n) {
+    const double e = epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+    mask[i] = (fcmp ? (float)e <= (float)thr2 : e <= thr2) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// cv::findFundamentalMat(FM_RANSAC) as OpenCV 4.x runs it for >= 15 points (calib3d fundam.cpp / ptsetreg.cpp, restated from the
+// published algorithm — the library is not in this image, PARITY UNPINNED):
+//   * RANSACPointSetRegistrator(modelPoints = 7): one cv::RNG, seeded with (uint64)-1, threaded through all iterations; getSubset
+//     draws index i as rng.uniform(0, n) = next() % n, drawn again while it repeats an earlier index of the sample; a complete
+//     sample whose LAST point is collinear with two earlier ones in either image (FMEstimatorCallback::checkSubset ->
+//     haveCollinearPoints) is drawn again as a whole, up to 10000 attempts;
+//   * cv::RNG::next(): multiply-with-carry, state = (uint32)state * 4164903690 + (state >> 32), value = (uint32)state;
+//   * run7Point: the two null vectors f1, f2 of the 7 x 9 system of RAW pixel coordinates, det(lambda f1 + (1 - lambda) f2) = 0 by
+//     cv::solveCubic (closed form), one model per real root, scaled to F(3,3) = 1; every model of a sample is scored in order;
+//   * findInliers: error and squared threshold compared as floats; a strictly better count replaces the best model and shortens the
+//     loop (RANSACUpdateNumIters with modelPoints = 7).  No refit on the inliers.
+// The sample sequence is sequential by nature (a repeated index or a rejected sample shifts everything behind it): it is made on
+// the HOST (cv_subsets: microseconds) and uploaded with the points; the models of all samples are fitted and scored at once as in
+// the library's own estimator above, and the sequential loop is replayed over the counts.  OpenCV takes the null space from an SVD
+// (this kernel: complete-pivoting elimination): the same models to rounding, but the order of a sample's models follows the basis,
+// so a tie in inlier count between two models of ONE sample may resolve differently.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct CvRng {
+  unsigned long long state;
+  explicit CvRng(unsigned long long s = 0xffffffffull) : state(s ? s : 0xffffffffull) {}
+  unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32); return (unsigned)state; }
+  int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+static bool cv_have_collinear(const float* pts, const int* idx, int count) {   // the LAST point against every earlier pair
+  const int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = pts[2 * idx[j]] - pts[2 * idx[i]], dy1 = pts[2 * idx[j] + 1] - pts[2 * idx[i] + 1];
+    for (int k = 0; k < j; k++) {
+      const double dx2 = pts[2 * idx[k]] - pts[2 * idx[i]], dy2 = pts[2 * idx[k] + 1] - pts[2 * idx[i] + 1];
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+
+// the samples of iterations 0 .. iters - 1 (modelPoints indices each); returns how many iterations found one
+static int cv_subsets(const float* p1, const float* p2, int n, int modelPoints, int iters, int32_t* idx_out) {
+  CvRng rng(~0ull);
+  int idx[16];
+  for (int it = 0; it < iters; it++) {
+    bool found = false;
+    for (int attempt = 0; attempt < 10000 && !found; attempt++) {
+      for (int i = 0; i < modelPoints; i++) {
+        int v;
+        bool dup;
+        do {
+          v = rng.uniform(0, n);
+          dup = false;
+          for (int j = 0; j < i; j++) dup = dup || idx[j] == v;
+        } while (dup);
+        idx[i] = v;
+      }
+      found = !(cv_have_collinear(p1, idx, modelPoints) || cv_have_collinear(p2, idx, modelPoints));
+    }
+    if (!found) return it;
+    for (int i = 0; i < modelPoints; i++) idx_out[(size_t)it * modelPoints + i] = idx[i];
+  }
+  return iters;
+}
+
+// cv::solveCubic for c[0] x^3 + c[1] x^2 + c[2] x + c[3] (closed form, roots in the order OpenCV returns them)
+__device__ __forceinline__ int cv_solve_cubic(const double* c, double* x) {
+  double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+  int n = 0;
+  x[0] = x[1] = x[2] = 0;
+  if (a0 == 0) {
+    if (a1 == 0) {
+      if (a2 == 0) return 0;
+      x[0] = -a3 / a2; return 1;
+    }
+    double d = a2 * a2 - 4 * a1 * a3;
+    if (d >= 0) {
+      d = sqrt(d);
+      const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+      if (fabs(q1) > fabs(q2)) { x[0] = q1 / a1; x[1] = a3 / q1; } else { x[0] = q2 / a1; x[1] = a3 / q2; }
+      n = d > 0 ? 2 : 1;
+    }
+    return n;
+  }
+  a0 = 1. / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+  const double Q = (a1 * a1 - 3 * a2) * (1. / 9), R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+  const double Qcubed = Q * Q * Q;
+  double d = Qcubed - R * R;
+  if (d > 0) {
+    const double theta = acos(R / sqrt(Qcubed)), sqrtQ = sqrt(Q);
+    const double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+    x[0] = t0 * cos(t1) - t2;
+    x[1] = t0 * cos(t1 + (2. * 3.1415926535897932384626433832795 / 3)) - t2;
+    x[2] = t0 * cos(t1 + (4. * 3.1415926535897932384626433832795 / 3)) - t2;
+    n = 3;
+  } else if (d == 0) {
+    if (R >= 0) { x[0] = -2 * pow(R, 1. / 3) - a1 / 3; x[1] = pow(R, 1. / 3) - a1 / 3; }
+    else { x[0] = 2 * pow(-R, 1. / 3) - a1 / 3; x[1] = -pow(-R, 1. / 3) - a1 / 3; }
+    n = x[0] == x[1] ? 1 : 2;
+    if (n == 1) x[1] = 0;
+  } else {
+    d = sqrt(-d);
+    double e = pow(d + fabs(R), 1. / 3);
+    if (R > 0) e = -e;
+    x[0] = (e + Q / e) - a1 * (1. / 3);
+    n = 1;
+  }
+  return n;
+}
+
+__device__ __forceinline__ double det3rows(const double* a, const double* b, const double* c) {   // rows a, b, c
+  return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+}
+
+// one thread = one sample: up to three models at Fout[3 h .. 3 h + 2]
+__global__ __launch_bounds__(64) void k_f7_hypotheses(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs,
+                                                      const int32_t* __restrict__ samples, int H, double* __restrict__ Fout, int* __restrict__ valid) {
+  const int h = blockIdx.x * 64 + threadIdx.x;
+  if (h >= H) return;
+  const RansacProb pb = probs[blockIdx.y];
+  p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off;
+  Fout += 27 * (size_t)H * blockIdx.y; valid += 3 * (size_t)H * blockIdx.y; samples += 7 * (size_t)H * blockIdx.y;
+  valid[3 * h] = valid[3 * h + 1] = valid[3 * h + 2] = 0;
+  if (h >= (int)pb.seed) return;   // iterations getSubset found no sample for
+  double A[7][9];
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const int id = samples[7 * (size_t)h + i];
+    const double x0 = p1[2 * id], y0 = p1[2 * id + 1], x1 = p2[2 * id], y1 = p2[2 * id + 1];
+    A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1; A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1; A[i][6] = x0; A[i][7] = y0; A[i][8] = 1.0;
+  }
+  // reduced row echelon form by Gauss-Jordan elimination with complete pivoting, everything unrolled and the run-time pivot position
+  // applied by selects (as in k_f_hypotheses: the matrix stays in registers); the two columns never chosen are the free ones
+  int colOf[7];
+  unsigned usedMask = 0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    if (ok) {
+      int pr = k, pc = -1;
+      double best = 0;
+#pragma unroll
+      for (int i = k; i < 7; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const double a = fabs(A[i][j]);
+          const bool take = !((usedMask >> j) & 1u) && a > best;
+          best = take ? a : best; pr = take ? i : pr; pc = take ? j : pc;
+        }
+      if (pc < 0 || !(best > 0)) {
+        ok = false;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const double tmp = A[k][j];
+          double apr = tmp;
+#pragma unroll
+          for (int i = k + 1; i < 7; i++) apr = i == pr ? A[i][j] : apr;
+          A[k][j] = apr;
+#pragma unroll
+          for (int i = k + 1; i < 7; i++) A[i][j] = i == pr ? tmp : A[i][j];
+        }
+        usedMask |= 1u << pc; colOf[k] = pc;
+        double piv = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) piv = j == pc ? A[k][j] : piv;
+        const double inv = 1.0 / piv;
+#pragma unroll
+        for (int j = 0; j < 9; j++) A[k][j] *= inv;
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+          if (i != k) {
+            double fcoef = 0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) fcoef = j == pc ? A[i][j] : fcoef;
+            const bool nz = fcoef != 0.0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) A[i][j] = nz ? A[i][j] - fcoef * A[k][j] : A[i][j];
+          }
+      }
+    }
+  }
+  if (!ok) return;
+  int fa = -1, fb = -1;
+#pragma unroll
+  for (int j = 0; j < 9; j++) if (!((usedMask >> j) & 1u)) { if (fa < 0) fa = j; else fb = j; }
+  double f1[9], f2[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) { f1[j] = j == fa ? 1.0 : 0.0; f2[j] = j == fb ? 1.0 : 0.0; }
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    double aa = 0, ab = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { aa = j == fa ? A[k][j] : aa; ab = j == fb ? A[k][j] : ab; }
+#pragma unroll
+    for (int j = 0; j < 9; j++) { f1[j] = j == colOf[k] ? -aa : f1[j]; f2[j] = j == colOf[k] ? -ab : f2[j]; }
+  }
+  // unit length (the elimination's basis has entries of very different size; OpenCV's comes from an SVD), then run7Point
+  double n1 = 0, n2 = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) { n1 += f1[j] * f1[j]; n2 += f2[j] * f2[j]; }
+  n1 = 1.0 / sqrt(n1); n2 = 1.0 / sqrt(n2);
+#pragma unroll
+  for (int j = 0; j < 9; j++) { f1[j] *= n1; f2[j] *= n2; }
+#pragma unroll
+  for (int j = 0; j < 9; j++) f1[j] -= f2[j];
+  // det(lambda f1 + f2) = c0 lambda^3 + c1 lambda^2 + c2 lambda + c3
+  double c[4];
+  c[0] = det3rows(f1, f1 + 3, f1 + 6);
+  c[1] = det3rows(f2, f1 + 3, f1 + 6) + det3rows(f1, f2 + 3, f1 + 6) + det3rows(f1, f1 + 3, f2 + 6);
+  c[2] = det3rows(f1, f2 + 3, f2 + 6) + det3rows(f2, f1 + 3, f2 + 6) + det3rows(f2, f2 + 3, f1 + 6);
+  c[3] = det3rows(f2, f2 + 3, f2 + 6);
+  double r[3];
+  const int nr = cv_solve_cubic(c, r);
+  for (int k = 0; k < nr; k++) {
+    double lambda = r[k], mu = 1.0;
+    const double sden = f1[8] * r[k] + f2[8];
+    double F[9];
+    if (fabs(sden) > DBL_EPSILON) { mu = 1.0 / sden; lambda *= mu; F[8] = 1.0; } else F[8] = 0.0;
+    bool fin = true;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { F[j] = f1[j] * lambda + f2[j] * mu; fin = fin && isfinite(F[j]); }
+    if (!fin) continue;
+#pragma unroll
+    for (int j = 0; j < 9; j++) Fout[9 * (size_t)(3 * h + k) + j] = F[j];
+    valid[3 * h + k] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -764,9 +997,9 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
   const int ndw_in = (int)(inb / 4);
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   hipLaunchKernelGGL(k_f_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, H, d_F, d_valid);
-  hipLaunchKernelGGL(k_f_score, dim3(H, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_valid, threshold * threshold, d_counts);
+  hipLaunchKernelGGL(k_f_score, dim3(H, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_valid, threshold * threshold, d_counts, 0);
   hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H, d_probs, 8, confidence, 1, d_sel);
-  hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_sel, threshold * threshold, d_mask, d_Fb);
+  hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 0);
   uint8_t* hout = hio + inb;
   if (outb <= 65536) {   // small results leave through the export kernel + a polled sequence number (no copy command, no wake-up)
     const int seq = ++*counter;
@@ -784,6 +1017,92 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
     if (F9) memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
   }
   if (total) memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
+  return DVS_OK;
+}
+
+// cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): every problem needs >= 15 correspondences —
+// below that OpenCV switches to LMedS, which is not restated (DVS_ERR_UNSUPPORTED: the caller keeps dvs_find_fundamental_ransac)
+dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
+                                         double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
+  DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096);
+  if (nprob == 0) return DVS_OK;
+  DVS_ARG(offsets && offsets[0] == 0 && pts1 && pts2 && inlier_mask);
+  if (threshold <= 0) threshold = 3;                                                 // as cv::findFundamentalMat
+  if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  int maxn = 0;
+  for (int b = 0; b < nprob; b++) {
+    DVS_ARG(offsets[b + 1] >= offsets[b]);
+    const int n = offsets[b + 1] - offsets[b];
+    if (n < 15) { set_error("dvs_find_fundamental_cv: problem %d has %d correspondences (OpenCV runs LMedS below 15: not restated)", b, n); return DVS_ERR_UNSUPPORTED; }
+    maxn = std::max(maxn, n);
+  }
+  const int total = offsets[nprob];
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const int H = max_iters, H3 = 3 * H;
+  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, pb = ((size_t)total * 8 + 15) & ~(size_t)15;
+  const size_t sb = ((size_t)nprob * H * 7 * 4 + 15) & ~(size_t)15;
+  const size_t inb = hb + 2 * pb + sb;
+  const size_t fb = (size_t)nprob * H3 * 72, vb = (size_t)nprob * H3 * 4;
+  const size_t outb = ((size_t)nprob * (16 + 72) + (size_t)total + 3) & ~(size_t)3;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, inb + fb + 2 * vb + outb + 64, (void**)&base));
+  const RansacProb* d_probs = (const RansacProb*)base;
+  float* d_p1 = (float*)(base + hb); float* d_p2 = (float*)(base + hb + pb);
+  const int32_t* d_samples = (const int32_t*)(base + hb + 2 * pb);
+  double* d_F = (double*)(base + inb);
+  int* d_valid = (int*)(base + inb + fb); int* d_counts = (int*)(base + inb + fb + vb);
+  uint8_t* d_out = base + inb + fb + 2 * vb;
+  int* d_sel = (int*)d_out; double* d_Fb = (double*)(d_out + (size_t)nprob * 16); unsigned char* d_mask = d_out + (size_t)nprob * 88;
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
+  RansacProb* hp = (RansacProb*)hio;
+  memcpy(hio + hb, pts1, (size_t)total * 8); memcpy(hio + hb + pb, pts2, (size_t)total * 8);
+  int32_t* hs = (int32_t*)(hio + hb + 2 * pb);
+  memset(hs, 0, sb);
+  for (int b = 0; b < nprob; b++) {
+    const int n = offsets[b + 1] - offsets[b];
+    const int found = cv_subsets(pts1 + 2 * (size_t)offsets[b], pts2 + 2 * (size_t)offsets[b], n, 7, H, hs + (size_t)b * H * 7);
+    hp[b] = RansacProb{offsets[b], n, (unsigned long long)found};   // the seed field carries the iterations that have a sample
+  }
+  const int ndw_in = (int)(inb / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
+  hipLaunchKernelGGL(k_f7_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, d_samples, H, d_F, d_valid);
+  hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
+  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1);
+  hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
+  uint8_t* hout = hio + inb;
+  if (outb <= 65536) {
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, st));
+  } else {
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+  }
+  const int* sel = (const int*)hout;
+  for (int b = 0; b < nprob; b++) {
+    if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
+    if (iterations) iterations[b] = sel[4 * b + 1];
+    if (F9) memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
+  }
+  memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
+  return DVS_OK;
+}
+
+dvs_status dvs_find_fundamental_cv(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
+                                   int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
+  DVS_ARG(ctx && n >= 0);
+  const int32_t offsets[2] = {0, n};
+  return dvs_find_fundamental_cv_batch(ctx, 1, offsets, pts1, pts2, threshold, confidence, max_iters, F9, inlier_mask, n_inliers, iterations);
+}
+
+// host only (no GPU): the sample sequence of the call above — iteration it draws idx[7 it .. 7 it + 6]; *found = iterations that have one
+dvs_status dvs_cv_ransac_subsets(const float* pts1, const float* pts2, int32_t n, int32_t model_points, int32_t iterations, int32_t* idx, int32_t* found) {
+  DVS_ARG(pts1 && pts2 && idx && found && n >= model_points && model_points >= 1 && model_points <= 16 && iterations >= 0);
+  *found = cv_subsets(pts1, pts2, n, model_points, iterations, idx);
   return DVS_OK;
 }
 

@@ -120,6 +120,9 @@ def lib():
     L.dvs_comm_all_gather.argtypes = [vp, vp, vp, vp, sz]
     L.dvs_find_fundamental_ransac.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, C.c_uint64, vp, vp, C.POINTER(i32)]
     L.dvs_solve_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_uint64, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.dvs_find_fundamental_cv.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.dvs_find_fundamental_cv_batch.argtypes = [vp, i32, vp, vp, vp, dbl, dbl, i32, vp, vp, vp, vp]
+    L.dvs_cv_ransac_subsets.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
     L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
     L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int

@@ -30,6 +30,25 @@ class FrontendGlue:
                                                   C.byref(n)))
         return F.reshape(3, 3), mask[:len(p1)], n.value
 
+    def find_fundamental_cv(self, pts1, pts2, threshold=2.0, confidence=0.99, max_iters=1000):
+        """cv::findFundamentalMat(FM_RANSAC) with OpenCV's own sample sequence and 7-point solver (>= 15 points)
+        -> (F 3x3, mask uint8[n], inliers of the model, iterations run)"""
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); n = C.c_int32(); it = C.c_int32()
+        check(self._L.dvs_find_fundamental_cv(self._h, ptr(p1), ptr(p2), len(p1), threshold, confidence, max_iters, ptr(F), ptr(mask), C.byref(n), C.byref(it)))
+        return F.reshape(3, 3), mask[:len(p1)], n.value, it.value
+
+    def find_fundamental_cv_batch(self, pts1_list, pts2_list, threshold=2.0, confidence=0.99, max_iters=1000):
+        """-> list of (mask uint8[n_b], inliers of the model, iterations run)"""
+        nprob = len(pts1_list)
+        off = np.zeros(nprob + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in pts1_list])
+        cat = lambda ps: np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in ps]), np.float32)
+        p1, p2 = cat(pts1_list), cat(pts2_list)
+        mask = np.zeros(max(int(off[-1]), 1), np.uint8); nin = np.zeros(nprob, np.int32); its = np.zeros(nprob, np.int32)
+        check(self._L.dvs_find_fundamental_cv_batch(self._h, nprob, ptr(off), ptr(p1), ptr(p2), threshold, confidence, max_iters, None, ptr(mask), ptr(nin), ptr(its)))
+        return [(mask[off[b]:off[b + 1]].copy(), int(nin[b]), int(its[b])) for b in range(nprob)]
+
     def solve_pnp_ransac(self, pts3d, pts2d, K4, iterations=100, reproj_err=4.0, confidence=0.99, seed=1):
         """cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations, reproj_err, confidence, inliers)
         -> (success, rvec, tvec, inlier indices)"""
@@ -172,3 +191,11 @@ def unpack_keyframe(payload, cap_n=4096):
                 translation=np.array(hdr.translation[:]), rotation_xyzw=np.array(hdr.rotation_xyzw[:]),
                 landmark_ids=lid[:nl.value], landmark_xyz=xyz[:nl.value], obs_landmark_ids=oid[:no.value], obs_pixels=px[:no.value],
                 obs_desc=desc[:no.value])
+
+
+def cv_ransac_subsets(pts1, pts2, model_points, iterations):
+    """host only: the sample sequence cv::findFundamentalMat's RANSAC draws (dvs_cv_ransac_subsets) -> (idx[found][model_points], found)"""
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    idx = np.zeros((max(iterations, 1), model_points), np.int32); found = C.c_int32()
+    check(lib().dvs_cv_ransac_subsets(ptr(p1), ptr(p2), len(p1), model_points, iterations, ptr(idx), C.byref(found)))
+    return idx[:found.value], found.value

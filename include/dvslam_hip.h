@@ -307,8 +307,8 @@ dvs_status dvs_keyframe_unpack_cdr(const uint8_t* buf, size_t len, dvs_keyframe_
                                    uint64_t* landmark_ids, double* landmark_xyz, uint64_t* obs_landmark_ids, double* obs_pixels,
                                    uint8_t* obs_desc, int32_t cap_n, int32_t* n_landmarks, int32_t* n_observations);
 /* ---- the frontend's robust-estimation stages, as batched-hypothesis kernels ---------------------------
- * OpenCV's RANSAC draws its samples from a cv::RNG whose state cannot be restated, so these are NOT bit-compatible with
- * cv::findFundamentalMat / cv::solvePnPRansac; they implement the same estimator (threshold, confidence, iteration cap, the
+ * Two forms.  dvs_find_fundamental_ransac / dvs_solve_pnp_ransac: the library's own minimal solvers (8-point, P3P) over a documented
+ * deterministic sampler — NOT OpenCV's sample sequence or kernels (7-point, EPnP); they implement the same estimator (threshold, confidence, iteration cap, the
  * adaptive stopping rule RANSACUpdateNumIters, error measures) over a documented deterministic sampler (`seed`; csrc/ransac.hip),
  * and parity is stated as a tolerance on the inlier set and the pose.  Host pointers.
  *
@@ -324,6 +324,22 @@ dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, cons
 dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets /* nprob + 1, offsets[0] = 0 */, const float* pts1,
                                              const float* pts2, double threshold, double confidence, int32_t max_iters, const uint64_t* seeds,
                                              double* F9 /* nprob x 9 or NULL */, uint8_t* inlier_mask /* offsets[nprob] */, int32_t* n_inliers /* nprob or NULL */);
+/* cv::findFundamentalMat(pts1, pts2, mask, cv::FM_RANSAC, threshold, confidence) (frontend.cpp:635, 1146-1147) the way OpenCV 4.x
+ * itself runs it for >= 15 correspondences, restated from the published algorithm (calib3d fundam.cpp / ptsetreg.cpp; csrc/ransac.hip
+ * k_f7_hypotheses): the sample sequence of RANSACPointSetRegistrator — ONE cv::RNG seeded with (uint64)-1, index = next() % n, drawn
+ * again while it repeats, whole samples drawn again while their last point is collinear with two earlier ones — the 7-point solver
+ * (two null vectors, cv::solveCubic, one model per real root, F(3,3) = 1), errors and threshold compared as floats, the adaptive
+ * stopping rule, no refit.  F9 row-major with F[8] = 1 (0 where OpenCV sets it so), may be NULL; *iterations (may be NULL) = loop
+ * iterations run.  OpenCV's maxIters default is 1000.  n < 15 (OpenCV switches to LMedS there): DVS_ERR_UNSUPPORTED.  PARITY
+ * UNPINNED like everything else (no OpenCV in this image); what cannot agree even in principle is a tie between two models of ONE
+ * sample, whose order follows the null-space basis (OpenCV: SVD). */
+dvs_status dvs_find_fundamental_cv(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
+                                   int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations);
+dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
+                                         double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations);
+/* host only (works without a GPU): the sample sequence of the call above — iteration i drew idx[model_points i ..]; *found =
+ * iterations that have a sample (cv::RNG((uint64)-1), uniform(0, n) = next() % n, repeats and collinear samples drawn again) */
+dvs_status dvs_cv_ransac_subsets(const float* pts1, const float* pts2, int32_t n, int32_t model_points, int32_t iterations, int32_t* idx, int32_t* found);
 /* cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations = 100, reproj_err = 4.0, confidence = 0.99, inliers)
  * (frontend.cpp:911-921; zero distortion): obj n x 3 float (camera frame of the previous image), img n x 2 float,
  * K4 = {fx, fy, cx, cy}.  P3P hypotheses, best by inlier count, Levenberg-Marquardt refinement on the inliers (the

@@ -174,6 +174,144 @@ int quarticRealRoots(double a4, double a3, double a2, double a1, double a0, doub
   return nr;
 }
 
+// ---- cv::findFundamentalMat(FM_RANSAC) as OpenCV 4.x runs it for >= 15 points (the checker of dvs_find_fundamental_cv) ----------------
+// The integer part — cv::RNG (multiply-with-carry, state = (uint32)state * 4164903690 + (state >> 32)), RANSACPointSetRegistrator::
+// getSubset (index = next() % n, drawn again while it repeats; a sample whose last point is collinear with two earlier ones in either
+// image is drawn again as a whole, FMEstimatorCallback::checkSubset) — is stated once more here and checked against a third statement
+// in Python (tests/test_ransac.py).  The 7-point models are NOT computed the product's way: Hartley-normalised coordinates, null space
+// from the Jacobi eigen-decomposition of A^T A, the cubic by Durand-Kerner, models mapped back by F = T2^T Fn T1 (the solution set of
+// the 7-point problem is covariant under the normalising transforms).
+struct CvRng {
+  uint64_t state;
+  explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffull) {}
+  unsigned next() { state = (uint64_t)(unsigned)state * 4164903690ull + (unsigned)(state >> 32); return (unsigned)state; }
+  int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+bool cvHaveCollinear(const float* pts, const int* idx, int count) {
+  const int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = pts[2 * idx[j]] - pts[2 * idx[i]], dy1 = pts[2 * idx[j] + 1] - pts[2 * idx[i] + 1];
+    for (int k = 0; k < j; k++) {
+      const double dx2 = pts[2 * idx[k]] - pts[2 * idx[i]], dy2 = pts[2 * idx[k] + 1] - pts[2 * idx[i] + 1];
+      if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+
+bool cvGetSubset(CvRng& rng, const float* p1, const float* p2, int n, int modelPoints, int* idx) {
+  for (int attempt = 0; attempt < 10000; attempt++) {
+    for (int i = 0; i < modelPoints; i++) {
+      int v;
+      for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {}
+      idx[i] = v;
+    }
+    if (!cvHaveCollinear(p1, idx, modelPoints) && !cvHaveCollinear(p2, idx, modelPoints)) return true;
+  }
+  return false;
+}
+
+int cubicRealRoots(double a3, double a2, double a1, double a0, double* roots) {   // Durand-Kerner, real roots polished by Newton steps
+  const double sc = std::fabs(a3) + std::fabs(a2) + std::fabs(a1) + std::fabs(a0);
+  if (!(sc > 0)) return 0;
+  if (!(std::fabs(a3) > 1e-14 * sc)) {   // (numerically) a quadratic
+    if (!(std::fabs(a2) > 1e-14 * sc)) { if (!(std::fabs(a1) > 1e-14 * sc)) return 0; roots[0] = -a0 / a1; return 1; }
+    const double d = a1 * a1 - 4 * a2 * a0;
+    if (d < 0) return 0;
+    const double q = -0.5 * (a1 + (a1 >= 0 ? 1.0 : -1.0) * std::sqrt(d));
+    roots[0] = q / a2; roots[1] = q != 0 ? a0 / q : roots[0];
+    return d > 0 ? 2 : 1;
+  }
+  typedef std::complex<double> cd;
+  const cd c[3] = {a2 / a3, a1 / a3, a0 / a3};
+  auto P = [&](cd x) { return ((x + c[0]) * x + c[1]) * x + c[2]; };
+  const double rad = 1.0 + std::max(std::abs(c[0]), std::max(std::abs(c[1]), std::abs(c[2])));
+  cd z[3];
+  for (int k = 0; k < 3; k++) z[k] = std::polar(rad * 0.7, 0.4 + 2.0 * M_PI * k / 3.0);
+  for (int it = 0; it < 800; it++) {
+    double move = 0;
+    for (int k = 0; k < 3; k++) {
+      cd den = 1.0;
+      for (int j = 0; j < 3; j++) if (j != k) den *= (z[k] - z[j]);
+      if (std::abs(den) < 1e-300) den = 1e-300;
+      const cd dz = P(z[k]) / den;
+      z[k] -= dz;
+      move = std::max(move, std::abs(dz));
+    }
+    if (move < 1e-15 * rad) break;
+  }
+  int nr = 0;
+  for (int k = 0; k < 3; k++)
+    if (std::fabs(z[k].imag()) <= 1e-7 * std::max(1.0, std::fabs(z[k].real()))) {
+      double x = z[k].real();
+      for (int it = 0; it < 3; it++) {
+        const double fx = ((a3 * x + a2) * x + a1) * x + a0, dfx = (3 * a3 * x + 2 * a2) * x + a1;
+        if (dfx == 0) break;
+        x -= fx / dfx;
+      }
+      roots[nr++] = x;
+    }
+  std::sort(roots, roots + nr);
+  return nr;
+}
+
+double det3(const double* a, const double* b, const double* c) {
+  return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+}
+
+// the models of one 7-point sample (F[8] = 1 where that is possible, as OpenCV scales them); returns how many
+int sevenPoint(const float* p1, const float* p2, const int* idx, double F[3][9]) {
+  double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+  for (int i = 0; i < 7; i++) { c1x += p1[2 * idx[i]]; c1y += p1[2 * idx[i] + 1]; c2x += p2[2 * idx[i]]; c2y += p2[2 * idx[i] + 1]; }
+  c1x /= 7; c1y /= 7; c2x /= 7; c2y /= 7;
+  double d1 = 0, d2 = 0;
+  for (int i = 0; i < 7; i++) { d1 += std::hypot(p1[2 * idx[i]] - c1x, p1[2 * idx[i] + 1] - c1y); d2 += std::hypot(p2[2 * idx[i]] - c2x, p2[2 * idx[i] + 1] - c2y); }
+  if (!(d1 > 1e-9) || !(d2 > 1e-9)) return 0;
+  const double s1 = std::sqrt(2.0) * 7 / d1, s2 = std::sqrt(2.0) * 7 / d2;
+  std::vector<double> M(81, 0.0), V;
+  for (int i = 0; i < 7; i++) {
+    const double u1 = (p1[2 * idx[i]] - c1x) * s1, v1 = (p1[2 * idx[i] + 1] - c1y) * s1, u2 = (p2[2 * idx[i]] - c2x) * s2, v2 = (p2[2 * idx[i] + 1] - c2y) * s2;
+    const double r[9] = {u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1.0};
+    for (int a = 0; a < 9; a++) for (int b = 0; b < 9; b++) M[9 * a + b] += r[a] * r[b];
+  }
+  jacobiEigen(M, 9, V);
+  int o[9];
+  for (int k = 0; k < 9; k++) o[k] = k;
+  std::sort(o, o + 9, [&](int a, int b) { return M[10 * a] < M[10 * b]; });
+  double f1[9], f2[9];
+  for (int k = 0; k < 9; k++) { f1[k] = V[9 * k + o[0]]; f2[k] = V[9 * k + o[1]]; }
+  // det(x f1 + (1 - x) f2) = 0 with g = f1 - f2: det(x g + f2)
+  double g[9];
+  for (int k = 0; k < 9; k++) g[k] = f1[k] - f2[k];
+  const double c3 = det3(g, g + 3, g + 6);
+  const double c2 = det3(f2, g + 3, g + 6) + det3(g, f2 + 3, g + 6) + det3(g, g + 3, f2 + 6);
+  const double c1 = det3(g, f2 + 3, f2 + 6) + det3(f2, g + 3, f2 + 6) + det3(f2, f2 + 3, g + 6);
+  const double c0 = det3(f2, f2 + 3, f2 + 6);
+  double roots[3];
+  const int nr = cubicRealRoots(c3, c2, c1, c0, roots);
+  int nm = 0;
+  for (int r = 0; r < nr; r++) {
+    double Fn[9], G[9], Fo[9];
+    for (int k = 0; k < 9; k++) Fn[k] = roots[r] * g[k] + f2[k];
+    for (int a = 0; a < 3; a++) {   // Fn T1
+      G[3 * a] = Fn[3 * a] * s1; G[3 * a + 1] = Fn[3 * a + 1] * s1;
+      G[3 * a + 2] = Fn[3 * a + 2] - s1 * (Fn[3 * a] * c1x + Fn[3 * a + 1] * c1y);
+    }
+    for (int b = 0; b < 3; b++) {   // T2^T (.)
+      Fo[b] = s2 * G[b]; Fo[3 + b] = s2 * G[3 + b];
+      Fo[6 + b] = G[6 + b] - s2 * (c2x * G[b] + c2y * G[3 + b]);
+    }
+    double nrm = 0;
+    for (int k = 0; k < 9; k++) nrm += Fo[k] * Fo[k];
+    if (!(nrm > 0) || !std::isfinite(nrm)) continue;
+    const double sc = std::fabs(Fo[8]) > 1e-14 * std::sqrt(nrm) ? 1.0 / Fo[8] : 1.0 / std::sqrt(nrm);
+    for (int k = 0; k < 9; k++) F[nm][k] = Fo[k] * sc;
+    nm++;
+  }
+  return nm;
+}
+
 struct Pose { double R[9], t[3]; };
 
 bool triad(const double* A0, const double* A1, const double* A2, double E[9]) {
@@ -319,6 +457,53 @@ void orc_find_fundamental_ransac(const float* p1, const float* p2, int n, double
   if (best < 0) return;
   memcpy(F9, Fb, sizeof(Fb));
   for (int i = 0; i < n; i++) mask[i] = epiErr(Fb, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr2 ? 1 : 0;
+}
+
+// cv::RNG / getSubset as the product's dvs_cv_ransac_subsets states them (same outputs expected, index for index)
+uint32_t orc_cv_rng_next(uint64_t* state) { CvRng r(*state); const uint32_t v = r.next(); *state = r.state; return v; }
+int orc_cv_subsets(const float* p1, const float* p2, int n, int modelPoints, int iters, int* idx) {
+  CvRng rng(~0ull);
+  for (int it = 0; it < iters; it++)
+    if (!cvGetSubset(rng, p1, p2, n, modelPoints, idx + (size_t)it * modelPoints)) return it;
+  return iters;
+}
+int orc_seven_point(const float* p1, const float* p2, const int* idx7, double* F27) {
+  double F[3][9];
+  const int n = sevenPoint(p1, p2, idx7, F);
+  memcpy(F27, F, sizeof(F));
+  return n;
+}
+
+// sel3: iteration of the best model, iterations run, inliers of the best model
+void orc_find_fundamental_cv(const float* p1, const float* p2, int n, double threshold, double confidence, int maxIters, double* F9, uint8_t* mask, int* sel3) {
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  for (int k = 0; k < 9; k++) F9[k] = 0;
+  sel3[0] = -1; sel3[1] = 0; sel3[2] = 0;
+  if (n < 15) return;
+  if (threshold <= 0) threshold = 3;
+  if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  const float t = (float)(threshold * threshold);
+  CvRng rng(~0ull);
+  int niters = maxIters, best = -1, bestCount = 0, it = 0;
+  double Fb[9] = {0};
+  for (; it < niters; it++) {
+    int idx[7];
+    if (!cvGetSubset(rng, p1, p2, n, 7, idx)) break;
+    double F[3][9];
+    const int nm = sevenPoint(p1, p2, idx, F);
+    for (int m = 0; m < nm; m++) {
+      int good = 0;
+      for (int i = 0; i < n; i++) good += (float)epiErr(F[m], p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t ? 1 : 0;
+      if (good > std::max(bestCount, 6)) {
+        bestCount = good; best = it; memcpy(Fb, F[m], sizeof(Fb));
+        niters = updateNumIters(confidence, (double)(n - good) / n, 7, niters);
+      }
+    }
+  }
+  sel3[0] = best; sel3[1] = it; sel3[2] = bestCount;
+  if (best < 0) return;
+  memcpy(F9, Fb, sizeof(Fb));
+  for (int i = 0; i < n; i++) mask[i] = (float)epiErr(Fb, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t ? 1 : 0;
 }
 
 // returns success; sel3 as above with the hypothesis index = 4 * iteration + solution

@@ -392,6 +392,10 @@ def _ransac_lib():
     L.orc_p3p.restype = i32; L.orc_p3p.argtypes = [vp, vp, vp]
     L.orc_eight_point.restype = i32; L.orc_eight_point.argtypes = [vp, vp, i32, vp]
     L.orc_find_fundamental_ransac.argtypes = [vp, vp, i32, dbl, dbl, i32, u64, vp, vp, vp]
+    L.orc_cv_rng_next.restype = C.c_uint32; L.orc_cv_rng_next.argtypes = [C.POINTER(u64)]
+    L.orc_cv_subsets.restype = i32; L.orc_cv_subsets.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.orc_seven_point.restype = i32; L.orc_seven_point.argtypes = [vp, vp, vp, vp]
+    L.orc_find_fundamental_cv.argtypes = [vp, vp, i32, dbl, dbl, i32, vp, vp, vp]
     L.orc_solve_pnp_ransac.restype = i32
     L.orc_solve_pnp_ransac.argtypes = [vp, vp, i32, vp, i32, dbl, dbl, u64, vp, vp, vp, vp, vp]
     return L
@@ -426,6 +430,33 @@ def find_fundamental_ransac(p1, p2, threshold=2.0, confidence=0.99, max_iters=10
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
     F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); sel = np.zeros(3, np.int32)
     _ransac_lib().orc_find_fundamental_ransac(_p(p1), _p(p2), len(p1), threshold, confidence, max_iters, seed, _p(F), _p(mask), _p(sel))
+    return F.reshape(3, 3), mask[:len(p1)], sel
+
+
+def cv_rng_sequence(state, count):
+    """cv::RNG(state).next() x count"""
+    st = C.c_uint64(state)
+    return [int(_ransac_lib().orc_cv_rng_next(C.byref(st))) for _ in range(count)]
+
+
+def cv_subsets(p1, p2, model_points, iterations):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    idx = np.zeros((max(iterations, 1), model_points), np.int32)
+    found = _ransac_lib().orc_cv_subsets(_p(p1), _p(p2), len(p1), model_points, iterations, _p(idx))
+    return idx[:found], found
+
+
+def seven_point(p1, p2, idx7):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    F = np.zeros((3, 9)); idx = np.ascontiguousarray(idx7, np.int32)
+    n = _ransac_lib().orc_seven_point(_p(p1), _p(p2), _p(idx), _p(F))
+    return [F[k].reshape(3, 3).copy() for k in range(n)]
+
+
+def find_fundamental_cv(p1, p2, threshold=2.0, confidence=0.99, max_iters=1000):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); sel = np.zeros(3, np.int32)
+    _ransac_lib().orc_find_fundamental_cv(_p(p1), _p(p2), len(p1), threshold, confidence, max_iters, _p(F), _p(mask), _p(sel))
     return F.reshape(3, 3), mask[:len(p1)], sel
 
 

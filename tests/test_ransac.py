@@ -1,9 +1,11 @@
 """The frontend's robust-estimation stages: cv::findFundamentalMat(FM_RANSAC, 2.0, 0.99) and
 cv::solvePnPRansac(100, 4.0, 0.99) as frontend.cpp:635, 911-921, 1146-1147 call them.
 
-OpenCV's cv::RNG sample sequence is not restatable, so parity is NOT bit equality with OpenCV: tolerances are stated per
-assertion as inlier-set IoU / pose error (a) against synthetic ground truth, for the CPU oracle and the HIP path alike, and (b)
-between the HIP path and the oracle, which share the documented sampler but not their numerical routines."""
+Two forms.  The library's own estimators (8-point / P3P over a documented sampler): tolerances are stated per assertion as inlier-set
+IoU / pose error (a) against synthetic ground truth, for the CPU oracle and the HIP path alike, and (b) between the HIP path and the
+oracle, which share the sampler but not their numerical routines.  And cv::findFundamentalMat as OpenCV 4.x itself runs it
+(dvs_find_fundamental_cv: cv::RNG sample sequence, 7-point solver; at the end of this file) — restated from the published algorithm,
+unpinned like everything else here (no OpenCV in the image)."""
 import numpy as np
 import pytest
 import ransac_scenes as rs
@@ -209,3 +211,137 @@ def test_gpu_ransac_batches_equal_the_single_calls(gpu):
     big = g.find_fundamental_ransac_batch([p1[0]] * 200, [p2[0]] * 200, list(range(200)), 2.0, 0.99, 1000)   # results leave by a copy command
     F, mask, nin = g.find_fundamental_ransac(p1[0], p2[0], 2.0, 0.99, 1000, seed=137)
     assert (big[137][0] == mask).all() and big[137][1] == nin
+
+
+# ---------------------------------------------------------------- cv::findFundamentalMat as OpenCV itself runs it (dvs_find_fundamental_cv)
+def _py_cv_rng(state):
+    """cv::RNG::next() — a third statement (Python integers) of the multiply-with-carry generator"""
+    state = state if state else 0xffffffff
+    while True:
+        state = ((state & 0xffffffff) * 4164903690 + (state >> 32)) & 0xffffffffffffffff
+        yield state & 0xffffffff
+
+
+def _py_cv_subsets(p1, p2, k, iters):
+    """RANSACPointSetRegistrator::getSubset over `iters` iterations, third statement (Python, float64 arithmetic on the float32 points)"""
+    n = len(p1)
+    rng = _py_cv_rng(0xffffffffffffffff)
+    eps = float(np.finfo(np.float32).eps)
+
+    def collinear(p, idx):
+        i = len(idx) - 1
+        for j in range(i):
+            dx1 = float(p[idx[j], 0]) - float(p[idx[i], 0]); dy1 = float(p[idx[j], 1]) - float(p[idx[i], 1])
+            for m in range(j):
+                dx2 = float(p[idx[m], 0]) - float(p[idx[i], 0]); dy2 = float(p[idx[m], 1]) - float(p[idx[i], 1])
+                if abs(dx2 * dy1 - dy2 * dx1) <= eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                    return True
+        return False
+    out = []
+    for _ in range(iters):
+        for attempt in range(10000):
+            idx = []
+            for i in range(k):
+                v = next(rng) % n
+                while v in idx:
+                    v = next(rng) % n
+                idx.append(v)
+            if not collinear(p1, idx) and not collinear(p2, idx):
+                break
+        else:
+            return out
+        out.append(idx)
+    return out
+
+
+def test_cv_rng_and_subsets_three_statements(hiplib, oracle):
+    """cv::RNG and getSubset: the product's host routine (dvs_cv_ransac_subsets), the oracle's and a Python statement give the same
+    sequence — on integer pixel coordinates (ORB keypoints of level 0), where collinear samples DO occur and are drawn again"""
+    from dvslam_amd import glue
+    g = _py_cv_rng(0xffffffffffffffff)
+    assert oracle.cv_rng_sequence(0xffffffffffffffff, 50) == [next(g) for _ in range(50)]
+    g = _py_cv_rng(0)
+    assert oracle.cv_rng_sequence(0, 5) == [next(g) for _ in range(5)]                      # state 0 -> 0xffffffff (cv::RNG's constructor)
+    rng = np.random.Generator(np.random.PCG64(9))
+    for n, k, iters in ((40, 7, 60), (300, 7, 200), (16, 7, 50), (500, 5, 100)):
+        p1 = rng.integers(0, 48, (n, 2)).astype(np.float32)                                # a small integer grid: many collinear triples
+        p2 = p1 + rng.integers(-2, 3, (n, 2)).astype(np.float32)
+        want = _py_cv_subsets(p1, p2, k, iters)
+        a, fa = glue.cv_ransac_subsets(p1, p2, k, iters)
+        b, fb = oracle.cv_subsets(p1, p2, k, iters)
+        assert fa == fb == len(want) == iters
+        assert a.tolist() == want and b.tolist() == want
+        assert all(len(set(r)) == k for r in want)
+    # without the collinearity redraw the sequence would differ: the test above is not vacuous
+    p1 = rng.integers(0, 48, (40, 2)).astype(np.float32); p2 = p1.copy()
+    plain = []
+    g = _py_cv_rng(0xffffffffffffffff)
+    for _ in range(60):
+        idx = []
+        for i in range(7):
+            v = next(g) % 40
+            while v in idx:
+                v = next(g) % 40
+            idx.append(v)
+        plain.append(idx)
+    assert plain != _py_cv_subsets(p1, p2, 7, 60)
+
+
+def test_oracle_seven_point_on_exact_correspondences(oracle):
+    """the 7-point models of exact correspondences: one of them is the true epipolar geometry, all are singular"""
+    sc = rs.two_view(n=40, outlier_frac=0.0, noise=0.0, seed=4)
+    rng = np.random.Generator(np.random.PCG64(2))
+    for _ in range(20):
+        idx = rng.choice(40, 7, replace=False)
+        Fs = oracle.seven_point(sc["pts1"], sc["pts2"], idx)
+        assert 1 <= len(Fs) <= 3
+        assert min(rs.sampson_truth_error(F, sc) for F in Fs) < 2e-2
+        for F in Fs:
+            assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9
+
+
+@pytest.mark.parametrize("seed,outliers", [(0, 0.3), (1, 0.5), (2, 0.1)])
+def test_oracle_fundamental_cv_against_ground_truth(oracle, seed, outliers):
+    sc = rs.two_view(n=600, outlier_frac=outliers, noise=0.5, seed=seed)
+    F, mask, sel = oracle.find_fundamental_cv(sc["pts1"], sc["pts2"], 2.0, 0.99, 1000)
+    assert sel[0] >= 0 and sel[1] <= 1000 and mask.sum() == sel[2]
+    recall = (mask.astype(bool) & sc["truth"]).sum() / sc["truth"].sum()
+    false_in = (mask.astype(bool) & ~sc["truth"]).sum() / max((~sc["truth"]).sum(), 1)
+    assert recall > (0.8 if outliers <= 0.3 else 0.65) and false_in < 0.1, (recall, false_in)   # a 7-point minimal model, no refit
+    assert sel[1] < 1000 or outliers >= 0.5
+    F2, mask2, sel2 = oracle.find_fundamental_cv(sc["pts1"][:14], sc["pts2"][:14])              # OpenCV runs LMedS below 15 points: not restated
+    assert sel2[0] == -1 and mask2.sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,outliers", [(600, 0, 0.3), (2000, 1, 0.5), (60, 2, 0.1), (15, 3, 0.0)])
+def test_gpu_fundamental_cv(gpu, oracle, n, seed, outliers):
+    """dvs_find_fundamental_cv against the oracle's statement of the same OpenCV algorithm: the same samples (integer arithmetic), the
+    same loop — iterations run, inliers of the best model and the inlier mask agree; the models come from different numerical routines
+    (elimination on raw coordinates / eigen-decomposition on normalised ones), so a correspondence within rounding of the threshold
+    may flip (IoU bar 0.99) and F agrees to 1e-6 relative when the masks are identical"""
+    from dvslam_amd import FrontendGlue
+    sc = rs.two_view(n=n, outlier_frac=outliers, noise=0.5, seed=seed)
+    if seed == 2:
+        sc["pts1"] = np.round(sc["pts1"]); sc["pts2"] = np.round(sc["pts2"])                # integer pixel coordinates (level-0 keypoints)
+    g = FrontendGlue()
+    F, mask, nin, its = g.find_fundamental_cv(sc["pts1"], sc["pts2"], 2.0, 0.99, 1000)
+    F2, mask2, sel = oracle.find_fundamental_cv(sc["pts1"], sc["pts2"], 2.0, 0.99, 1000)
+    assert nin == mask.sum() and sel[0] >= 0
+    assert rs.iou(mask, mask2) > 0.99, (mask.sum(), mask2.sum())
+    if (mask == mask2).all():
+        assert its == sel[1] and nin == sel[2]
+        assert np.abs(F / np.linalg.norm(F) - F2 / np.linalg.norm(F2)).max() < 1e-6 or np.abs(F / np.linalg.norm(F) + F2 / np.linalg.norm(F2)).max() < 1e-6
+    assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9 and (F[2, 2] == 1.0 or F[2, 2] == 0.0)
+    if n >= 60:
+        recall = (mask.astype(bool) & sc["truth"]).sum() / sc["truth"].sum()
+        assert recall > (0.8 if outliers <= 0.3 else 0.65)
+    F3, mask3, nin3, its3 = g.find_fundamental_cv(sc["pts1"], sc["pts2"], 2.0, 0.99, 1000)
+    assert (mask3 == mask).all() and (F3 == F).all() and its3 == its
+    # batch = single, and fewer than 15 points are refused (OpenCV would run LMedS)
+    fb = g.find_fundamental_cv_batch([sc["pts1"], sc["pts1"][: max(15, n // 2)]], [sc["pts2"], sc["pts2"][: max(15, n // 2)]])
+    assert (fb[0][0] == mask).all() and fb[0][1] == nin and fb[0][2] == its
+    Fh, mh, nh, ih = g.find_fundamental_cv(sc["pts1"][: max(15, n // 2)], sc["pts2"][: max(15, n // 2)])
+    assert (fb[1][0] == mh).all() and fb[1][1] == nh
+    with pytest.raises(Exception):
+        g.find_fundamental_cv(sc["pts1"][:14], sc["pts2"][:14])
