@@ -271,14 +271,17 @@ __device__ __forceinline__ int ransac_update_iters(double p, double ep, int mode
 // the sequential RANSAC loop replayed over the hypothesis counts (RANSACPointSetRegistrator::run): hypothesis h is iteration h,
 // a strictly better count replaces the best and shortens the loop.  sel[0] = best hypothesis (-1: none), sel[1] = iterations used.
 __global__ void k_ransac_select(const int* __restrict__ counts, int H, const RansacProb* __restrict__ probs, int modelPoints, double confidence, int group,
-                                int* __restrict__ sel, int capInSeed = 0) {
+                                int* __restrict__ sel, int capInSeed = 0, int maxItersTrue = 0) {
   if (threadIdx.x != 0) return;
   const int n = probs[blockIdx.x].n;
   counts += (size_t)H * blockIdx.x; sel += 4 * (size_t)blockIdx.x;
-  int niters = H / group, best = -1, bestCount = 0, it = 0;
+  // cv mode: only the first H / group iterations of a loop of up to maxItersTrue have their models here (the loop usually stops long
+  // before); the seed field carries how many iterations getSubset found a sample for.  sel[3] = 1: the loop wanted to go on past them
+  const int avail = H / group;
+  int niters = maxItersTrue > 0 ? maxItersTrue : avail, best = -1, bestCount = 0, it = 0;
   const int maxIters = niters;
-  if (capInSeed) niters = min(niters, (int)probs[blockIdx.x].seed);   // cv mode: the iterations getSubset found a sample for
-  for (; it < niters; it++) {
+  const int found = capInSeed ? (int)probs[blockIdx.x].seed : avail;
+  for (; it < niters && it < avail && it < found; it++) {
     for (int s = 0; s < group; s++) {   // `group` candidate models per iteration (P3P: up to 4 poses per sample), in order
       const int h = it * group + s;
       const int good = counts[h];
@@ -289,6 +292,7 @@ __global__ void k_ransac_select(const int* __restrict__ counts, int H, const Ran
     }
   }
   sel[0] = best; sel[1] = it; sel[2] = bestCount;
+  sel[3] = it < niters && it >= avail && found >= avail ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_f_mask(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
@@ -1022,24 +1026,14 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
 
 // cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): every problem needs >= 15 correspondences —
 // below that OpenCV switches to LMedS, which is not restated (DVS_ERR_UNSUPPORTED: the caller keeps dvs_find_fundamental_ransac)
-dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
-                                         double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
-  DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096);
-  if (nprob == 0) return DVS_OK;
-  DVS_ARG(offsets && offsets[0] == 0 && pts1 && pts2 && inlier_mask);
-  if (threshold <= 0) threshold = 3;                                                 // as cv::findFundamentalMat
-  if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+// one pass over `nprob` problems with the models of the first H iterations; unfinished[b] = 1 where the loop wanted more than H
+static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold, double confidence,
+                             int32_t max_iters, int32_t H, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations, uint8_t* unfinished) {
   int maxn = 0;
-  for (int b = 0; b < nprob; b++) {
-    DVS_ARG(offsets[b + 1] >= offsets[b]);
-    const int n = offsets[b + 1] - offsets[b];
-    if (n < 15) { set_error("dvs_find_fundamental_cv: problem %d has %d correspondences (OpenCV runs LMedS below 15: not restated)", b, n); return DVS_ERR_UNSUPPORTED; }
-    maxn = std::max(maxn, n);
-  }
+  for (int b = 0; b < nprob; b++) maxn = std::max(maxn, offsets[b + 1] - offsets[b]);
   const int total = offsets[nprob];
-  DVS_HIP(hipSetDevice(matcher_device(ctx)));
   hipStream_t st = matcher_stream(ctx);
-  const int H = max_iters, H3 = 3 * H;
+  const int H3 = 3 * H;
   const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, pb = ((size_t)total * 8 + 15) & ~(size_t)15;
   const size_t sb = ((size_t)nprob * H * 7 * 4 + 15) & ~(size_t)15;
   const size_t inb = hb + 2 * pb + sb;
@@ -1069,7 +1063,7 @@ dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const 
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   hipLaunchKernelGGL(k_f7_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, d_samples, H, d_F, d_valid);
   hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
-  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1);
+  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1, max_iters);
   hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
   uint8_t* hout = hio + inb;
   if (outb <= 65536) {
@@ -1086,9 +1080,55 @@ dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const 
   for (int b = 0; b < nprob; b++) {
     if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
     if (iterations) iterations[b] = sel[4 * b + 1];
+    unfinished[b] = (uint8_t)sel[4 * b + 3];
     if (F9) memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
   }
   memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
+  return DVS_OK;
+}
+
+dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
+                                         double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
+  DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096);
+  if (nprob == 0) return DVS_OK;
+  DVS_ARG(offsets && offsets[0] == 0 && pts1 && pts2 && inlier_mask);
+  if (threshold <= 0) threshold = 3;                                                 // as cv::findFundamentalMat
+  if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  for (int b = 0; b < nprob; b++) {
+    DVS_ARG(offsets[b + 1] >= offsets[b]);
+    const int n = offsets[b + 1] - offsets[b];
+    if (n < 15) { set_error("dvs_find_fundamental_cv: problem %d has %d correspondences (OpenCV runs LMedS below 15: not restated)", b, n); return DVS_ERR_UNSUPPORTED; }
+  }
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  // The adaptive rule ends most loops after a few dozen iterations (10 % outliers: ~10), and the sample sequence is the same whatever
+  // the number of samples drawn: first the models of 96 iterations for every problem, then — only for the problems whose loop wanted
+  // more — all max_iters (the same result a full run gives, by construction: a prefix of the same sequence).
+  const int H1 = std::min<int>(max_iters, 96);
+  std::vector<uint8_t> unf((size_t)nprob, 0);
+  DVS_TRY(fm_cv_pass(ctx, nprob, offsets, pts1, pts2, threshold, confidence, max_iters, H1, F9, inlier_mask, n_inliers, iterations, unf.data()));
+  std::vector<int> again;
+  for (int b = 0; b < nprob; b++) if (unf[b]) again.push_back(b);
+  if (again.empty() || H1 == max_iters) return DVS_OK;
+  std::vector<int32_t> off2(again.size() + 1, 0);
+  for (size_t i = 0; i < again.size(); i++) off2[i + 1] = off2[i] + (offsets[again[i] + 1] - offsets[again[i]]);
+  std::vector<float> q1((size_t)off2.back() * 2), q2((size_t)off2.back() * 2);
+  for (size_t i = 0; i < again.size(); i++) {
+    const int b = again[i], n = offsets[b + 1] - offsets[b];
+    memcpy(q1.data() + 2 * (size_t)off2[i], pts1 + 2 * (size_t)offsets[b], (size_t)n * 8);
+    memcpy(q2.data() + 2 * (size_t)off2[i], pts2 + 2 * (size_t)offsets[b], (size_t)n * 8);
+  }
+  const int m = (int)again.size();
+  std::vector<double> F2((size_t)m * 9);
+  std::vector<uint8_t> mask2((size_t)off2.back()), unf2((size_t)m);
+  std::vector<int32_t> nin2((size_t)m), it2((size_t)m);
+  DVS_TRY(fm_cv_pass(ctx, m, off2.data(), q1.data(), q2.data(), threshold, confidence, max_iters, max_iters, F2.data(), mask2.data(), nin2.data(), it2.data(), unf2.data()));
+  for (int i = 0; i < m; i++) {
+    const int b = again[i], n = offsets[b + 1] - offsets[b];
+    memcpy(inlier_mask + offsets[b], mask2.data() + off2[i], (size_t)n);
+    if (n_inliers) n_inliers[b] = nin2[i];
+    if (iterations) iterations[b] = it2[i];
+    if (F9) memcpy(F9 + 9 * (size_t)b, F2.data() + 9 * (size_t)i, 72);
+  }
   return DVS_OK;
 }
 

@@ -17,6 +17,7 @@ K4 = np.array([f, f, cx, cy])
 for _ in range(5):
     g.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, 7); g.solve_pnp_ransac(X.astype(np.float32), p2, K4, 100, 4.0, 0.99, 9)
 for name, fn in [("fundamental", lambda s: g.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, s)),
+                 ("fundamental_cv", lambda s: g.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)),
                  ("pnp", lambda s: g.solve_pnp_ransac(X.astype(np.float32), p2, K4, 100, 4.0, 0.99, s))]:
     ts = []
     for s in range(200):
