@@ -7,6 +7,7 @@
 #include "dynamic_visual_slam/ORBextractor.hpp"
 #include "dynamic_visual_slam/bundle_adjustment.hpp"
 #include "dvslam/bf_matcher.hpp"
+#include "dvslam/calib3d.hpp"
 #include "dvslam/cv_orb.hpp"
 
 int main() {
@@ -95,6 +96,27 @@ int main() {
       std::printf("dvslam::ORB: %d x %d descriptors\n", descriptors2.rows, descriptors2.cols); return 1;
     }
     std::printf("dvslam::ORB on the disc image: %d descriptors\n", descriptors2.rows);
+  }
+  {  // frontend.cpp:627-644 with cv::findFundamentalMat -> dvslam::findFundamentalMat(matcher_, ...): a pure translation between two views plus
+     // gross outliers; the mask keeps the consistent correspondences
+    std::vector<cv::Point2f> last_kf_pts, current_kf_pts;
+    uint32_t s = 99;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.f; };
+    for (int i = 0; i < 120; i++) {
+      const float X = rnd() * 2.f - 1.f, Y = rnd() * 1.4f - 0.7f, Z = 1.5f + rnd();
+      last_kf_pts.push_back(cv::Point2f(600.f * X / Z + 320.f, 600.f * Y / Z + 240.f));
+      if (i % 6 == 5) current_kf_pts.push_back(cv::Point2f(rnd() * 640.f, rnd() * 480.f));
+      else current_kf_pts.push_back(cv::Point2f(600.f * (X - 0.05f) / (Z - 0.02f) + 320.f, 600.f * (Y + 0.01f) / (Z - 0.02f) + 240.f));
+    }
+    std::vector<uchar> kf_inliers_mask;
+    cv::Mat F = dvslam::findFundamentalMat(matcher_, last_kf_pts, current_kf_pts, kf_inliers_mask, dvslam::FM_RANSAC, 2.0, 0.99);
+    int kept = 0, kept_outliers = 0;
+    for (size_t i = 0; i < kf_inliers_mask.size(); i++) if (kf_inliers_mask[i]) { kept++; kept_outliers += i % 6 == 5; }
+    if (F.rows != 3 || kf_inliers_mask.size() != 120 || kept < 85 || kept_outliers > 4) { std::printf("findFundamentalMat: %d kept, %d of them outliers\n", kept, kept_outliers); return 1; }
+    std::vector<cv::Point2f> few(last_kf_pts.begin(), last_kf_pts.begin() + 10), few2(current_kf_pts.begin(), current_kf_pts.begin() + 10);
+    dvslam::findFundamentalMat(matcher_, few, few2, kf_inliers_mask, dvslam::FM_RANSAC, 2.0, 0.99);   // below 15 points: the library's own estimator
+    if (kf_inliers_mask.size() != 10) return 1;
+    std::printf("dvslam::findFundamentalMat: %d of 120 kept\n", kept);
   }
   std::printf("opencv-typed adapters ok: %d keypoints, BA cost %.3e in %d steps\n", n, result.final_cost, result.iterations_completed);
   return 0;

@@ -10,6 +10,7 @@
 #include <stdexcept>
 #include <vector>
 
+typedef unsigned char uchar;   // as opencv2/core/hal/interface.h declares it, in the global namespace
 #define CV_8U 0
 #define CV_64F 6
 #define CV_8UC1 0
