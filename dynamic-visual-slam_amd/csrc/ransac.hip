@@ -268,6 +268,17 @@ __device__ __forceinline__ int ransac_update_iters(double p, double ep, int mode
   return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 
+static int ransac_update_iters_host(double p, double ep, int modelPoints, int maxIters) {   // the same on the host (LMedS' iteration count)
+  p = std::max(p, 0.0); p = std::min(p, 1.0);
+  ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - std::pow(1.0 - ep, (double)modelPoints);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)std::rint(num / denom);
+}
+
 // the sequential RANSAC loop replayed over the hypothesis counts (RANSACPointSetRegistrator::run): hypothesis h is iteration h,
 // a strictly better count replaces the best and shortens the loop.  sel[0] = best hypothesis (-1: none), sel[1] = iterations used.
 __global__ void k_ransac_select(const int* __restrict__ counts, int H, const RansacProb* __restrict__ probs, int modelPoints, double confidence, int group,
@@ -352,12 +363,12 @@ static bool cv_have_collinear(const float* pts, const int* idx, int count) {   /
 }
 
 // the samples of iterations 0 .. iters - 1 (modelPoints indices each); returns how many iterations found one
-static int cv_subsets(const float* p1, const float* p2, int n, int modelPoints, int iters, int32_t* idx_out) {
+static int cv_subsets(const float* p1, const float* p2, int n, int modelPoints, int iters, int32_t* idx_out, int maxAttempts = 10000) {
   CvRng rng(~0ull);
   int idx[16];
   for (int it = 0; it < iters; it++) {
     bool found = false;
-    for (int attempt = 0; attempt < 10000 && !found; attempt++) {
+    for (int attempt = 0; attempt < maxAttempts && !found; attempt++) {
       for (int i = 0; i < modelPoints; i++) {
         int v;
         bool dup;
@@ -538,6 +549,67 @@ __global__ __launch_bounds__(64) void k_f7_hypotheses(const float* __restrict__ 
     for (int j = 0; j < 9; j++) Fout[9 * (size_t)(3 * h + k) + j] = F[j];
     valid[3 * h + k] = 1;
   }
+}
+
+// cv::LMeDSPointSetRegistrator::run over the models of k_f7_hypotheses — what cv::findFundamentalMat(FM_RANSAC) runs BELOW 15 points
+// (calib3d ptsetreg.cpp, restated from the published algorithm): a fixed number of iterations (RANSACUpdateNumIters(confidence, 0.45, 7,
+// maxIters), at least 3: 300 for 0.99), the same sample procedure (getSubset with 1000 attempts), every model of a sample in order;
+// a model's score is the MEDIAN of its float errors (std::nth_element at count / 2: the upper median), a strictly smaller median
+// replaces the best; then sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(minMedian), at least 0.001, the inliers are the errors
+// <= (float)(sigma^2), and the call succeeds when at least 7 of them remain (the mask is written either way).  One workgroup per
+// problem (n <= 14 here): the threads take the models in turn, the lowest (median, index) wins, thread 0 writes the mask.
+// sel[0] = best model (-1: none), sel[1] = iterations run, sel[2] = inliers, sel[3] = success.
+__global__ __launch_bounds__(256) void k_lmeds_select(const float* __restrict__ p1, const float* __restrict__ p2, const RansacProb* __restrict__ probs, int H,
+                                                      int niters, const double* __restrict__ Fall, const int* __restrict__ valid, int* __restrict__ sel,
+                                                      unsigned char* __restrict__ mask, double* __restrict__ Fbest) {
+  const RansacProb pb = probs[blockIdx.x];
+  const int n = pb.n, tid = threadIdx.x;
+  p1 += 2 * (size_t)pb.off; p2 += 2 * (size_t)pb.off; mask += pb.off;
+  Fall += 27 * (size_t)H * blockIdx.x; valid += 3 * (size_t)H * blockIdx.x; sel += 4 * (size_t)blockIdx.x; Fbest += 9 * (size_t)blockIdx.x;
+  const int iters = min(min(niters, H), (int)pb.seed);
+  __shared__ unsigned long long s_best[256];
+  unsigned long long best = ~0ull;   // (median's float bits << 32) | model index: non-negative floats order as their bit patterns
+  for (int m = tid; m < 3 * iters; m += 256) {
+    if (!valid[m]) continue;
+    double F[9];
+    for (int k = 0; k < 9; k++) F[k] = Fall[9 * (size_t)m + k];
+    float e[16];
+    for (int i = 0; i < 16; i++) e[i] = 3.0e38f;
+    for (int i = 0; i < n && i < 16; i++) e[i] = (float)epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+    for (int i = 1; i < 16; i++) {   // insertion sort (n <= 14; NaN errors of a degenerate model sort as they fall: the model cannot win)
+      const float v = e[i];
+      int j = i - 1;
+      while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; j--; }
+      e[j + 1] = v;
+    }
+    const float med = e[n / 2];
+    if (!(med >= 0.0f)) continue;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(med) << 32) | (unsigned)m;
+    best = key < best ? key : best;
+  }
+  s_best[tid] = best;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_best[tid] = s_best[tid + s] < s_best[tid] ? s_best[tid + s] : s_best[tid];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  best = s_best[0];
+  sel[1] = iters;
+  if (best == ~0ull) { sel[0] = -1; sel[2] = 0; sel[3] = 0; for (int i = 0; i < n; i++) mask[i] = 0; for (int k = 0; k < 9; k++) Fbest[k] = 0.0; return; }
+  const int bm = (int)(unsigned)best;
+  const double minMedian = (double)__uint_as_float((unsigned)(best >> 32));
+  double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(minMedian);
+  sigma = fmax(sigma, 0.001);
+  const float t = (float)(sigma * sigma);
+  double F[9];
+  for (int k = 0; k < 9; k++) { F[k] = Fall[9 * (size_t)bm + k]; Fbest[k] = F[k]; }
+  int cnt = 0;
+  for (int i = 0; i < n; i++) {
+    const int in = (float)epi_err(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t ? 1 : 0;
+    mask[i] = (unsigned char)in; cnt += in;
+  }
+  sel[0] = bm; sel[2] = cnt; sel[3] = cnt >= 7 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1027,8 +1099,11 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
 // cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): every problem needs >= 15 correspondences —
 // below that OpenCV switches to LMedS, which is not restated (DVS_ERR_UNSUPPORTED: the caller keeps dvs_find_fundamental_ransac)
 // one pass over `nprob` problems with the models of the first H iterations; unfinished[b] = 1 where the loop wanted more than H
+// (lmeds: the problems are below 15 points — H = the fixed iteration count, k_lmeds_select instead of score / select / mask,
+//  unfinished[b] = 1 where the call FAILED, i.e. fewer than 7 inliers: OpenCV returns an empty matrix then, the mask stays as written)
 static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold, double confidence,
-                             int32_t max_iters, int32_t H, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations, uint8_t* unfinished) {
+                             int32_t max_iters, int32_t H, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations, uint8_t* unfinished,
+                             bool lmeds = false) {
   int maxn = 0;
   for (int b = 0; b < nprob; b++) maxn = std::max(maxn, offsets[b + 1] - offsets[b]);
   const int total = offsets[nprob];
@@ -1056,15 +1131,19 @@ static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* off
   memset(hs, 0, sb);
   for (int b = 0; b < nprob; b++) {
     const int n = offsets[b + 1] - offsets[b];
-    const int found = cv_subsets(pts1 + 2 * (size_t)offsets[b], pts2 + 2 * (size_t)offsets[b], n, 7, H, hs + (size_t)b * H * 7);
+    const int found = cv_subsets(pts1 + 2 * (size_t)offsets[b], pts2 + 2 * (size_t)offsets[b], n, 7, H, hs + (size_t)b * H * 7, lmeds ? 1000 : 10000);
     hp[b] = RansacProb{offsets[b], n, (unsigned long long)found};   // the seed field carries the iterations that have a sample
   }
   const int ndw_in = (int)(inb / 4);
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   hipLaunchKernelGGL(k_f7_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, d_samples, H, d_F, d_valid);
-  hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
-  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1, max_iters);
-  hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
+  if (lmeds) {
+    hipLaunchKernelGGL(k_lmeds_select, dim3(nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, H, d_F, d_valid, d_sel, d_mask, d_Fb);
+  } else {
+    hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
+    hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1, max_iters);
+    hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
+  }
   uint8_t* hout = hio + inb;
   if (outb <= 65536) {
     const int seq = ++*counter;
@@ -1080,12 +1159,48 @@ static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* off
   for (int b = 0; b < nprob; b++) {
     if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
     if (iterations) iterations[b] = sel[4 * b + 1];
-    unfinished[b] = (uint8_t)sel[4 * b + 3];
-    if (F9) memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
+    unfinished[b] = lmeds ? (uint8_t)(sel[4 * b + 3] ? 0 : 1) : (uint8_t)sel[4 * b + 3];
+    if (F9) {
+      if (lmeds && !sel[4 * b + 3]) memset(F9 + 9 * (size_t)b, 0, 72);
+      else memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
+    }
   }
   memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
   return DVS_OK;
 }
+
+// a subset of a batch's problems as a batch of its own (concatenated copies), and its results written back
+namespace {
+struct FmSubset {
+  std::vector<int> which;
+  std::vector<int32_t> off;
+  std::vector<float> q1, q2;
+  std::vector<double> F;
+  std::vector<uint8_t> mask, flag;
+  std::vector<int32_t> nin, its;
+  void gather(const std::vector<int>& w, const int32_t* offsets, const float* pts1, const float* pts2) {
+    which = w;
+    off.assign(w.size() + 1, 0);
+    for (size_t i = 0; i < w.size(); i++) off[i + 1] = off[i] + (offsets[w[i] + 1] - offsets[w[i]]);
+    q1.resize((size_t)off.back() * 2 + 2); q2.resize((size_t)off.back() * 2 + 2);
+    for (size_t i = 0; i < w.size(); i++) {
+      const int b = w[i], n = offsets[b + 1] - offsets[b];
+      memcpy(q1.data() + 2 * (size_t)off[i], pts1 + 2 * (size_t)offsets[b], (size_t)n * 8);
+      memcpy(q2.data() + 2 * (size_t)off[i], pts2 + 2 * (size_t)offsets[b], (size_t)n * 8);
+    }
+    F.assign(w.size() * 9, 0.0); mask.assign((size_t)off.back() + 1, 0); flag.assign(w.size(), 0); nin.assign(w.size(), 0); its.assign(w.size(), 0);
+  }
+  void scatter(const int32_t* offsets, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) const {
+    for (size_t i = 0; i < which.size(); i++) {
+      const int b = which[i], n = offsets[b + 1] - offsets[b];
+      memcpy(inlier_mask + offsets[b], mask.data() + off[i], (size_t)n);
+      if (n_inliers) n_inliers[b] = nin[i];
+      if (iterations) iterations[b] = its[i];
+      if (F9) memcpy(F9 + 9 * (size_t)b, F.data() + 9 * i, 72);
+    }
+  }
+};
+}  // namespace
 
 dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
                                          double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
@@ -1094,40 +1209,42 @@ dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const 
   DVS_ARG(offsets && offsets[0] == 0 && pts1 && pts2 && inlier_mask);
   if (threshold <= 0) threshold = 3;                                                 // as cv::findFundamentalMat
   if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  std::vector<int> big, small;
   for (int b = 0; b < nprob; b++) {
     DVS_ARG(offsets[b + 1] >= offsets[b]);
     const int n = offsets[b + 1] - offsets[b];
-    if (n < 15) { set_error("dvs_find_fundamental_cv: problem %d has %d correspondences (OpenCV runs LMedS below 15: not restated)", b, n); return DVS_ERR_UNSUPPORTED; }
+    if (n < 8) { set_error("dvs_find_fundamental_cv: problem %d has %d correspondences (the reference calls with >= 8, frontend.cpp:627)", b, n); return DVS_ERR_UNSUPPORTED; }
+    (n >= 15 ? big : small).push_back(b);
   }
   DVS_HIP(hipSetDevice(matcher_device(ctx)));
-  // The adaptive rule ends most loops after a few dozen iterations (10 % outliers: ~10), and the sample sequence is the same whatever
-  // the number of samples drawn: first the models of 96 iterations for every problem, then — only for the problems whose loop wanted
-  // more — all max_iters (the same result a full run gives, by construction: a prefix of the same sequence).
-  const int H1 = std::min<int>(max_iters, 96);
-  std::vector<uint8_t> unf((size_t)nprob, 0);
-  DVS_TRY(fm_cv_pass(ctx, nprob, offsets, pts1, pts2, threshold, confidence, max_iters, H1, F9, inlier_mask, n_inliers, iterations, unf.data()));
-  std::vector<int> again;
-  for (int b = 0; b < nprob; b++) if (unf[b]) again.push_back(b);
-  if (again.empty() || H1 == max_iters) return DVS_OK;
-  std::vector<int32_t> off2(again.size() + 1, 0);
-  for (size_t i = 0; i < again.size(); i++) off2[i + 1] = off2[i] + (offsets[again[i] + 1] - offsets[again[i]]);
-  std::vector<float> q1((size_t)off2.back() * 2), q2((size_t)off2.back() * 2);
-  for (size_t i = 0; i < again.size(); i++) {
-    const int b = again[i], n = offsets[b + 1] - offsets[b];
-    memcpy(q1.data() + 2 * (size_t)off2[i], pts1 + 2 * (size_t)offsets[b], (size_t)n * 8);
-    memcpy(q2.data() + 2 * (size_t)off2[i], pts2 + 2 * (size_t)offsets[b], (size_t)n * 8);
+  // ---- >= 15 points: RANSAC.  The adaptive rule ends most loops after a few dozen iterations (10 % outliers: ~10), and the sample
+  // sequence is the same whatever the number of samples drawn: first the models of 96 iterations for every problem, then — only for
+  // the problems whose loop wanted more — all max_iters (the same result a full run gives, by construction: a prefix of the same sequence).
+  if (!big.empty()) {
+    FmSubset A;
+    A.gather(big, offsets, pts1, pts2);
+    const int H1 = std::min<int>(max_iters, 96);
+    DVS_TRY(fm_cv_pass(ctx, (int)big.size(), A.off.data(), A.q1.data(), A.q2.data(), threshold, confidence, max_iters, H1, A.F.data(), A.mask.data(), A.nin.data(),
+                       A.its.data(), A.flag.data()));
+    A.scatter(offsets, F9, inlier_mask, n_inliers, iterations);
+    std::vector<int> again;
+    for (size_t i = 0; i < big.size(); i++) if (A.flag[i]) again.push_back(big[i]);
+    if (!again.empty() && H1 < max_iters) {
+      FmSubset B;
+      B.gather(again, offsets, pts1, pts2);
+      DVS_TRY(fm_cv_pass(ctx, (int)again.size(), B.off.data(), B.q1.data(), B.q2.data(), threshold, confidence, max_iters, max_iters, B.F.data(), B.mask.data(),
+                         B.nin.data(), B.its.data(), B.flag.data()));
+      B.scatter(offsets, F9, inlier_mask, n_inliers, iterations);
+    }
   }
-  const int m = (int)again.size();
-  std::vector<double> F2((size_t)m * 9);
-  std::vector<uint8_t> mask2((size_t)off2.back()), unf2((size_t)m);
-  std::vector<int32_t> nin2((size_t)m), it2((size_t)m);
-  DVS_TRY(fm_cv_pass(ctx, m, off2.data(), q1.data(), q2.data(), threshold, confidence, max_iters, max_iters, F2.data(), mask2.data(), nin2.data(), it2.data(), unf2.data()));
-  for (int i = 0; i < m; i++) {
-    const int b = again[i], n = offsets[b + 1] - offsets[b];
-    memcpy(inlier_mask + offsets[b], mask2.data() + off2[i], (size_t)n);
-    if (n_inliers) n_inliers[b] = nin2[i];
-    if (iterations) iterations[b] = it2[i];
-    if (F9) memcpy(F9 + 9 * (size_t)b, F2.data() + 9 * (size_t)i, 72);
+  // ---- 8 .. 14 points: LMedS with its fixed iteration count (k_lmeds_select)
+  if (!small.empty()) {
+    const int niters = std::max(ransac_update_iters_host(confidence, 0.45, 7, max_iters), 3);   // outlierRatio = 0.45; 300 for 0.99
+    FmSubset C;
+    C.gather(small, offsets, pts1, pts2);
+    DVS_TRY(fm_cv_pass(ctx, (int)small.size(), C.off.data(), C.q1.data(), C.q2.data(), threshold, confidence, max_iters, niters, C.F.data(), C.mask.data(), C.nin.data(),
+                       C.its.data(), C.flag.data(), true));
+    C.scatter(offsets, F9, inlier_mask, n_inliers, iterations);
   }
   return DVS_OK;
 }

@@ -1,9 +1,8 @@
 // dvslam/calib3d.hpp — adapter with the call surface of
 //   cv::findFundamentalMat(points1, points2, mask, cv::FM_RANSAC, 2.0, 0.99)        src/frontend.cpp:635, 1146-1147
-// over the C-ABI.  From 15 correspondences on it is OpenCV's own procedure (dvs_find_fundamental_cv: the cv::RNG sample sequence,
-// 7-point solver, float error compare, adaptive stop); between 8 and 14 OpenCV switches to LMedS, which is not restated — the
-// library's own RANSAC estimator (dvs_find_fundamental_ransac, `fallbackSeed`) answers there; below 8 the reference never calls
-// (frontend.cpp:627 `if (... size() >= 8)`): an all-zero mask and an all-zero F.
+// over the C-ABI: OpenCV's own procedure (dvs_find_fundamental_cv — the cv::RNG sample sequence, 7-point solver, float error compare;
+// RANSAC with the adaptive stop from 15 correspondences on, LMedS below, as cv::findFundamentalMat switches).  Below 8 the reference
+// never calls (frontend.cpp:627 `if (... size() >= 8)`): an all-zero mask and an empty F.
 //   dvslam::findFundamentalMat(matcher, pts1, pts2, n, mask, F9)                       plain pointers (n x 2 floats)
 //   (DVSLAM_WITH_OPENCV) findFundamentalMat(matcher, vector<cv::Point2f>, vector<cv::Point2f>, vector<uchar>& mask, method, ...)
 // `matcher` is the dvslam::BFMatcher the node already owns (frontend.cpp:220): the stage shares its handle, stream and scratch.
@@ -18,19 +17,17 @@ constexpr int FM_RANSAC = 8;   // cv::FM_RANSAC
 
 // returns true when a model was found; F9 row-major (may be nullptr)
 inline bool findFundamentalMat(BFMatcher& matcher, const float* pts1, const float* pts2, int n, std::vector<unsigned char>& mask, double* F9 = nullptr,
-                               double ransacReprojThreshold = 2.0, double confidence = 0.99, int maxIters = 1000, uint64_t fallbackSeed = 1) {
+                               double ransacReprojThreshold = 2.0, double confidence = 0.99, int maxIters = 1000) {
   mask.assign((size_t)(n > 0 ? n : 0), 0);
   double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t inliers = 0;
-  if (n >= 15) {
-    if (dvs_find_fundamental_cv(matcher.handle(), pts1, pts2, n, ransacReprojThreshold, confidence, maxIters, F, mask.data(), &inliers, nullptr) != DVS_OK)
-      throw std::runtime_error(dvs_last_error());
-  } else if (n >= 8) {
-    if (dvs_find_fundamental_ransac(matcher.handle(), pts1, pts2, n, ransacReprojThreshold, confidence, maxIters, fallbackSeed, F, mask.data(), &inliers) != DVS_OK)
-      throw std::runtime_error(dvs_last_error());
-  }
+  if (n >= 8 &&
+      dvs_find_fundamental_cv(matcher.handle(), pts1, pts2, n, ransacReprojThreshold, confidence, maxIters, F, mask.data(), &inliers, nullptr) != DVS_OK)
+    throw std::runtime_error(dvs_last_error());
   if (F9) for (int k = 0; k < 9; k++) F9[k] = F[k];
-  return inliers > 0;
+  bool any = false;
+  for (int k = 0; k < 9; k++) any = any || F[k] != 0.0;
+  return any;   // false: OpenCV would return an empty matrix (the mask is written either way)
 }
 
 #ifdef DVSLAM_WITH_OPENCV

@@ -325,14 +325,19 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
                                              const float* pts2, double threshold, double confidence, int32_t max_iters, const uint64_t* seeds,
                                              double* F9 /* nprob x 9 or NULL */, uint8_t* inlier_mask /* offsets[nprob] */, int32_t* n_inliers /* nprob or NULL */);
 /* cv::findFundamentalMat(pts1, pts2, mask, cv::FM_RANSAC, threshold, confidence) (frontend.cpp:635, 1146-1147) the way OpenCV 4.x
- * itself runs it for >= 15 correspondences, restated from the published algorithm (calib3d fundam.cpp / ptsetreg.cpp; csrc/ransac.hip
- * k_f7_hypotheses): the sample sequence of RANSACPointSetRegistrator — ONE cv::RNG seeded with (uint64)-1, index = next() % n, drawn
- * again while it repeats, whole samples drawn again while their last point is collinear with two earlier ones — the 7-point solver
- * (two null vectors, cv::solveCubic, one model per real root, F(3,3) = 1), errors and threshold compared as floats, the adaptive
- * stopping rule, no refit.  F9 row-major with F[8] = 1 (0 where OpenCV sets it so), may be NULL; *iterations (may be NULL) = loop
- * iterations run.  OpenCV's maxIters default is 1000.  n < 15 (OpenCV switches to LMedS there): DVS_ERR_UNSUPPORTED.  PARITY
- * UNPINNED like everything else (no OpenCV in this image); what cannot agree even in principle is a tie between two models of ONE
- * sample, whose order follows the null-space basis (OpenCV: SVD). */
+ * itself runs it, restated from the published algorithm (calib3d fundam.cpp / ptsetreg.cpp; csrc/ransac.hip k_f7_hypotheses,
+ * k_lmeds_select): the sample sequence — ONE cv::RNG seeded with (uint64)-1, index = next() % n, drawn again while it repeats, whole
+ * samples drawn again while their last point is collinear with two earlier ones — and the 7-point solver (two null vectors,
+ * cv::solveCubic, one model per real root, F(3,3) = 1), errors compared as floats.  From 15 correspondences on RANSAC
+ * (RANSACPointSetRegistrator: strictly better inlier count wins, adaptive stopping rule, no refit; *iterations = loop iterations run);
+ * from 8 to 14 LMedS, as OpenCV switches (LMeDSPointSetRegistrator: a fixed 300 iterations at confidence 0.99, smallest MEDIAN error
+ * wins, inliers within sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median) >= 0.001; fewer than 7 of them: F9 all zero — OpenCV
+ * returns an empty matrix — with the mask still written).  F9 row-major with F[8] = 1 (0 where OpenCV sets it so), may be NULL.
+ * OpenCV's maxIters default is 1000.  n < 8 (the reference never calls there, frontend.cpp:627): DVS_ERR_UNSUPPORTED.  PARITY UNPINNED
+ * like everything else (no OpenCV in this image).  What cannot agree even in principle: a tie between two models of ONE sample,
+ * whose order follows the null-space basis (OpenCV: SVD); and LMedS below 14 points, where every model's median is the error of one
+ * of its own sample points — rounding noise — so that WHICH of the 300 samples wins (and becomes the 7-point inlier set) is decided
+ * by the rounding of the solver at hand. */
 dvs_status dvs_find_fundamental_cv(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,
                                    int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations);
 dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,

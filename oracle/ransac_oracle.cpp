@@ -200,8 +200,8 @@ bool cvHaveCollinear(const float* pts, const int* idx, int count) {
   return false;
 }
 
-bool cvGetSubset(CvRng& rng, const float* p1, const float* p2, int n, int modelPoints, int* idx) {
-  for (int attempt = 0; attempt < 10000; attempt++) {
+bool cvGetSubset(CvRng& rng, const float* p1, const float* p2, int n, int modelPoints, int* idx, int maxAttempts = 10000) {
+  for (int attempt = 0; attempt < maxAttempts; attempt++) {
     for (int i = 0; i < modelPoints; i++) {
       int v;
       for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {}
@@ -479,9 +479,40 @@ void orc_find_fundamental_cv(const float* p1, const float* p2, int n, double thr
   for (int i = 0; i < n; i++) mask[i] = 0;
   for (int k = 0; k < 9; k++) F9[k] = 0;
   sel3[0] = -1; sel3[1] = 0; sel3[2] = 0;
-  if (n < 15) return;
+  if (n < 8) return;
   if (threshold <= 0) threshold = 3;
   if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+  if (n < 15) {
+    // LMeDSPointSetRegistrator::run (what OpenCV runs below 15 points): fixed iteration count, the model with the smallest MEDIAN error
+    // (upper median, std::nth_element at count / 2) wins, inliers within sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(median)
+    const int niters = std::max(updateNumIters(confidence, 0.45, 7, maxIters), 3);
+    CvRng rng(~0ull);
+    double minMedian = DBL_MAX, Fb[9] = {0};
+    int best = -1, it = 0;
+    std::vector<float> e(n);
+    for (; it < niters; it++) {
+      int idx[7];
+      if (!cvGetSubset(rng, p1, p2, n, 7, idx, 1000)) break;
+      double F[3][9];
+      const int nm = sevenPoint(p1, p2, idx, F);
+      for (int m = 0; m < nm; m++) {
+        for (int i = 0; i < n; i++) e[i] = (float)epiErr(F[m], p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+        std::nth_element(e.begin(), e.begin() + n / 2, e.end());
+        const double median = e[n / 2];
+        if (median < minMedian) { minMedian = median; best = it; memcpy(Fb, F[m], sizeof(Fb)); }
+      }
+    }
+    sel3[0] = best; sel3[1] = it;
+    if (best < 0) return;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * std::sqrt(minMedian);
+    sigma = std::max(sigma, 0.001);
+    const float ts = (float)(sigma * sigma);
+    int cnt = 0;
+    for (int i = 0; i < n; i++) { mask[i] = (float)epiErr(Fb, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= ts ? 1 : 0; cnt += mask[i]; }
+    sel3[2] = cnt;
+    if (cnt >= 7) memcpy(F9, Fb, sizeof(Fb));   // fewer: OpenCV returns an empty matrix, the mask stays
+    return;
+  }
   const float t = (float)(threshold * threshold);
   CvRng rng(~0ull);
   int niters = maxIters, best = -1, bestCount = 0, it = 0;

@@ -114,7 +114,7 @@ int main() {
     for (size_t i = 0; i < kf_inliers_mask.size(); i++) if (kf_inliers_mask[i]) { kept++; kept_outliers += i % 6 == 5; }
     if (F.rows != 3 || kf_inliers_mask.size() != 120 || kept < 85 || kept_outliers > 4) { std::printf("findFundamentalMat: %d kept, %d of them outliers\n", kept, kept_outliers); return 1; }
     std::vector<cv::Point2f> few(last_kf_pts.begin(), last_kf_pts.begin() + 10), few2(current_kf_pts.begin(), current_kf_pts.begin() + 10);
-    dvslam::findFundamentalMat(matcher_, few, few2, kf_inliers_mask, dvslam::FM_RANSAC, 2.0, 0.99);   // below 15 points: the library's own estimator
+    dvslam::findFundamentalMat(matcher_, few, few2, kf_inliers_mask, dvslam::FM_RANSAC, 2.0, 0.99);   // below 15 points: LMedS, as OpenCV switches
     if (kf_inliers_mask.size() != 10) return 1;
     std::printf("dvslam::findFundamentalMat: %d of 120 kept\n", kept);
   }

@@ -75,11 +75,9 @@ class HipStages:
         return self.mat.match(q, t)
 
     def fundamental_inliers(self, p1, p2, seed):
-        # cv::findFundamentalMat(FM_RANSAC, 2.0, 0.99) as OpenCV runs it (its own sample sequence and 7-point solver) from 15 points on;
-        # below that OpenCV switches to LMedS, which is not restated: the library's own estimator with the replay's seed
-        if len(p1) >= 15:
-            return self.g.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
-        return self.g.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, seed)[1].astype(bool)
+        # cv::findFundamentalMat(FM_RANSAC, 2.0, 0.99) as OpenCV runs it: its own sample sequence and 7-point solver, RANSAC from 15 points
+        # on and LMedS below (the reference calls with >= 8, frontend.cpp:627); `seed` belongs to the library's own estimator, unused here
+        return self.g.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
 
     def pnp(self, obj, img, K4, seed):
         ok, rvec, tvec, inl = self.g.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
@@ -90,17 +88,7 @@ class HipStages:
 
     # ---- the same stages over MANY frames at once (track_batched): one launch sequence per stage ----
     def fundamental_inliers_batch(self, p1_list, p2_list, seeds):
-        big = [i for i, p in enumerate(p1_list) if len(p) >= 15]
-        small = [i for i, p in enumerate(p1_list) if len(p) < 15]
-        out = [None] * len(p1_list)
-        if big:
-            for i, (m, _, _) in zip(big, self.g.find_fundamental_cv_batch([p1_list[i] for i in big], [p2_list[i] for i in big], 2.0, 0.99, 1000)):
-                out[i] = m.astype(bool)
-        if small:
-            for i, (m, _) in zip(small, self.g.find_fundamental_ransac_batch([p1_list[i] for i in small], [p2_list[i] for i in small],
-                                                                             [seeds[i] for i in small], 2.0, 0.99, 1000)):
-                out[i] = m.astype(bool)
-        return out
+        return [m.astype(bool) for m, _, _ in self.g.find_fundamental_cv_batch(p1_list, p2_list, 2.0, 0.99, 1000)]
 
     def pnp_batch(self, obj_list, img_list, K4, seeds):
         return [(ok, rvec, tvec, len(inl)) for ok, rvec, tvec, inl in self.g.solve_pnp_ransac_batch(obj_list, img_list, K4, seeds, 100, 4.0, 0.99)]
@@ -155,9 +143,7 @@ class CpuStages:
         return self.ob.match(q, t)
 
     def fundamental_inliers(self, p1, p2, seed):
-        if len(p1) >= 15:
-            return self.ob.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
-        return self.ob.find_fundamental_ransac(p1, p2, 2.0, 0.99, 1000, seed)[1].astype(bool)
+        return self.ob.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
 
     def pnp(self, obj, img, K4, seed):
         ok, rvec, tvec, inl, sel = self.ob.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
