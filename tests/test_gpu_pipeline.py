@@ -75,10 +75,11 @@ def test_timed_configuration_against_oracle(gpu, oracle):
     pipe.close()
 
 
-@pytest.mark.parametrize("B,rows,cols,nf,nsets,steps", [(5, 480, 640, 800, 3, 8), (33, 360, 1000, 700, 3, 5), (1, 720, 1280, 2000, 4, 9), (9, 250, 332, 200, 5, 6)])
+@pytest.mark.parametrize("B,rows,cols,nf,nsets,steps", [(5, 480, 640, 800, 3, 8), (33, 360, 1000, 700, 3, 5), (1, 720, 1280, 2000, 4, 9), (9, 250, 332, 200, 5, 6),
+                                                        (16, 480, 640, 600, 3, 4), (24, 360, 1000, 500, 3, 4)])
 def test_other_shapes_of_the_pipelined_step(gpu, oracle, B, rows, cols, nf, nsets, steps):
     """the same step at other batch sizes (1 and 33: the small-batch kernel variants and the 256-thread quad-tree on either side of
-    their thresholds), resolutions (widths that are not multiples of 4 take the generic kernels) and output-set counts: the resident
+    their thresholds; 16 and 24: the pyramid kernel's lanes run over 2 / 3 frames of an XCD's share, 64 in the test above over 8), resolutions (widths that are not multiples of 4 take the generic kernels) and output-set counts: the resident
     batches and their match jobs against the oracle"""
     _run_shape(oracle, B, rows, cols, nf, nsets, steps)
 
