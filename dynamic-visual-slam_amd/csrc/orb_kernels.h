@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_resize(const u8* __restrict__ src, uint
 // gathers: v_alignbit moves the group's first tap to byte 0 of an 8-byte window (all 8 taps of the group lie inside it for
 // scale factors < 1.5), then per pixel ONE v_perm picks (left, right) into 16-bit halves and ONE v_dot2_u32_u16 applies the
 // Q11 pair.  Whenever the reference clamps the right tap (last column) its coefficient is 0, so its byte is irrelevant.
-constexpr int kResizeRows = 4;  // output rows per thread: one table entry, 2 x kResizeRows independent 12-byte windows in flight
+constexpr int kResizeRows = 8;  // output rows per thread: one table entry, 2 x kResizeRows independent 12-byte windows in flight, 7 of the 16 row windows shared (4 rows: 3 of 8; step -0.6 % in same-box alternating runs)
 __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uint64_t sfs, int sw, int sh, int sp,
                                                  u8* __restrict__ dst, uint64_t dfs, int dw, int dh, int dp,
                                                  const ResizeGroup* __restrict__ xt, const int* __restrict__ yofs,
