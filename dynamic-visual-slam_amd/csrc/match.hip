@@ -279,36 +279,52 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict_
   }
 }
 
-// threshold variant, pass 1: number of train rows with distance < maxDist per query
+// every (query, train) pair with distance < maxDist (the backend's association loop, backend.cpp:1068-1077, as ONE job), in two passes.
+// One WAVEFRONT per query: its lanes take the train descriptors in turn — 64 consecutive 32-byte rows per trip, coalesced — so a map
+// of 13 000 landmarks is 204 trips instead of 13 000 iterations of one thread (round 2's form: four workgroups, 1.8 ms per keyframe
+// at that map size — half of the replay's GPU time; now a few microseconds).
+// pass 1: matches per query
 __global__ __launch_bounds__(256) void k_thresh_count(const u64* __restrict__ q, int nq, const u64* __restrict__ t, int nt,
                                                       int maxDist, int* __restrict__ counts) {
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (qi >= nq) return;
+  const int lane = (int)(threadIdx.x & 63);
   const u64* qp = q + (size_t)qi * 4;
   const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
   int c = 0;
-  for (int j = 0; j < nt; j++) {
+  for (int j = lane; j < nt; j += 64) {
     const u64* r = t + (size_t)j * 4;
     const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
     c += d < maxDist ? 1 : 0;
   }
-  counts[qi] = c;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) counts[qi] = c;
 }
-// pass 2: write (q, t, dist) triplets at the query's exclusive offset (offsets computed between the passes)
+// pass 2: write (q, t, dist) triplets at the query's exclusive offset (offsets computed between the passes), train index ascending:
+// a trip's hits are ranked by the ballot
 __global__ __launch_bounds__(256) void k_thresh_write(const u64* __restrict__ q, int nq, const u64* __restrict__ t, int nt,
                                                       int maxDist, const long long* __restrict__ offs, int* __restrict__ pairs, long long cap) {
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (qi >= nq) return;
+  const int lane = (int)(threadIdx.x & 63);
   const u64* qp = q + (size_t)qi * 4;
   const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
   long long o = offs[qi];
-  for (int j = 0; j < nt; j++) {
-    const u64* r = t + (size_t)j * 4;
-    const int d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
-    if (d < maxDist) {
-      if (o < cap) { pairs[3 * o] = qi; pairs[3 * o + 1] = j; pairs[3 * o + 2] = d; }
-      o++;
+  for (int j0 = 0; j0 < nt; j0 += 64) {
+    const int j = j0 + lane;
+    int d = 0;
+    bool hit = false;
+    if (j < nt) {
+      const u64* r = t + (size_t)j * 4;
+      d = __popcll(a0 ^ r[0]) + __popcll(a1 ^ r[1]) + __popcll(a2 ^ r[2]) + __popcll(a3 ^ r[3]);
+      hit = d < maxDist;
     }
+    const unsigned long long b = __ballot(hit);
+    if (hit) {
+      const long long pos = o + (long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      if (pos < cap) { pairs[3 * pos] = qi; pairs[3 * pos + 1] = j; pairs[3 * pos + 2] = d; }
+    }
+    o += __popcll(b);
   }
 }
 // single-block exclusive scan of int counts into 64-bit offsets (+ total at offs[n])
@@ -430,7 +446,7 @@ dvs_status matcher_thresh_device(dvs_matcher* m, const uint8_t* q, int nq, const
   DVS_HIP(hipMalloc(&m->d_offs, ((size_t)nq + 1) * 8));
   DVS_HIP(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
   DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-  const dim3 grid((nq + 255) / 256);
+  const dim3 grid((nq + 3) / 4);   // one wavefront per query
   hipLaunchKernelGGL(k_thresh_count, grid, dim3(256), 0, m->stream, (const u64*)m->d_q, nq, (const u64*)m->d_t, nt, max_dist, (int*)m->d_counts);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, m->stream, (const int*)m->d_counts, nq, (long long*)m->d_offs);
   DVS_HIP(hipGetLastError());
