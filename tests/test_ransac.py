@@ -128,6 +128,13 @@ def test_oracle_degenerate_inputs(oracle):
     assert sel[0] == -1 and mask.sum() == 0
     ok, rvec, tvec, inl, sel = oracle.solve_pnp_ransac(np.zeros((3, 3), np.float32), np.zeros((3, 2), np.float32), [600, 600, 320, 240])
     assert not ok and inl.size == 0
+    for n in (20, 10):                                                                     # OpenCV's procedure: no sample passes checkSubset -> no model
+        p = np.full((n, 2), 7.0, np.float32)
+        F, mask, sel = oracle.find_fundamental_cv(p, p)
+        assert sel[0] == -1 and sel[1] == 0 and mask.sum() == 0 and (F == 0).all()
+    q = np.stack([np.arange(30, dtype=np.float32), 2 * np.arange(30, dtype=np.float32) + 1], 1)   # all points on one line
+    F, mask, sel = oracle.find_fundamental_cv(q, q + 3)
+    assert sel[0] == -1 and mask.sum() == 0
 
 
 # ---------------------------------------------------------------- GPU: the HIP stages against ground truth and against the oracle
@@ -184,6 +191,13 @@ def test_gpu_ransac_degenerate_inputs(gpu):
     assert nin == 0 and mask.sum() == 0 and (F == 0).all()
     ok, rvec, tvec, inl = g.solve_pnp_ransac(np.zeros((3, 3), np.float32), np.zeros((3, 2), np.float32), [600, 600, 320, 240])
     assert not ok and inl.size == 0
+    for n in (20, 10):                                                                     # dvs_find_fundamental_cv: no sample passes checkSubset
+        p = np.full((n, 2), 7.0, np.float32)
+        F, mask, nin, its = g.find_fundamental_cv(p, p)
+        assert nin == 0 and its == 0 and mask.sum() == 0 and (F == 0).all()
+    q = np.stack([np.arange(30, dtype=np.float32), 2 * np.arange(30, dtype=np.float32) + 1], 1)
+    F, mask, nin, its = g.find_fundamental_cv(q, q + 3)
+    assert nin == 0 and mask.sum() == 0 and (F == 0).all()
     rng = np.random.Generator(np.random.PCG64(1))                                          # pure noise: no consistent pose
     ok, rvec, tvec, inl = g.solve_pnp_ransac(rng.uniform(-1, 1, (50, 3)) + [0, 0, 2], rng.uniform(0, 640, (50, 2)), [600, 600, 320, 240])
     assert inl.size < 15
