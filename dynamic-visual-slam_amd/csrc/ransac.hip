@@ -1018,6 +1018,109 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const float* __restrict__ ob
   }
 }
 
+// one pass over `nprob` problems with the models of the first H iterations; unfinished[b] = 1 where the loop wanted more than H
+// (lmeds: the problems are below 15 points — H = the fixed iteration count, k_lmeds_select instead of score / select / mask,
+//  unfinished[b] = 1 where the call FAILED, i.e. fewer than 7 inliers: OpenCV returns an empty matrix then, the mask stays as written)
+static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold, double confidence,
+                             int32_t max_iters, int32_t H, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations, uint8_t* unfinished,
+                             bool lmeds = false) {
+  int maxn = 0;
+  for (int b = 0; b < nprob; b++) maxn = std::max(maxn, offsets[b + 1] - offsets[b]);
+  const int total = offsets[nprob];
+  hipStream_t st = matcher_stream(ctx);
+  const int H3 = 3 * H;
+  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, pb = ((size_t)total * 8 + 15) & ~(size_t)15;
+  const size_t sb = ((size_t)nprob * H * 7 * 4 + 15) & ~(size_t)15;
+  const size_t inb = hb + 2 * pb + sb;
+  const size_t fb = (size_t)nprob * H3 * 72, vb = (size_t)nprob * H3 * 4;
+  const size_t outb = ((size_t)nprob * (16 + 72) + (size_t)total + 3) & ~(size_t)3;
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, inb + fb + 2 * vb + outb + 64, (void**)&base));
+  const RansacProb* d_probs = (const RansacProb*)base;
+  float* d_p1 = (float*)(base + hb); float* d_p2 = (float*)(base + hb + pb);
+  const int32_t* d_samples = (const int32_t*)(base + hb + 2 * pb);
+  double* d_F = (double*)(base + inb);
+  int* d_valid = (int*)(base + inb + fb); int* d_counts = (int*)(base + inb + fb + vb);
+  uint8_t* d_out = base + inb + fb + 2 * vb;
+  int* d_sel = (int*)d_out; double* d_Fb = (double*)(d_out + (size_t)nprob * 16); unsigned char* d_mask = d_out + (size_t)nprob * 88;
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
+  RansacProb* hp = (RansacProb*)hio;
+  memcpy(hio + hb, pts1, (size_t)total * 8); memcpy(hio + hb + pb, pts2, (size_t)total * 8);
+  int32_t* hs = (int32_t*)(hio + hb + 2 * pb);
+  memset(hs, 0, sb);
+  for (int b = 0; b < nprob; b++) {
+    const int n = offsets[b + 1] - offsets[b];
+    const int found = cv_subsets(pts1 + 2 * (size_t)offsets[b], pts2 + 2 * (size_t)offsets[b], n, 7, H, hs + (size_t)b * H * 7, lmeds ? 1000 : 10000);
+    hp[b] = RansacProb{offsets[b], n, (unsigned long long)found};   // the seed field carries the iterations that have a sample
+  }
+  const int ndw_in = (int)(inb / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
+  hipLaunchKernelGGL(k_f7_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, d_samples, H, d_F, d_valid);
+  if (lmeds) {
+    hipLaunchKernelGGL(k_lmeds_select, dim3(nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, H, d_F, d_valid, d_sel, d_mask, d_Fb);
+  } else {
+    hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
+    hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1, max_iters);
+    hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
+  }
+  uint8_t* hout = hio + inb;
+  if (outb <= 65536) {
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, st));
+  } else {
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+  }
+  const int* sel = (const int*)hout;
+  for (int b = 0; b < nprob; b++) {
+    if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
+    if (iterations) iterations[b] = sel[4 * b + 1];
+    unfinished[b] = lmeds ? (uint8_t)(sel[4 * b + 3] ? 0 : 1) : (uint8_t)sel[4 * b + 3];
+    if (F9) {
+      if (lmeds && !sel[4 * b + 3]) memset(F9 + 9 * (size_t)b, 0, 72);
+      else memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
+    }
+  }
+  memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
+  return DVS_OK;
+}
+
+// a subset of a batch's problems as a batch of its own (concatenated copies), and its results written back
+struct FmSubset {
+  std::vector<int> which;
+  std::vector<int32_t> off;
+  std::vector<float> q1, q2;
+  std::vector<double> F;
+  std::vector<uint8_t> mask, flag;
+  std::vector<int32_t> nin, its;
+  void gather(const std::vector<int>& w, const int32_t* offsets, const float* pts1, const float* pts2) {
+    which = w;
+    off.assign(w.size() + 1, 0);
+    for (size_t i = 0; i < w.size(); i++) off[i + 1] = off[i] + (offsets[w[i] + 1] - offsets[w[i]]);
+    q1.resize((size_t)off.back() * 2 + 2); q2.resize((size_t)off.back() * 2 + 2);
+    for (size_t i = 0; i < w.size(); i++) {
+      const int b = w[i], n = offsets[b + 1] - offsets[b];
+      memcpy(q1.data() + 2 * (size_t)off[i], pts1 + 2 * (size_t)offsets[b], (size_t)n * 8);
+      memcpy(q2.data() + 2 * (size_t)off[i], pts2 + 2 * (size_t)offsets[b], (size_t)n * 8);
+    }
+    F.assign(w.size() * 9, 0.0); mask.assign((size_t)off.back() + 1, 0); flag.assign(w.size(), 0); nin.assign(w.size(), 0); its.assign(w.size(), 0);
+  }
+  void scatter(const int32_t* offsets, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) const {
+    for (size_t i = 0; i < which.size(); i++) {
+      const int b = which[i], n = offsets[b + 1] - offsets[b];
+      memcpy(inlier_mask + offsets[b], mask.data() + off[i], (size_t)n);
+      if (n_inliers) n_inliers[b] = nin[i];
+      if (iterations) iterations[b] = its[i];
+      if (F9) memcpy(F9 + 9 * (size_t)b, F.data() + 9 * i, 72);
+    }
+  }
+};
+
+
 }  // namespace dvs
 
 using namespace dvs;
@@ -1098,110 +1201,6 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
 
 // cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): every problem needs >= 15 correspondences —
 // below that OpenCV switches to LMedS, which is not restated (DVS_ERR_UNSUPPORTED: the caller keeps dvs_find_fundamental_ransac)
-// one pass over `nprob` problems with the models of the first H iterations; unfinished[b] = 1 where the loop wanted more than H
-// (lmeds: the problems are below 15 points — H = the fixed iteration count, k_lmeds_select instead of score / select / mask,
-//  unfinished[b] = 1 where the call FAILED, i.e. fewer than 7 inliers: OpenCV returns an empty matrix then, the mask stays as written)
-static dvs_status fm_cv_pass(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold, double confidence,
-                             int32_t max_iters, int32_t H, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations, uint8_t* unfinished,
-                             bool lmeds = false) {
-  int maxn = 0;
-  for (int b = 0; b < nprob; b++) maxn = std::max(maxn, offsets[b + 1] - offsets[b]);
-  const int total = offsets[nprob];
-  hipStream_t st = matcher_stream(ctx);
-  const int H3 = 3 * H;
-  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, pb = ((size_t)total * 8 + 15) & ~(size_t)15;
-  const size_t sb = ((size_t)nprob * H * 7 * 4 + 15) & ~(size_t)15;
-  const size_t inb = hb + 2 * pb + sb;
-  const size_t fb = (size_t)nprob * H3 * 72, vb = (size_t)nprob * H3 * 4;
-  const size_t outb = ((size_t)nprob * (16 + 72) + (size_t)total + 3) & ~(size_t)3;
-  uint8_t* base;
-  DVS_TRY(matcher_scratch(ctx, 0, inb + fb + 2 * vb + outb + 64, (void**)&base));
-  const RansacProb* d_probs = (const RansacProb*)base;
-  float* d_p1 = (float*)(base + hb); float* d_p2 = (float*)(base + hb + pb);
-  const int32_t* d_samples = (const int32_t*)(base + hb + 2 * pb);
-  double* d_F = (double*)(base + inb);
-  int* d_valid = (int*)(base + inb + fb); int* d_counts = (int*)(base + inb + fb + vb);
-  uint8_t* d_out = base + inb + fb + 2 * vb;
-  int* d_sel = (int*)d_out; double* d_Fb = (double*)(d_out + (size_t)nprob * 16); unsigned char* d_mask = d_out + (size_t)nprob * 88;
-  uint8_t* hio; int *hseq, *counter;
-  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
-  RansacProb* hp = (RansacProb*)hio;
-  memcpy(hio + hb, pts1, (size_t)total * 8); memcpy(hio + hb + pb, pts2, (size_t)total * 8);
-  int32_t* hs = (int32_t*)(hio + hb + 2 * pb);
-  memset(hs, 0, sb);
-  for (int b = 0; b < nprob; b++) {
-    const int n = offsets[b + 1] - offsets[b];
-    const int found = cv_subsets(pts1 + 2 * (size_t)offsets[b], pts2 + 2 * (size_t)offsets[b], n, 7, H, hs + (size_t)b * H * 7, lmeds ? 1000 : 10000);
-    hp[b] = RansacProb{offsets[b], n, (unsigned long long)found};   // the seed field carries the iterations that have a sample
-  }
-  const int ndw_in = (int)(inb / 4);
-  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
-  hipLaunchKernelGGL(k_f7_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_p1, d_p2, d_probs, d_samples, H, d_F, d_valid);
-  if (lmeds) {
-    hipLaunchKernelGGL(k_lmeds_select, dim3(nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H, H, d_F, d_valid, d_sel, d_mask, d_Fb);
-  } else {
-    hipLaunchKernelGGL(k_f_score, dim3(H3, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_valid, threshold * threshold, d_counts, 1);
-    hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H3, d_probs, 7, confidence, 3, d_sel, 1, max_iters);
-    hipLaunchKernelGGL(k_f_mask, dim3((std::max(maxn, 9) + 255) / 256, nprob), dim3(256), 0, st, d_p1, d_p2, d_probs, H3, d_F, d_sel, threshold * threshold, d_mask, d_Fb, 1);
-  }
-  uint8_t* hout = hio + inb;
-  if (outb <= 65536) {
-    const int seq = ++*counter;
-    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
-    DVS_HIP(hipGetLastError());
-    DVS_TRY(io_wait(hseq, seq, st));
-  } else {
-    DVS_HIP(hipGetLastError());
-    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
-    DVS_HIP(hipStreamSynchronize(st));
-  }
-  const int* sel = (const int*)hout;
-  for (int b = 0; b < nprob; b++) {
-    if (n_inliers) n_inliers[b] = sel[4 * b] >= 0 ? sel[4 * b + 2] : 0;
-    if (iterations) iterations[b] = sel[4 * b + 1];
-    unfinished[b] = lmeds ? (uint8_t)(sel[4 * b + 3] ? 0 : 1) : (uint8_t)sel[4 * b + 3];
-    if (F9) {
-      if (lmeds && !sel[4 * b + 3]) memset(F9 + 9 * (size_t)b, 0, 72);
-      else memcpy(F9 + 9 * (size_t)b, hout + (size_t)nprob * 16 + 72 * (size_t)b, 72);
-    }
-  }
-  memcpy(inlier_mask, hout + (size_t)nprob * 88, (size_t)total);
-  return DVS_OK;
-}
-
-// a subset of a batch's problems as a batch of its own (concatenated copies), and its results written back
-namespace {
-struct FmSubset {
-  std::vector<int> which;
-  std::vector<int32_t> off;
-  std::vector<float> q1, q2;
-  std::vector<double> F;
-  std::vector<uint8_t> mask, flag;
-  std::vector<int32_t> nin, its;
-  void gather(const std::vector<int>& w, const int32_t* offsets, const float* pts1, const float* pts2) {
-    which = w;
-    off.assign(w.size() + 1, 0);
-    for (size_t i = 0; i < w.size(); i++) off[i + 1] = off[i] + (offsets[w[i] + 1] - offsets[w[i]]);
-    q1.resize((size_t)off.back() * 2 + 2); q2.resize((size_t)off.back() * 2 + 2);
-    for (size_t i = 0; i < w.size(); i++) {
-      const int b = w[i], n = offsets[b + 1] - offsets[b];
-      memcpy(q1.data() + 2 * (size_t)off[i], pts1 + 2 * (size_t)offsets[b], (size_t)n * 8);
-      memcpy(q2.data() + 2 * (size_t)off[i], pts2 + 2 * (size_t)offsets[b], (size_t)n * 8);
-    }
-    F.assign(w.size() * 9, 0.0); mask.assign((size_t)off.back() + 1, 0); flag.assign(w.size(), 0); nin.assign(w.size(), 0); its.assign(w.size(), 0);
-  }
-  void scatter(const int32_t* offsets, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) const {
-    for (size_t i = 0; i < which.size(); i++) {
-      const int b = which[i], n = offsets[b + 1] - offsets[b];
-      memcpy(inlier_mask + offsets[b], mask.data() + off[i], (size_t)n);
-      if (n_inliers) n_inliers[b] = nin[i];
-      if (iterations) iterations[b] = its[i];
-      if (F9) memcpy(F9 + 9 * (size_t)b, F.data() + 9 * i, 72);
-    }
-  }
-};
-}  // namespace
-
 dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
                                          double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
   DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096);
