@@ -425,13 +425,13 @@ def main():
     orb.set_overlap(overlap_default)
     # (a) the pipelined schedule: what a kernel takes WHILE its neighbours share the machine (= rocprofv3's statistics of this command);
     #     last, so that the timed region follows work of its own intensity
-    pipe.i = 0
+    pipe.reset()
     for k in range(K):
         pipe.step(img[k % NB], img[(k + 1) % NB])
     pipe.synchronize()
     ov_ms, ov_calls = orb.stage_times()
     orb.enable_stage_timing(False)
-    pipe.i = 0
+    pipe.reset()
 
     for _ in range(args.warmup):
         step()

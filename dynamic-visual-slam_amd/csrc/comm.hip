@@ -113,6 +113,12 @@ struct dvs_comm {
   long calls = 0;
   size_t block = 0;
   int turn = 0;
+  // a caller may issue successive calls on different streams (the lane schedule of dvs_pipeline): a call that finds another stream
+  // than its predecessor's orders itself behind that call's gather — rank 0's result points into the PREVIOUS call's buffer
+  // (the first change of stream is covered by a host wait, from then on every call records an event: single-stream callers pay nothing)
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false, multi_stream = false;
 };
 
 namespace {
@@ -231,6 +237,7 @@ void dvs_comm_destroy(dvs_comm* c) {
     }
   }
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  if (c->ev_last) (void)hipEventDestroy(c->ev_last);
   for (uint8_t* p : c->gather) if (p) (void)hipFree(p);
   delete c;
 }
@@ -268,6 +275,14 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   c->turn = (c->turn + 1) % 3;
   c->calls++;
   hipStream_t st = (hipStream_t)stream;
+  if (c->has_last && c->last_stream != st) {
+    if (c->multi_stream) DVS_HIP(hipStreamWaitEvent(st, c->ev_last, 0));
+    else {
+      DVS_HIP(hipStreamSynchronize(c->last_stream));
+      DVS_HIP(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+      c->multi_stream = true;
+    }
+  }
   if (c->loop) DVS_TRY(loop_before_send(c, st));
   uint8_t* mine = g + (size_t)c->rank * blk;
   const int rows16 = cap * 2, blk16 = (int)(blk / 16);
@@ -275,6 +290,8 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   DVS_HIP(hipGetLastError());
   // in place: this rank's block already sits at its slot of the receive buffer
   DVS_TRY(comm_all_gather(c, mine, g, blk, st));
+  if (c->multi_stream) DVS_HIP(hipEventRecord(c->ev_last, st));
+  c->last_stream = st; c->has_last = true;
   // predecessor of this rank's FIRST frame of the batch: the previous rank's last frame of the SAME batch — or, for rank 0, the
   // last rank's last frame of the PREVIOUS batch (the previous call's gather; nothing on the first call)
   const uint8_t* pb = c->rank > 0 ? g + (size_t)(c->rank - 1) * blk : (gprev ? gprev + (size_t)(c->world - 1) * blk : nullptr);

@@ -581,11 +581,15 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
     return launch_match_mfma(m, (const int8_t*)m->d_expand[0], sb, 1, (const int8_t*)m->d_expand[0], sb, d_n, stride_rows, d_n - 1, stride_rows, d_prev_n,
                              nframes, d_idx, d_dist);
   }
-  constexpr int kSplit = 8, kQPL = 2;
-  dim3 grid((stride_rows + 64 * kQPL - 1) / (64 * kQPL), nframes);
+  // a few jobs (everything below the matrix-core threshold): favour wavefront count over per-wave efficiency, as the batch entry point does —
+  // one 2000 x 2000 job on <8, 2> occupies 16 workgroups for 39 us
   // train of job p >= 1 = frame p - 1: the base pointers are shifted back by one frame and never dereferenced for job 0
-  hipLaunchKernelGGL((k_match<kSplit, kQPL>), grid, dim3(64 * kSplit), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
-                     (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
+  if ((long long)nframes * stride_rows <= 16384)
+    hipLaunchKernelGGL((k_match<16, 1>), dim3((stride_rows + 63) / 64, nframes), dim3(1024), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
+                       (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
+  else   // DVS_MATCH_MFMA=0 with many jobs: the throughput shape
+    hipLaunchKernelGGL((k_match<8, 2>), dim3((stride_rows + 127) / 128, nframes), dim3(512), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
+                       (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }

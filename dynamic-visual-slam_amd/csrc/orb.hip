@@ -40,6 +40,7 @@ struct dvs_orb {
   int pf_idx = 0;
   hipEvent_t ev_level[DVS_MAX_LEVELS] = {};  // level l of the pyramid is complete (in-step chain beside FAST)
   bool overlap = true;
+  bool single_stream = false;              // dvs_orb_create_single_stream: no auxiliary / prefetch streams exist, overlap stays off
   int max_batch = 1;
   // ctor tables (ORBextractor.cpp:414-445)
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -320,12 +321,16 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     auto srcy = [&](int k, int y) { return std::min(std::max(yofs[G.lv[k].ytab + y], 0), G.lv[k - 1].h - 1); };  // top tap
     int maxBytes = 0;
     bool cascade_ok = true;
-    for (int ty = 0; ty < G.lv[1].h; ty += kPyrTileH)
-      for (int tx = 0; tx < G.lv[1].w; tx += kPyrTileW) {
+    // tile = the level-1 pixels a workgroup owns (results do not depend on the tiling).  Smaller tiles = more, shorter workgroups were
+    // measured for the few-frame case the cascade serves (profiles/r04_batch_sweep.json): 1 frame 0.057 -> 0.053 ms per step at 64 x 16,
+    // 8 frames 0.118 -> 0.142: its latency is the seven dependent levels, not the tile's size.  128 x 64 stays.
+    const int tileW = kPyrTileW, tileH = kPyrTileH;
+    for (int ty = 0; ty < G.lv[1].h; ty += tileH)
+      for (int tx = 0; tx < G.lv[1].w; tx += tileW) {
         PyrTile T{};
         int oxa[DVS_MAX_LEVELS], oxb[DVS_MAX_LEVELS], oya[DVS_MAX_LEVELS], oyb[DVS_MAX_LEVELS];
-        oxa[1] = tx; oxb[1] = std::min(tx + kPyrTileW, G.lv[1].w);
-        oya[1] = ty; oyb[1] = std::min(ty + kPyrTileH, G.lv[1].h);
+        oxa[1] = tx; oxb[1] = std::min(tx + tileW, G.lv[1].w);
+        oya[1] = ty; oyb[1] = std::min(ty + tileH, G.lv[1].h);
         for (int k = 2; k < nl; k++) {  // owner of a pixel = owner of its top-left source tap
           int a = 0, b;
           while (a < G.lv[k].w && srcx(k, a) < oxa[k - 1]) a++;
@@ -817,7 +822,11 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
 
 extern "C" {
 
-dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) {
+static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, dvs_orb** out);
+dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, false, out); }
+dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, true, out); }
+
+static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, dvs_orb** out) {
   DVS_ARG(params && out);
   *out = nullptr;
   DVS_ARG(params->nlevels >= 1 && params->nlevels <= DVS_MAX_LEVELS);
@@ -843,7 +852,8 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   // The switches of this handle, read once (see the struct).  DVS_NO_OVERLAP=1 = dvs_orb_set_overlap(h, 0) from the start: every
   // stage alone on the main stream.
   auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0;
+  h->single_stream = single_stream;
+  h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0 && !single_stream;
   h->env_cascade = env_int("DVS_CASCADE", -1);
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
@@ -859,8 +869,8 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
   // workgroups launched at the same moment on the main stream all become resident first — with the blur's workgroups dispatched
   // ahead of them some quad-tree workgroups started 90 us late and the kernel took 170 us instead of 110 (64 frames per step:
   // 0.628 -> 0.592 ms, neutral below 64)
-  bool ok = hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
-            hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  bool ok = single_stream || (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+                              hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) == hipSuccess);
   hipEvent_t* evs[] = {&h->ev_fork, &h->ev_blur, &h->ev_start, &h->ev_chain_gate, &h->ev_pf2[0], &h->ev_pf2[1], &h->ev_outs[0], &h->ev_outs[1],
                        &h->ev_oct, &h->ev_end};
   for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
@@ -878,8 +888,9 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
 void dvs_orb_destroy(dvs_orb* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  hipStream_t streams[] = {h->stream, h->aux_stream, h->pf_stream};
-  for (hipStream_t q : streams) if (q || q == h->stream) (void)hipStreamSynchronize(q);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+  if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
   h->timer.resolve();
   free_workspace(h);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -903,9 +914,10 @@ dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
 dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
+  if (on && h->single_stream) { set_error("dvs_orb_set_overlap: this extractor was created with one stream only"); return DVS_ERR_UNSUPPORTED; }
   DVS_HIP(hipStreamSynchronize(h->stream));
-  DVS_HIP(hipStreamSynchronize(h->aux_stream));
-  DVS_HIP(hipStreamSynchronize(h->pf_stream));
+  if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
   h->pf_valid = false; h->pf_joined = false;
   h->out_pending = false;   // everything, a deferred descriptor stage included, has completed above
   h->overlap = on != 0;
@@ -925,7 +937,7 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->out_pending) { DVS_HIP(hipStreamSynchronize(h->aux_stream)); h->out_pending = false; }   // a deferred descriptor stage
-  DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
+  if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
   return DVS_OK;
 }
 

@@ -24,6 +24,16 @@ class OrbParams(C.Structure):
                 ("min_th_fast", C.c_int32), ("gauss_kernel", C.c_int32 * 7), ("max_batch", C.c_int32)]
 
 
+class PipelineParams(C.Structure):
+    _fields_ = [("orb", OrbParams), ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("nsets", C.c_int32), ("pipelined", C.c_int32),
+                ("lanes", C.c_int32)]
+
+
+class PipelineSet(C.Structure):
+    _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("d_n", C.c_void_p), ("d_idx", C.c_void_p), ("d_dist", C.c_void_p),
+                ("ev_extracted", C.c_void_p), ("ev_matched", C.c_void_p), ("capacity", C.c_int32)]
+
+
 class KeyframeHeader(C.Structure):
     _fields_ = [("stamp_sec", C.c_int32), ("stamp_nanosec", C.c_uint32), ("frame_id", C.c_char_p), ("keyframe_id", C.c_uint64),
                 ("translation", C.c_double * 3), ("rotation_xyzw", C.c_double * 4)]
@@ -118,6 +128,21 @@ def lib():
     L.dvs_boundary_block_bytes.argtypes = [i32]; L.dvs_boundary_block_bytes.restype = sz
     L.dvs_exchange_boundary.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.dvs_comm_all_gather.argtypes = [vp, vp, vp, vp, sz]
+    L.dvs_pipeline_create.argtypes = [C.POINTER(PipelineParams), i32, C.POINTER(vp)]
+    L.dvs_pipeline_destroy.argtypes = [vp]; L.dvs_pipeline_destroy.restype = None
+    L.dvs_pipeline_attach_comm.argtypes = [vp, vp]
+    L.dvs_pipeline_step.argtypes = [vp, vp, vp, i32]
+    L.dvs_pipeline_flush.argtypes = [vp]
+    L.dvs_pipeline_synchronize.argtypes = [vp]
+    L.dvs_pipeline_reset.argtypes = [vp]
+    L.dvs_pipeline_steps.argtypes = [vp]; L.dvs_pipeline_steps.restype = C.c_int64
+    L.dvs_pipeline_get_set.argtypes = [vp, C.c_int64, C.POINTER(PipelineSet)]
+    L.dvs_pipeline_lanes.argtypes = [vp]
+    L.dvs_pipeline_nsets.argtypes = [vp]
+    L.dvs_orb_create_single_stream.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
+    L.dvs_pipeline_extractor.argtypes = [vp]; L.dvs_pipeline_extractor.restype = vp
+    L.dvs_pipeline_matcher.argtypes = [vp]; L.dvs_pipeline_matcher.restype = vp
+    L.dvs_pipeline_match_stream.argtypes = [vp]; L.dvs_pipeline_match_stream.restype = vp
     L.dvs_find_fundamental_ransac.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, C.c_uint64, vp, vp, C.POINTER(i32)]
     L.dvs_solve_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_uint64, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_find_fundamental_cv.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, vp, vp, C.POINTER(i32), C.POINTER(i32)]
@@ -159,7 +184,7 @@ def device_count():
     return lib().dvs_device_count()
 
 
-PROFILED_SOURCES = ("orb.hip", "orb_kernels.h", "orb_geom.h", "orb_device_common.h", "lsort.h", "glibc_sincosf.h", "brief_pattern.inc", "match.hip",
+PROFILED_SOURCES = ("pipeline.hip", "orb.hip", "orb_kernels.h", "orb_geom.h", "orb_device_common.h", "lsort.h", "glibc_sincosf.h", "brief_pattern.inc", "match.hip",
                     "common.h")
 
 

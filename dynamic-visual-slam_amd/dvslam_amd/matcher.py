@@ -18,9 +18,17 @@ class BFMatcher:
             check(self._L.dvs_matcher_create_on_stream(device, stream, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_handle(cls, handle):
+        """non-owning view of a dvs_matcher* that lives inside another handle (dvs_pipeline_matcher)"""
+        m = cls.__new__(cls)
+        m._L, m._h, m._owned = lib(), C.c_void_p(handle), False
+        return m
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.dvs_matcher_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.dvs_matcher_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -23,9 +23,19 @@ class ORBextractor:
         self.nfeatures, self.nlevels, self.scaleFactor, self.device, self.max_batch = nfeatures, nlevels, scaleFactor, device, max_batch
         self.capacity = self._L.dvs_orb_max_keypoints(self._h)
 
+    @classmethod
+    def from_handle(cls, handle, nfeatures, nlevels, scaleFactor, device, max_batch):
+        """non-owning view of a dvs_orb* that lives inside another handle (dvs_pipeline_extractor)"""
+        o = cls.__new__(cls)
+        o._L, o._h, o._owned = lib(), C.c_void_p(handle), False
+        o.nfeatures, o.nlevels, o.scaleFactor, o.device, o.max_batch = nfeatures, nlevels, scaleFactor, device, max_batch
+        o.capacity = o._L.dvs_orb_max_keypoints(o._h)
+        return o
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.dvs_orb_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.dvs_orb_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -93,6 +93,10 @@ typedef struct dvs_orb_params {
 #define DVS_MAX_LEVELS 16
 
 dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out);
+/* the same extractor with ONE stream for good: every stage runs in order on the handle's stream, no auxiliary / prefetch streams are
+ * created (every HIP stream is a hardware queue, and a process has four) and dvs_orb_set_overlap(h, 1) is refused.  What the lanes of
+ * dvs_pipeline are made of; results are identical. */
+dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out);
 void dvs_orb_destroy(dvs_orb* h);
 /* capacity a caller must provide per frame: nfeatures + 3 * nlevels (a level may return quota + 2, ORBextractor.cpp:746-747) */
 int32_t dvs_orb_max_keypoints(const dvs_orb* h);
@@ -245,6 +249,67 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
                                  const uint8_t** d_prev_desc, const int32_t** d_prev_n);
 /* plain all-gather of bytes_per_rank bytes per rank (level-sharded extraction gathers its per-level blocks with it) */
 dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, void* d_recv, size_t bytes_per_rank);
+
+/* ======================= the streaming step: extract batch i + match batch i - 1 ================= */
+/* The reference's frame loop (frontend.cpp:1084-1123: gray -> (*orb_extractor_)(...) -> orb_matcher_->match(current, previous)) for a
+ * host that holds its frames in device memory B at a time.  ONE call per step enqueues the whole software-pipelined schedule that
+ * bench.py times and tests/test_gpu_pipeline.py checks frame by frame against the oracle:
+ *   - the extraction of batch i on the extractor's streams (next batch's pyramid beside FAST, blur beside the quad-tree, the
+ *     descriptor stage deferred beside the NEXT step's FAST);
+ *   - the B match jobs of batch i - 1 (frame t against t - 1; frame 0 against the last frame of batch i - 2, or against the frame a
+ *     communicator's boundary exchange returns) on the match stream, released behind batch i's FAST;
+ *   - `nsets` (>= 3 when pipelined) output sets in rotation, the extraction of step i + nsets gated on the last reader of set i.
+ * pipelined = 0: the plain schedule — every batch's match behind its own extraction on one stream (nsets >= 1).
+ * Small batches (lanes >= 2; automatic for batch <= DVS_PIPELINE_LANE_BATCH): the machine is mostly idle within one step and the
+ * step is the latency of its kernel chain, so `lanes` independent extractor / matcher pairs, one stream each, take the steps in turn
+ * — step i runs serially on lane i % lanes (pyramid -> FAST -> quad-tree -> blur -> descriptors -> its own match, no internal
+ * forks), up to `lanes` steps in flight, ordered only where data flows: the match of batch i waits for batch i - 1's descriptors
+ * (another lane), the extraction of step i + nsets for the readers of set i.  Results are those of any other schedule, bit for bit.
+ * The handle owns extractors, matchers, streams, events and the output sets; nothing is allocated per step.  Not thread-safe. */
+typedef struct dvs_pipeline dvs_pipeline;
+typedef struct dvs_pipeline_params {
+  dvs_orb_params orb;   /* max_batch is ignored (= batch) */
+  int32_t batch;        /* B frames per step, tight rows: frame f at d_imgs + f * rows * cols */
+  int32_t rows, cols;
+  int32_t nsets;        /* output sets in rotation; 0 = 4 (lane schedule: two per lane); lanes are reduced to a divisor of nsets */
+  int32_t pipelined;    /* 1: the software pipeline described above; 0: serial match */
+  int32_t lanes;        /* pipelined only.  0 = by batch size (3 up to DVS_PIPELINE_LANE_BATCH frames, else 1); 1 = the two-stream
+                           software pipeline; 2..DVS_PIPELINE_MAX_LANES = lanes */
+} dvs_pipeline_params;
+#define DVS_PIPELINE_MAX_LANES 4     /* HIP streams beyond four share hardware queues on this part */
+#define DVS_PIPELINE_LANE_BATCH 4    /* lanes = 0: batches up to this size run on lanes (measured: 8 frames and more tie or lose) */
+/* results of one step's batch (device pointers into the handle's output set; valid until step + nsets is enqueued) */
+typedef struct dvs_pipeline_set {
+  const dvs_keypoint* d_kps;  /* [B][capacity] */
+  const uint8_t* d_desc;      /* [B][capacity][32] */
+  const int32_t* d_n;         /* [B] */
+  const int32_t* d_idx;       /* [B][capacity] trainIdx of frame f's keypoints in frame f - 1 */
+  const int32_t* d_dist;      /* [B][capacity] */
+  void* ev_extracted;         /* hipEvent_t: keypoints / descriptors / counts complete */
+  void* ev_matched;           /* hipEvent_t: the batch's match jobs complete (recorded when they are enqueued: one step late if pipelined) */
+  int32_t capacity;
+} dvs_pipeline_set;
+enum { DVS_PIPELINE_NO_MATCH = 1 };   /* step flags: extraction only (per-stage timing passes) */
+dvs_status dvs_pipeline_create(const dvs_pipeline_params* params, int32_t device, dvs_pipeline** out);
+void dvs_pipeline_destroy(dvs_pipeline* p);
+/* frames sharded contiguously over ranks: frame 0 of a batch is matched against the frame dvs_exchange_boundary
+ * returns (one all-gather per global batch on the match stream) instead of the previous batch's last frame.  NULL detaches. */
+dvs_status dvs_pipeline_attach_comm(dvs_pipeline* p, dvs_comm* comm);
+/* step i: d_imgs = this step's batch, d_next_imgs = the batch the NEXT step will pass (its pyramid is built ahead), NULL if unknown */
+dvs_status dvs_pipeline_step(dvs_pipeline* p, const uint8_t* d_imgs, const uint8_t* d_next_imgs, int32_t flags);
+/* the match of the last extracted batch (the pipelined schedule runs it one step late); no-op for the serial schedule */
+dvs_status dvs_pipeline_flush(dvs_pipeline* p);
+dvs_status dvs_pipeline_synchronize(dvs_pipeline* p);
+/* synchronise and restart the sequence at step 0 (the next batch has no predecessor) */
+dvs_status dvs_pipeline_reset(dvs_pipeline* p);
+int64_t dvs_pipeline_steps(const dvs_pipeline* p);   /* steps enqueued since creation / reset */
+dvs_status dvs_pipeline_get_set(const dvs_pipeline* p, int64_t step, dvs_pipeline_set* out);
+/* the handles inside (stage timing, overlap switch, stream for a caller's own events); owned by the pipeline */
+int32_t dvs_pipeline_nsets(const dvs_pipeline* p);    /* output sets in rotation */
+int32_t dvs_pipeline_lanes(const dvs_pipeline* p);    /* 0: serial schedule, 1: two-stream software pipeline, >= 2: lanes */
+dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p);      /* lane 0's */
+dvs_matcher* dvs_pipeline_matcher(dvs_pipeline* p);
+void* dvs_pipeline_match_stream(dvs_pipeline* p);
 
 /* ======================= glue either side of the path =============== */
 /* A dvs_matcher handle is the context (stream + scratch).  Host pointers unless the name says _device. */

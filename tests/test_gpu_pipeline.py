@@ -90,7 +90,16 @@ def test_pipelined_step_with_the_lds_free_matrix_core_blur(gpu, oracle, monkeypa
     _run_shape(oracle, 5, 480, 640, 800, 3, 8)
 
 
-def _run_shape(oracle, B, rows, cols, nf, nsets, steps):
+@pytest.mark.parametrize("B,lanes,nsets,steps", [(1, 4, 4, 11), (2, 2, 4, 9), (8, 4, 4, 7), (8, 1, 3, 5), (3, 3, 3, 8), (16, 2, 6, 8), (8, 3, 0, 11), (1, 0, 0, 13)])
+def test_lane_schedule_for_small_batches(gpu, oracle, B, lanes, nsets, steps):
+    """the small-batch schedule (dvs_pipeline_params::lanes): whole steps in flight on `lanes` extractor / matcher pairs, cross-lane
+    order by events only — every resident frame and match job against the oracle, at 1280x720 / 2000 like the timed configuration;
+    (8, 1): the two-stream software pipeline forced at a lane-sized batch"""
+    p = _run_shape(oracle, B, 720, 1280, 2000, nsets, steps, lanes=lanes)
+    assert p == (lanes or 3)                                              # lanes = 0: three lanes (and six sets) up to 4 frames per step
+
+
+def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0):
     from dvslam_amd import _lib
     from dvslam_amd.pipeline import StreamingPipeline
     NB = 3
@@ -98,7 +107,8 @@ def _run_shape(oracle, B, rows, cols, nf, nsets, steps):
     o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
     ref = [[o.extract(f) for f in batch] for batch in frames]
     d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
-    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True)
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True, lanes=lanes)
+    used, nsets = pipe.lanes, pipe.nsets
     for i in range(steps):
         pipe.step(d_img[i % NB].ptr, d_img[(i + 1) % NB].ptr)
     pipe.flush(); pipe.synchronize()
@@ -113,6 +123,7 @@ def _run_shape(oracle, B, rows, cols, nf, nsets, steps):
             i2, d2 = oracle.match(ref[i % NB][f][2], t[2])
             assert (idx[f, :n[f]] == i2).all() and (dist[f, :n[f]] == d2).all(), (i, f)
     pipe.close()
+    return used
 
 
 def test_serial_schedule_against_oracle(gpu, oracle):
@@ -153,10 +164,19 @@ def test_frame_sharded_loopback_equals_single_rank(gpu, oracle):
     one.flush(); one.synchronize()
     want = [(one.outputs(i), one.matches(i)) for i in range(STEPS)]
     one.close()
-    # 8 logical ranks, each with its own handles, streams, communicator and host thread
-    pipes = [StreamingPipeline(B, ROWS, COLS, NF, nsets=STEPS, pipelined=True) for _ in range(WORLD)]
-    comms = dvdist.Comm.loopback(0, WORLD)
     d_rank = [[_lib.DeviceBuffer(gb[g][r * B:(r + 1) * B].nbytes).upload(gb[g][r * B:(r + 1) * B]) for g in range(NG)] for r in range(WORLD)]
+    for lanes in (1, 2):    # the two-stream software pipeline per rank; the lane schedule (strong-scaling form: 8 frames per rank), whose
+        _loopback_ranks(oracle, want, d_rank, WORLD, B, NG, STEPS, lanes)    # successive exchanges run on different streams
+
+
+def _loopback_ranks(oracle, want, d_rank, WORLD, B, NG, STEPS, lanes):
+    from dvslam_amd import dist as dvdist
+    from dvslam_amd.pipeline import StreamingPipeline
+    G = WORLD * B
+    # 8 logical ranks, each with its own handles, streams, communicator and host thread
+    pipes = [StreamingPipeline(B, ROWS, COLS, NF, nsets=STEPS, pipelined=True, lanes=lanes) for _ in range(WORLD)]
+    assert all(p.lanes == lanes for p in pipes)
+    comms = dvdist.Comm.loopback(0, WORLD)
     for r in range(WORLD):
         assert comms[r].rank == r and comms[r].world == WORLD
         pipes[r].attach_comm(comms[r])
