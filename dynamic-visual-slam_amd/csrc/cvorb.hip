@@ -17,6 +17,9 @@
 #include <new>
 #include <vector>
 #include "common.h"
+#ifdef DVS_TEST_HOOKS
+#include "../../include/dvslam_hip_test.h"
+#endif
 #include "glibc_sincosf.h"
 #include "orb_device_common.h"
 
@@ -366,10 +369,12 @@ __global__ __launch_bounds__(256) void k_cv_describe(CvGeom G, const u8* __restr
 }
 
 // test hook: wave_retain_best alone
+#ifdef DVS_TEST_HOOKS
 __global__ __launch_bounds__(64) void k_test_retain(unsigned long long* a, int n, int n_points, int* Lp, int* Rp, int* out_n) {
   const int r = wave_retain_best(a, n, n_points, Lp, Rp);
   if (threadIdx.x == 0) *out_n = r;
 }
+#endif
 
 }  // namespace
 }  // namespace dvs
@@ -591,6 +596,7 @@ dvs_status dvs_cvorb_get_level(dvs_cvorb* h, int32_t level, int32_t blurred, uin
   return DVS_OK;
 }
 
+#ifdef DVS_TEST_HOOKS   // libdvslam_hip_test.so only (include/dvslam_hip_test.h)
 // test hook: KeyPointsFilter::retainBest on bare responses through the kernel's wavefront routine; perm[i] = original index
 dvs_status dvs_test_retain_best_device(const float* responses, int32_t n, int32_t n_points, int32_t* perm, int32_t* n_kept) {
   DVS_ARG(n >= 0 && n_kept && (n == 0 || (responses && perm)));
@@ -641,5 +647,7 @@ void dvs_test_retain_best_host(const float* responses, int32_t n, int32_t n_poin
   *n_kept = kept;
   for (int i = 0; i < kept; i++) perm[i] = (int)(uint32_t)v[i];
 }
+
+#endif  // DVS_TEST_HOOKS
 
 }  // extern "C"

@@ -10,6 +10,9 @@
 #include <chrono>
 #include <vector>
 #include "common.h"
+#ifdef DVS_TEST_HOOKS
+#include "../../include/dvslam_hip_test.h"
+#endif
 #include "orb_kernels.h"
 
 namespace dvs {
@@ -103,6 +106,28 @@ struct dvs_orb {
   int export_seq = 0;
   size_t octree_smem = 0;
   int octree_nmax = 0, octree_ptscap = 0;
+  // The quad-tree off the main stream (dvs_orb_set_async_quadtree): it runs on the auxiliary stream beside the NEXT call's FAST.  FAST then
+  // writes the candidate lists of two sets in turn; launches are graded by level class — the dynamic LDS of a dispatch is uniform, so the
+  // small levels get a launch of their own with their own (smaller) node / point capacities instead of the level-0 footprint.
+  bool async_oct = false, last_async = false;
+  hipStream_t tail_stream = nullptr;       // dvs_orb_set_tail_stream: the descriptor stage of an asynchronous call runs there (the caller's match stream)
+  // ... and its blur on the MAIN stream ahead of FAST (main: blur + FAST, prefetch: level chain, auxiliary: quad-tree, tail: descriptors +
+  // the caller's match — four streams of similar length for batches whose kernels do not fill the machine).  The blurred block then exists
+  // three times: blur k + 1 rewrites the block descriptor stage k - 2 read, which the level chain FAST k + 1 waited for was gated on.
+  u8* d_blur3[3] = {nullptr, nullptr, nullptr};
+  int bset = 0;
+  // THREE candidate sets in turn (the second and third allocated on first use): FAST k + 1 writes while tree k reads, and the level chain
+  // of call k + 2 — launched in call k + 1, ahead of FAST k + 1 — is gated on tree k - 1, the last reader of the set FAST k + 2 will write:
+  // a tree that finished a whole step ago (with two sets the gate would be the tree still running beside that FAST)
+  uint32_t* d_cand2[3] = {nullptr, nullptr, nullptr};
+  int* d_cellcount2[3] = {nullptr, nullptr, nullptr};
+  int cset = 0;
+  hipEvent_t ev_octdone[3] = {nullptr, nullptr, nullptr};
+  bool octdone_valid[3] = {false, false, false};
+  int oct_ncls = 0;                        // level classes of the graded launches (0 = no grading): class c = levels [oct_l0[c], oct_l0[c + 1])
+  int oct_l0[4] = {0, 0, 0, 0};
+  size_t oct_smem_cls[3] = {0, 0, 0};
+  int oct_nmax_cls[3] = {0, 0, 0}, oct_ptscap_cls[3] = {0, 0, 0};
   int last_nimg = 0;
   ImgSrc last_src{};
   StageTimer timer;
@@ -111,10 +136,18 @@ struct dvs_orb {
 namespace {
 
 void free_workspace(dvs_orb* h) {
-  void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur,
-                  h->d_pyr_alt, h->d_pyr_3rd, h->d_cand, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_cellcount, h->d_celloff, h->d_candtotal,
+  void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur3[0],
+                  h->d_pyr_alt, h->d_pyr_3rd, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_celloff, h->d_candtotal,
                   h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_kps, h->d_desc, h->d_nout, h->d_ticket};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int k = 1; k < 3; k++) { if (h->d_blur3[k]) (void)hipFree(h->d_blur3[k]); h->d_blur3[k] = nullptr; }   // ([0] = the workspace's block, freed above)
+  h->d_blur3[0] = nullptr; h->bset = 0;
+  for (int k = 0; k < 3; k++) {   // (set 0 is the pair allocated with the workspace; h->d_cand / h->d_cellcount point at the set in use)
+    if (h->d_cand2[k]) (void)hipFree(h->d_cand2[k]);
+    if (h->d_cellcount2[k]) (void)hipFree(h->d_cellcount2[k]);
+    h->d_cand2[k] = nullptr; h->d_cellcount2[k] = nullptr; h->octdone_valid[k] = false;
+  }
+  h->cset = 0;
   void* pinned[] = {h->h_kps, h->h_desc, h->h_nout, h->h_seq};
   for (void* p : pinned) if (p) (void)hipHostFree(p);
   h->h_seq = nullptr; h->d_ticket = nullptr;
@@ -481,6 +514,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
+  if (h->out_pending) DVS_HIP(hipEventSynchronize(h->ev_out));   // a deferred descriptor stage on the tail stream
   h->out_pending = false; h->pf_joined = false; h->pf_valid = false;
   free_workspace(h);
   Geom G;
@@ -543,6 +577,28 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   }
   h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4) + (size_t)h->octree_ptscap * 8;
   DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
+  h->d_cand2[0] = h->d_cand; h->d_cellcount2[0] = h->d_cellcount; h->cset = 0;
+  h->d_blur3[0] = h->d_blur; h->bset = 0;
+  {
+    // level classes for graded launches ({L0, L1}, {L2, L3}, {L4 ..}): node capacity from the class's largest quota, point capacity =
+    // level 0's scaled by the level's share of pixels (a level whose candidates exceed it keeps them in HBM — slower, never wrong)
+    const long per_node = (long)(2 * sizeof(QNode) + 8 + 16 + 4 * 4);
+    h->oct_ncls = G.nlevels >= 6 ? 3 : (G.nlevels >= 4 ? 2 : 0);
+    h->oct_l0[0] = 0; h->oct_l0[1] = 2; h->oct_l0[2] = h->oct_ncls == 3 ? 4 : G.nlevels; h->oct_l0[3] = G.nlevels;
+    for (int c = 0; c < h->oct_ncls; c++) {
+      const int l0 = h->oct_l0[c], l1 = h->oct_l0[c + 1];
+      int nmax = 0; long pts = 0;
+      for (int l = l0; l < l1; l++) {
+        nmax = std::max(nmax, std::max(G.lv[l].N + 3, 4 * G.lv[l].nIni) + 8);
+        const double share = (double)G.lv[l].w * G.lv[l].h / ((double)G.lv[0].w * G.lv[0].h);
+        pts = std::max(pts, std::min<long>(G.lv[l].ptsCap, (long)(share * h->octree_ptscap) + 64));
+      }
+      h->oct_nmax_cls[c] = nmax;
+      h->oct_ptscap_cls[c] = (int)std::min<long>(pts, h->octree_ptscap);
+      h->oct_smem_cls[c] = (size_t)nmax * per_node + (size_t)h->oct_ptscap_cls[c] * 8;
+      if (h->oct_smem_cls[c] > h->octree_smem) { h->oct_smem_cls[c] = h->octree_smem; h->oct_nmax_cls[c] = h->octree_nmax; h->oct_ptscap_cls[c] = h->octree_ptscap; }
+    }
+  }
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
   DVS_HIP(hipFuncSetAttribute((const void*)k_fast_wave<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G.fastWaveLds));
@@ -626,6 +682,8 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
     if (!gate) { gate = h->ev_chain_gate; DVS_HIP(hipEventRecord(gate, h->stream)); }
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
   }
+  // asynchronous quad-trees: the FAST that follows this chain writes candidate set cset + 1, last read by the tree of two calls ago
+  if (h->async_oct && h->octdone_valid[(h->cset + 1) % 3]) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_octdone[(h->cset + 1) % 3], 0));
   ImgSrc nsrc = src;
   nsrc.img0 = next_img0;
   h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
@@ -660,6 +718,27 @@ void launch_blur(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t bst, bool 
     hipLaunchKernelGGL(k_blur, dim3(G.blurTiles, nimg), dim3(256), 0, bst, h->d_geom, h->d_tiles, src, h->d_blur);
 }
 
+// quad-tree of every (frame, level) on `qs`.  graded: one launch per level class with that class's capacities (LDS) instead of level 0's
+void launch_octree(dvs_orb* h, int nimg, hipStream_t qs, uint32_t levelMask, bool graded) {
+  const Geom& G = h->geom;
+  if (graded && h->oct_ncls >= 2) {
+    for (int c = 0; c < h->oct_ncls; c++) {
+      const int l0 = h->oct_l0[c], nl = h->oct_l0[c + 1] - l0;
+      if (nl <= 0) continue;
+      // the first class holds the long workgroups (levels 0 and 1): 512 threads each; the others 256
+      hipLaunchKernelGGL(k_octree, dim3(nimg, nl), dim3(c == 0 ? kOctTMax : kOctT), h->oct_smem_cls[c], qs, h->d_geom, h->d_cand, h->d_cellcount, h->d_celloff,
+                         h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->oct_nmax_cls[c], h->oct_ptscap_cls[c], levelMask, l0);
+    }
+    return;
+  }
+  // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames); beyond,
+  // two 256-thread workgroups per CU run beside the blur and a pipelined caller's match, and the wave slots 512 threads hold cost
+  // those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 / 384 threads: 0.729 / 0.690)
+  const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
+  hipLaunchKernelGGL(k_octree, dim3(nimg, G.nlevels), dim3(oct_t), h->octree_smem, qs, h->d_geom, h->d_cand, h->d_cellcount,
+                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, levelMask, 0);
+}
+
 // Enqueue the whole extraction of `nimg` frames whose level 0 is described by `src`.  Schedule:
 //   main stream      [wait: this batch's chain]  FAST ............  quad-tree ......................  [descriptors, if not deferred]
 //   prefetch stream  next batch's level chain (beside FAST)
@@ -688,6 +767,26 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   // this call defers its own descriptor stage: outputs by event, stage on the auxiliary stream, main stream not joined
   const bool will_defer = h->overlap && may_defer && h->output_event && h->defer_outputs && !sharded;
+  // quad-tree off the main stream: the pipelined pattern only (this call's pyramid prefetched, its descriptor stage deferred).  FAST
+  // writes the other candidate set: the previous call's tree may still be reading its own.  (Any other call joined the previous call's
+  // auxiliary work above — its tree included — and keeps the current set.)
+  const bool async = h->async_oct && prefetched && will_defer && aligned0;
+  if (async) {
+    h->cset = (h->cset + 1) % 3;
+    if (!h->d_cand2[h->cset]) {
+      DVS_HIP(hipMalloc((void**)&h->d_cand2[h->cset], (size_t)h->max_batch * G.candPerFrame * 4));
+      DVS_HIP(hipMalloc((void**)&h->d_cellcount2[h->cset], (size_t)h->max_batch * G.totalCells * 4));
+    }
+    h->d_cand = h->d_cand2[h->cset]; h->d_cellcount = h->d_cellcount2[h->cset];
+    if (h->tail_stream) {
+      h->bset = (h->bset + 1) % 3;
+      if (!h->d_blur3[h->bset]) DVS_HIP(hipMalloc((void**)&h->d_blur3[h->bset], (size_t)h->max_batch * G.frameBytes));
+      h->d_blur = h->d_blur3[h->bset];
+    }
+  } else if (h->last_async) {
+    DVS_HIP(hipStreamWaitEvent(st, h->ev_octdone[h->cset], 0));   // this call's FAST rewrites the set the previous call's tree reads
+  }
+  h->last_async = async;
 
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192)
   //    prefetched: nothing to build (non-deferred calls joined the chain through their blur — no barrier packet at all then);
@@ -733,6 +832,15 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     if (h->pf_valid && !sharded && !(h->defer_outputs && h->output_event)) { DVS_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_prefetch, 0)); h->pf_joined = true; }
   }
 
+  // (tail mode: this call's blur first — it needs the pyramid only, which the main stream has just joined; the one record behind FAST
+  // then covers it too)
+  const bool tail = async && h->tail_stream != nullptr;
+  if (tail) {
+    h->timer.begin(DVS_STAGE_BLUR, st);
+    launch_blur(h, src, nimg, st, false);
+    h->timer.end(st);
+  }
+
   // 2. FAST per cell.  One launch over all levels; with the in-step chain one launch per level, each gated on its own level only
   //    (the small tail levels — each < 1/16 of the cells — share one); a level-sharded call launches its levels.
   if (ov) {
@@ -766,33 +874,40 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   //    it takes the next of the three level keypoint sets: stages k - 1 and k - 2 may still read theirs; stage k - 3 wrote its event
   //    before the level chain of THIS batch started, which this call's FAST waited for.
   if (pend) { h->lset = (h->lset + 1) % 3; h->d_lvlkp = h->d_lvlkp3[h->lset]; h->d_lvlcount = h->d_lvlcount3[h->lset]; }
-  // 512-thread workgroups while there is at most one of them per CU (<= 32 frames of 8 levels: +9..11 % at 8 / 16 / 32 frames); beyond,
-  // two 256-thread workgroups per CU run beside the blur and a pipelined caller's match, and the wave slots 512 threads hold cost
-  // those more than the shorter tree returns (64 frames: 0.681 -> 0.664 ms per step; 128 / 384 threads: 0.729 / 0.690)
-  const int oct_t = h->env_oct_threads ? h->env_oct_threads : (G.nlevels * nimg <= 256 ? kOctTMax : kOctT);
-  h->timer.begin(DVS_STAGE_OCTREE, st);
-  hipLaunchKernelGGL(k_octree, dim3(nimg, G.nlevels), dim3(oct_t), h->octree_smem, st, h->d_geom, h->d_cand, h->d_cellcount,
-                     h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask);
-  h->timer.end(st);
+  //    Asynchronous (dvs_orb_set_async_quadtree, pipelined callers): on the auxiliary stream behind this call's FAST — nothing on the main
+  //    stream needs it, so the next call's FAST follows this one's immediately and the tree runs beside it.
+  hipStream_t qs = async ? bst : st;
+  if (async) DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
+  h->timer.begin(DVS_STAGE_OCTREE, qs);
+  launch_octree(h, nimg, qs, src.levelMask, async && G.nlevels * nimg > 256);
+  h->timer.end(qs);
+  if (async) { DVS_HIP(hipEventRecord(h->ev_octdone[h->cset], qs)); h->octdone_valid[h->cset] = true; }
 
   // 4. blur
-  if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
+  if (async) {}   // (the auxiliary stream already waited for FAST in front of the quad-tree)
+  else if (bst != st) DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
   else if (h->guard_event) DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
   hipEvent_t late_guard = bst != st ? h->guard_event : nullptr;   // still set only for a deferring call (see above)
   h->guard_event = nullptr;   // one-shot
-  h->timer.begin(DVS_STAGE_BLUR, bst);
-  launch_blur(h, src, nimg, bst, cascade);
-  h->timer.end(bst);
+  if (!tail) {
+    h->timer.begin(DVS_STAGE_BLUR, bst);
+    launch_blur(h, src, nimg, bst, cascade);
+    h->timer.end(bst);
+  }
 
   // 5. orientation + descriptors + output records
   hipStream_t dst = st;
   if (will_defer) {
     // the stage follows the blur on the auxiliary stream and the main stream is NOT joined: the next call's FAST (vector-ALU bound,
     // light on memory) starts at once and runs beside it (fetch-bound).  Consumers order themselves on the caller's output event.
-    dst = bst;
-    DVS_HIP(hipEventRecord(h->ev_oct, st));
-    DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
-    if (late_guard) DVS_HIP(hipStreamWaitEvent(bst, late_guard, 0));   // the caller's readers of the output buffers
+    dst = tail ? h->tail_stream : bst;
+    if (tail) {     // the quad-tree's own event: the tree followed FAST, FAST followed the blur
+      DVS_HIP(hipStreamWaitEvent(dst, h->ev_octdone[h->cset], 0));
+    } else if (!async) {   // (asynchronous: the quad-tree precedes on this very stream)
+      DVS_HIP(hipEventRecord(h->ev_oct, st));
+      DVS_HIP(hipStreamWaitEvent(bst, h->ev_oct, 0));
+    }
+    if (late_guard) DVS_HIP(hipStreamWaitEvent(dst, late_guard, 0));   // the caller's readers of the output buffers
   } else if (bst != st) {
     DVS_HIP(hipEventRecord(h->ev_blur, bst));
     DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));
@@ -872,7 +987,7 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   bool ok = single_stream || (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
                               hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) == hipSuccess);
   hipEvent_t* evs[] = {&h->ev_fork, &h->ev_blur, &h->ev_start, &h->ev_chain_gate, &h->ev_pf2[0], &h->ev_pf2[1], &h->ev_outs[0], &h->ev_outs[1],
-                       &h->ev_oct, &h->ev_end};
+                       &h->ev_oct, &h->ev_end, &h->ev_octdone[0], &h->ev_octdone[1], &h->ev_octdone[2]};
   for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l < params->nlevels; l++) ok = ok && hipEventCreateWithFlags(&h->ev_level[l], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -895,7 +1010,8 @@ void dvs_orb_destroy(dvs_orb* h) {
   free_workspace(h);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
-  hipEvent_t evs[] = {h->ev_fork, h->ev_blur, h->ev_start, h->ev_chain_gate, h->ev_pf2[0], h->ev_pf2[1], h->ev_outs[0], h->ev_outs[1], h->ev_oct, h->ev_end};
+  hipEvent_t evs[] = {h->ev_fork, h->ev_blur, h->ev_start, h->ev_chain_gate, h->ev_pf2[0], h->ev_pf2[1], h->ev_outs[0], h->ev_outs[1], h->ev_oct, h->ev_end,
+                      h->ev_octdone[0], h->ev_octdone[1], h->ev_octdone[2]};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -919,8 +1035,30 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
   h->pf_valid = false; h->pf_joined = false;
+  if (h->out_pending) DVS_HIP(hipEventSynchronize(h->ev_out));
   h->out_pending = false;   // everything, a deferred descriptor stage included, has completed above
   h->overlap = on != 0;
+  return DVS_OK;
+}
+dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on) {
+  DVS_ARG(h);
+  if (on && h->single_stream) { set_error("dvs_orb_set_async_quadtree: this extractor was created with one stream only"); return DVS_ERR_UNSUPPORTED; }
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
+  if (h->out_pending) DVS_HIP(hipEventSynchronize(h->ev_out));
+  h->out_pending = false; h->last_async = false;
+  h->async_oct = on != 0;
+  return DVS_OK;
+}
+dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
+  DVS_ARG(h);
+  DVS_HIP(hipSetDevice(h->device));
+  DVS_HIP(hipStreamSynchronize(h->stream));
+  if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  if (h->out_pending) { DVS_HIP(hipEventSynchronize(h->ev_out)); h->out_pending = false; }
+  h->tail_stream = (hipStream_t)hip_stream;
   return DVS_OK;
 }
 dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
@@ -936,7 +1074,7 @@ dvs_status dvs_orb_synchronize(dvs_orb* h) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
-  if (h->out_pending) { DVS_HIP(hipStreamSynchronize(h->aux_stream)); h->out_pending = false; }   // a deferred descriptor stage
+  if (h->out_pending) { DVS_HIP(hipEventSynchronize(h->ev_out)); h->out_pending = false; }   // a deferred descriptor stage (auxiliary or tail stream)
   if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));  // an announced next batch's pyramid may still be reading the caller's images
   return DVS_OK;
 }
@@ -1178,6 +1316,7 @@ dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32
   return DVS_OK;
 }
 
+#ifdef DVS_TEST_HOOKS   // libdvslam_hip_test.so only (include/dvslam_hip_test.h)
 // ---- host-logic test hooks (no GPU needed): the introsort replica and the glibc sincosf restatement
 void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm) {
   std::vector<unsigned long long> v(n);
@@ -1229,5 +1368,7 @@ dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t
   }
   return DVS_OK;
 }
+
+#endif  // DVS_TEST_HOOKS
 
 }  // extern "C"

@@ -1164,6 +1164,7 @@ __device__ __forceinline__ void qt_sort_block(unsigned long long* a, int m, int*
   __syncthreads();
 }
 
+#ifdef DVS_TEST_HOOKS
 __global__ __launch_bounds__(kOctTMax) void k_test_sort(unsigned long long* __restrict__ v, int m) {
   __shared__ unsigned long long a[kMaxQuota];
   __shared__ int Lp[kMaxQuota], Rp[kMaxQuota];
@@ -1173,12 +1174,13 @@ __global__ __launch_bounds__(kOctTMax) void k_test_sort(unsigned long long* __re
   qt_sort_block(a, m, Lp, Rp, ss);
   for (int i = threadIdx.x; i < m; i += OCT_T) v[i] = a[i];
 }
+#endif
 
 __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
-                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask) {
+                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int level0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   DVS_CHAIN_PRIO();
   __shared__ int wsum[kOctTMax / 64 + 1];
@@ -1188,7 +1190,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   // grid = (frames, levels): the linear workgroup id is frame + frames x level, so the level-0 workgroups — the long ones — are
   // dispatched first and dealt round-robin over the XCDs, eight per XCD.  With (levels, frames) the id was level + 8 x frame and
   // XCD l received all 64 workgroups of level l: XCD 0 the 64 long ones, two per CU.
-  const int level = blockIdx.y, f = blockIdx.x;
+  // level0: first level of this launch — a launch may cover a class of levels only, with the node / point capacities (nmax, ptsLdsCap:
+  // the dynamic LDS) of that class (graded launches of the quad-tree beside FAST, orb.hip)
+  const int level = blockIdx.y + level0, f = blockIdx.x;
   if (tid >= OCT_T) return;  // wavefronts this level does not use leave before the first barrier
   if (!((levelMask >> level) & 1u)) {  // a level another rank owns: no keypoints from here
     if (tid == 0) { lvlKpCount[f * g->nlevels + level] = 0; candTotal[f * g->nlevels + level] = 0; }

@@ -28,6 +28,7 @@ struct dvs_pipeline {
   int device = 0, B = 0, rows = 0, cols = 0, nsets = 0, cap = 0;
   bool pipelined = true;
   int lanes = 1;                          // >= 2: the lane schedule
+  bool quadtree_async = false;            // the four-stream form of the two-stream pipeline
   dvs_orb* orb = nullptr;                 // = orbs[0]
   dvs_matcher* mat = nullptr;             // = mats[0]
   std::vector<dvs_orb*> orbs;             // one extractor / matcher pair per lane (one pair for the other schedules)
@@ -101,6 +102,7 @@ extern "C" {
 dvs_status dvs_pipeline_create(const dvs_pipeline_params* prm, int32_t device, dvs_pipeline** out) {
   DVS_ARG(prm && out);
   *out = nullptr;
+  DVS_ARG(prm->quadtree_async >= -1 && prm->quadtree_async <= 1);
   DVS_ARG(prm->batch >= 1 && prm->rows > 0 && prm->cols > 0 && prm->nsets >= 0 && prm->lanes >= 0 && prm->lanes <= DVS_PIPELINE_MAX_LANES);
   int lanes = !prm->pipelined ? 1 : (prm->lanes ? prm->lanes : (prm->batch <= DVS_PIPELINE_LANE_BATCH ? 3 : 1));
   // lanes steps are in flight and the match of the oldest still reads the set before it: two sets per lane keep every lane busy
@@ -165,6 +167,14 @@ dvs_status dvs_pipeline_create(const dvs_pipeline_params* prm, int32_t device, d
   if (hipEventCreateWithFlags(&p->ev_fast, hipEventDisableTiming) != hipSuccess) return fail(DVS_ERR_HIP);
   if (p->pipelined && lanes == 1) {
     if ((st = dvs_orb_set_after_fast_event(p->orb, p->ev_fast)) != DVS_OK) return fail(st);
+  }
+  // the four-stream form for batches whose kernels do not fill the machine (main: blur + FAST, prefetch: level chain, auxiliary:
+  // quad-tree, match stream: descriptors + match)
+  p->quadtree_async = p->pipelined && lanes == 1 &&
+                      (prm->quadtree_async > 0 || (prm->quadtree_async == 0 && prm->batch > DVS_PIPELINE_LANE_BATCH && prm->batch <= DVS_PIPELINE_ASYNC_BATCH));
+  if (p->quadtree_async) {
+    if ((st = dvs_orb_set_async_quadtree(p->orb, 1)) != DVS_OK) return fail(st);
+    if ((st = dvs_orb_set_tail_stream(p->orb, p->M)) != DVS_OK) return fail(st);
   }
   if ((st = dvs_orb_set_output_event(p->orb, p->ev_ext[0])) != DVS_OK) return fail(st);
   if ((st = dvs_orb_set_defer_outputs(p->orb, p->pipelined && lanes == 1 ? 1 : 0)) != DVS_OK) return fail(st);
@@ -262,6 +272,7 @@ dvs_status dvs_pipeline_get_set(const dvs_pipeline* p, int64_t step, dvs_pipelin
   return DVS_OK;
 }
 
+int32_t dvs_pipeline_quadtree_async(const dvs_pipeline* p) { return p && p->quadtree_async ? 1 : 0; }
 int32_t dvs_pipeline_nsets(const dvs_pipeline* p) { return p ? p->nsets : 0; }
 int32_t dvs_pipeline_lanes(const dvs_pipeline* p) { return !p ? 0 : (p->pipelined ? p->lanes : 0); }
 dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p) { return p ? p->orb : nullptr; }

@@ -23,6 +23,9 @@
 #include <chrono>
 #include <vector>
 #include "common.h"
+#ifdef DVS_TEST_HOOKS
+#include "../../include/dvslam_hip_test.h"
+#endif
 #include "io_pinned.h"
 
 namespace dvs {
@@ -1127,6 +1130,7 @@ using namespace dvs;
 
 extern "C" {
 
+#ifdef DVS_TEST_HOOKS   // libdvslam_hip_test.so only (include/dvslam_hip_test.h)
 // host-logic test hooks (no GPU): the product's quartic and P3P routines, compiled for the host
 int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, double a0, double* roots4) {
   return quartic_real_roots(a4, a3, a2, a1, a0, roots4);
@@ -1136,6 +1140,7 @@ int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48) {
   memcpy(P, P9, sizeof(P)); memcpy(j, j9, sizeof(j));
   return p3p_solve(P, j, poses48);
 }
+#endif  // DVS_TEST_HOOKS
 
 // ---- batches of independent RANSAC problems (one launch sequence for all of them; the single-problem entry points are batches of one) ----
 // problem b = correspondences [offsets[b], offsets[b + 1]) of the concatenated point arrays, sampler seed seeds[b]

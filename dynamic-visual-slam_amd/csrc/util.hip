@@ -1,6 +1,9 @@
 // util.hip — error text, device selection, raw device-memory helpers of the C-ABI
 #include <string.h>
 #include "common.h"
+#ifdef DVS_TEST_HOOKS
+#include "../../include/dvslam_hip_test.h"
+#endif
 
 namespace dvs {
 
@@ -56,11 +59,13 @@ StageTimer::~StageTimer() { for (int i = 0; i < npool; i++) hipEventDestroy(pool
 
 }  // namespace dvs
 
+#ifdef DVS_TEST_HOOKS
 // test hook: one wavefront that holds its stream for `ticks` of the 100 MHz wall clock (bounded: every lane leaves at the deadline)
 __global__ void k_test_spin(unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+#endif
 
 extern "C" {
 
@@ -188,10 +193,12 @@ dvs_status dvs_memset(int32_t device, void* dst, int value, size_t bytes) {
   DVS_HIP(hipStreamSynchronize(nullptr));  // complete before the caller enqueues on a non-blocking stream
   return DVS_OK;
 }
+#ifdef DVS_TEST_HOOKS
 dvs_status dvs_test_stream_delay(void* stream, int32_t microseconds) {
   DVS_ARG(microseconds >= 0 && microseconds <= 200000);   // bounded: 0.2 s
   hipLaunchKernelGGL(k_test_spin, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
   DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
+#endif
 }

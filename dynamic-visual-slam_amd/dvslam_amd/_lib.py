@@ -26,7 +26,7 @@ class OrbParams(C.Structure):
 
 class PipelineParams(C.Structure):
     _fields_ = [("orb", OrbParams), ("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("nsets", C.c_int32), ("pipelined", C.c_int32),
-                ("lanes", C.c_int32)]
+                ("lanes", C.c_int32), ("quadtree_async", C.c_int32)]
 
 
 class PipelineSet(C.Structure):
@@ -87,7 +87,6 @@ def lib():
     L.dvs_stream_destroy.argtypes = [vp]
     L.dvs_stream_synchronize.argtypes = [vp]
     L.dvs_event_create.argtypes = [i32, C.POINTER(vp)]
-    L.dvs_test_stream_delay.argtypes = [vp, i32]
     L.dvs_event_query.argtypes = [vp, C.POINTER(i32)]
     L.dvs_event_create_timing.argtypes = [i32, C.POINTER(vp)]
     L.dvs_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
@@ -100,6 +99,8 @@ def lib():
     L.dvs_orb_set_output_event.argtypes = [vp, vp]
     L.dvs_orb_set_defer_outputs.argtypes = [vp, i32]
     L.dvs_orb_set_reuse_guard_event.argtypes = [vp, vp]
+    L.dvs_orb_set_async_quadtree.argtypes = [vp, i32]
+    L.dvs_orb_set_tail_stream.argtypes = [vp, vp]
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]
@@ -139,6 +140,7 @@ def lib():
     L.dvs_pipeline_get_set.argtypes = [vp, C.c_int64, C.POINTER(PipelineSet)]
     L.dvs_pipeline_lanes.argtypes = [vp]
     L.dvs_pipeline_nsets.argtypes = [vp]
+    L.dvs_pipeline_quadtree_async.argtypes = [vp]
     L.dvs_orb_create_single_stream.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
     L.dvs_pipeline_extractor.argtypes = [vp]; L.dvs_pipeline_extractor.restype = vp
     L.dvs_pipeline_matcher.argtypes = [vp]; L.dvs_pipeline_matcher.restype = vp
@@ -148,13 +150,6 @@ def lib():
     L.dvs_find_fundamental_cv.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_find_fundamental_cv_batch.argtypes = [vp, i32, vp, vp, vp, dbl, dbl, i32, vp, vp, vp, vp]
     L.dvs_cv_ransac_subsets.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
-    L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
-    L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
-    L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int
-    L.dvs_test_quartic_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
-    L.dvs_test_p3p.argtypes = [vp, vp, vp]
-    L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
-    L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "dvs_ba_create"):
         L.dvs_ba_create.argtypes = [i32, C.POINTER(vp)]
         L.dvs_ba_destroy.argtypes = [vp]; L.dvs_ba_destroy.restype = None
@@ -175,6 +170,35 @@ def lib():
     return L
 
 
+TEST_SO_PATH = os.path.join(os.path.dirname(SO_PATH), "libdvslam_hip_test.so")
+_test_lib = None
+
+
+def test_lib():
+    """lib/libdvslam_hip_test.so: the same sources built with -DDVS_TEST_HOOKS (include/dvslam_hip_test.h).  Only the dvs_test_* hooks are
+    called through it; the product library exports none of them."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_SO_PATH):
+        subprocess.check_call(["make", "-s", "-j4", "-C", _PKG, "test-lib"])
+    L = C.CDLL(TEST_SO_PATH)
+    vp, i32, dbl = C.c_void_p, C.c_int32, C.c_double
+    L.dvs_last_error.restype = C.c_char_p
+    L.dvs_test_stream_delay.argtypes = [vp, i32]
+    L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
+    L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
+    L.dvs_test_sort_nodes_device.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_device.restype = C.c_int
+    L.dvs_test_quartic_roots.argtypes = [dbl, dbl, dbl, dbl, dbl, vp]
+    L.dvs_test_p3p.argtypes = [vp, vp, vp]
+    L.dvs_test_sincosf.argtypes = [C.c_float, vp, vp]; L.dvs_test_sincosf.restype = None
+    L.dvs_test_geometry.argtypes = [C.POINTER(OrbParams), i32, i32, vp, vp, vp, vp, vp, vp]
+    L.dvs_test_retain_best_host.argtypes = [vp, i32, i32, vp, C.POINTER(i32)]; L.dvs_test_retain_best_host.restype = None
+    L.dvs_test_retain_best_device.argtypes = [vp, i32, i32, vp, C.POINTER(i32)]
+    _test_lib = L
+    return L
+
+
 def check(code):
     if code != 0:
         raise DvsError(code, lib().dvs_last_error().decode(errors="replace"))
@@ -184,17 +208,14 @@ def device_count():
     return lib().dvs_device_count()
 
 
-PROFILED_SOURCES = ("pipeline.hip", "orb.hip", "orb_kernels.h", "orb_geom.h", "orb_device_common.h", "lsort.h", "glibc_sincosf.h", "brief_pattern.inc", "match.hip",
-                    "common.h")
-
-
 def kernel_source_digest():
-    """sha256 (first 16 hex digits) over the sources of the kernels bench.py times and tools/collect_profiles.sh counts (extractor and
-    matcher) — stamps profile data (profiles/pmc_traffic.json) with the code it was collected on"""
+    """sha256 (first 16 hex digits) over EVERY source of the library (csrc/*.hip, *.h, *.inc, in name order) — stamps profile data
+    (profiles/pmc_traffic.json) with the code it was collected on"""
     import hashlib
     h = hashlib.sha256()
-    for name in PROFILED_SOURCES:
-        h.update(name.encode()); h.update(open(os.path.join(_PKG, "csrc", name), "rb").read())
+    d = os.path.join(_PKG, "csrc")
+    for name in sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h", ".inc"))):
+        h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -68,20 +68,19 @@ class CvORB:
 
 def retain_best_host(responses, n_points):
     """csrc/lsort.h's restatement of KeyPointsFilter::retainBest (std::nth_element + std::partition) -> surviving original indices"""
-    L = lib()
+    from ._lib import test_lib
+    L = test_lib()
     r = np.ascontiguousarray(responses, np.float32)
     perm = np.zeros(max(len(r), 1), np.int32); k = C.c_int32()
-    L.dvs_test_retain_best_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
-    L.dvs_test_retain_best_host.restype = None
     L.dvs_test_retain_best_host(ptr(r), len(r), n_points, ptr(perm), C.byref(k))
     return perm[:k.value].copy()
 
 
 def retain_best_device(responses, n_points):
     """the same through the wavefront routine of the cv::ORB kernels (needs the GPU)"""
-    L = lib()
+    from ._lib import test_lib
+    L = test_lib()
     r = np.ascontiguousarray(responses, np.float32)
     perm = np.zeros(max(len(r), 1), np.int32); k = C.c_int32()
-    L.dvs_test_retain_best_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
     check(L.dvs_test_retain_best_device(ptr(r), len(r), n_points, ptr(perm), C.byref(k)))
     return perm[:k.value].copy()

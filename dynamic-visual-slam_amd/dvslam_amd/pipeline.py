@@ -7,7 +7,8 @@ ORBextractor.cpp:1086-1167) and matches batch i - 1 (B jobs: frame t against fra
 rotate (>= 3 when pipelined — refused by dvs_pipeline_create otherwise).  With a communicator (frames sharded contiguously over
 ranks) the frame before this rank's first frame comes from `dvs_exchange_boundary`.  `pipelined=False` is the
 plain schedule: every batch's match behind its own extraction on one stream.  `lanes`: 0 = by batch size, 1 = the two-stream software
-pipeline, 2..4 = the small-batch lane schedule (whole steps in flight on independent extractor / matcher pairs).
+pipeline, 2..4 = the small-batch lane schedule (whole steps in flight on independent extractor / matcher pairs).  `quadtree_async`:
+1 / -1 / 0 = the four-stream form of the two-stream pipeline on / off / by batch size (5..12 frames per step).
 
 Pure ctypes: no torch in here."""
 import ctypes as C
@@ -34,11 +35,11 @@ class _Ptr:
 
 
 class StreamingPipeline:
-    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=4, pipelined=True, params=(1.2, 8, 20, 7), lanes=0):
+    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=4, pipelined=True, params=(1.2, 8, 20, 7), lanes=0, quadtree_async=0):
         self.L = L = _lib.lib()
         self.B, self.rows, self.cols, self.device, self.nsets, self.pipelined = B, rows, cols, device, nsets, pipelined
         prm = _lib.PipelineParams(_lib.OrbParams(nfeatures, params[0], params[1], params[2], params[3], (C.c_int32 * 7)(*([0] * 7)), B),
-                                  B, rows, cols, nsets, int(bool(pipelined)), lanes)
+                                  B, rows, cols, nsets, int(bool(pipelined)), lanes, quadtree_async)
         h = C.c_void_p()
         code = L.dvs_pipeline_create(C.byref(prm), device, C.byref(h))
         if code == -6 and pipelined and nsets < 3:
@@ -46,6 +47,7 @@ class StreamingPipeline:
         _lib.check(code)
         self._h = h
         self.nsets = nsets = int(L.dvs_pipeline_nsets(h))   # nsets = 0 asks for the schedule's default
+        self.quadtree_async = bool(L.dvs_pipeline_quadtree_async(h))   # the four-stream form (dvs_pipeline_params::quadtree_async)
         self.lanes = int(L.dvs_pipeline_lanes(h))   # 0: serial, 1: two-stream software pipeline, >= 2: lane schedule
         # non-owning views of the handles inside (stage timing, overlap switch, the bench's serial re-run of a match job)
         self.orb = ORBextractor.from_handle(L.dvs_pipeline_extractor(h), nfeatures, params[1], params[0], device, B)

@@ -24,12 +24,12 @@ namespace dvslam {
 class StreamingPipeline {
  public:
   StreamingPipeline(int batch, int rows, int cols, int nfeatures = 2000, float scaleFactor = 1.2f, int nlevels = 8, int iniThFAST = 20,
-                    int minThFAST = 7, int device = 0, int nsets = 4, bool pipelined = true, int lanes = 0)
+                    int minThFAST = 7, int device = 0, int nsets = 4, bool pipelined = true, int lanes = 0, int quadtree_async = 0)
       : device_(device), batch_(batch) {
     dvs_pipeline_params p;
     std::memset(&p, 0, sizeof(p));
     p.orb.nfeatures = nfeatures; p.orb.scale_factor = scaleFactor; p.orb.nlevels = nlevels; p.orb.ini_th_fast = iniThFAST; p.orb.min_th_fast = minThFAST;
-    p.batch = batch; p.rows = rows; p.cols = cols; p.nsets = nsets; p.pipelined = pipelined ? 1 : 0; p.lanes = lanes;
+    p.batch = batch; p.rows = rows; p.cols = cols; p.nsets = nsets; p.pipelined = pipelined ? 1 : 0; p.lanes = lanes; p.quadtree_async = quadtree_async;
     check(dvs_pipeline_create(&p, device, &h_), "dvs_pipeline_create");
     dvs_pipeline_set s;
     check(dvs_pipeline_get_set(h_, 0, &s), "dvs_pipeline_get_set");

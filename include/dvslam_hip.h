@@ -153,6 +153,14 @@ dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on);
  * hipStreamWaitEvent on the main stream before the call, but the wait rides on the blur's stream, off the critical path in front of
  * FAST (outputs are only written by the descriptor stage, which joins the blur). */
 dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event);
+/* Quad-tree off the main stream (pipelined callers: announced next batch + deferred outputs).  on = 1: the quad-tree of a call runs on
+ * the auxiliary stream behind that call's FAST, so the next call's FAST follows immediately and the latency-bound tree runs beside it
+ * (FAST writes three candidate-list sets in turn; with more than one workgroup per CU the tree is launched per level class with that
+ * class's LDS footprint instead of level 0's).  Results are unaffected.  Synchronises the handle's streams. */
+dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on);
+/* ... and its descriptor stage on a stream of the caller (NULL: the auxiliary stream): with the quad-tree and the blur on the auxiliary
+ * stream that stream alone would carry a whole step; a pipelined caller hands over its match stream (dvs_pipeline does). */
+dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream);
 
 /* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
  * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per
@@ -275,7 +283,12 @@ typedef struct dvs_pipeline_params {
   int32_t pipelined;    /* 1: the software pipeline described above; 0: serial match */
   int32_t lanes;        /* pipelined only.  0 = by batch size (3 up to DVS_PIPELINE_LANE_BATCH frames, else 1); 1 = the two-stream
                            software pipeline; 2..DVS_PIPELINE_MAX_LANES = lanes */
+  int32_t quadtree_async; /* two-stream pipeline only.  1: the four-stream form — quad-tree on the extractor's auxiliary stream beside the next
+                           step's FAST (dvs_orb_set_async_quadtree), descriptor stage on the match stream (dvs_orb_set_tail_stream), blur on the
+                           main stream ahead of FAST; -1: off; 0 = by batch size (on for DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH:
+                           measured +21 % at 8 frames per step, +7 % at 12, a tie at 16, -9 % at 64) */
 } dvs_pipeline_params;
+#define DVS_PIPELINE_ASYNC_BATCH 12
 #define DVS_PIPELINE_MAX_LANES 4     /* HIP streams beyond four share hardware queues on this part */
 #define DVS_PIPELINE_LANE_BATCH 4    /* lanes = 0: batches up to this size run on lanes (measured: 8 frames and more tie or lose) */
 /* results of one step's batch (device pointers into the handle's output set; valid until step + nsets is enqueued) */
@@ -305,6 +318,7 @@ dvs_status dvs_pipeline_reset(dvs_pipeline* p);
 int64_t dvs_pipeline_steps(const dvs_pipeline* p);   /* steps enqueued since creation / reset */
 dvs_status dvs_pipeline_get_set(const dvs_pipeline* p, int64_t step, dvs_pipeline_set* out);
 /* the handles inside (stage timing, overlap switch, stream for a caller's own events); owned by the pipeline */
+int32_t dvs_pipeline_quadtree_async(const dvs_pipeline* p);   /* 1: the four-stream form is in use */
 int32_t dvs_pipeline_nsets(const dvs_pipeline* p);    /* output sets in rotation */
 int32_t dvs_pipeline_lanes(const dvs_pipeline* p);    /* 0: serial schedule, 1: two-stream software pipeline, >= 2: lanes */
 dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p);      /* lane 0's */
@@ -535,26 +549,6 @@ dvs_status dvs_cvorb_detect_and_compute(dvs_cvorb* h, const uint8_t* gray, int32
                                         uint8_t* desc /* capacity x 32 */, int32_t capacity, int32_t* n_out);
 /* parity introspection: level `level` of the last call's pyramid (blurred = 1: after the Gaussian), tight rows */
 dvs_status dvs_cvorb_get_level(dvs_cvorb* h, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes, int32_t* w, int32_t* hgt);
-
-/* ======================================= host-logic test hooks ================================= */
-/* (no GPU needed) libstdc++ std::sort replica used by the quad-tree, glibc sinf/cosf restatement, geometry tables */
-void dvs_test_sort_nodes(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
-/* the same order through the rank-pairing restatement the quad-tree kernel runs (host, sequential) ... */
-void dvs_test_sort_nodes_ranked(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
-/* ... and through the kernel's workgroup sort itself (needs a GPU; n <= 1500) */
-dvs_status dvs_test_sort_nodes_device(const int32_t* count, const int32_t* ulx, int32_t n, int32_t* perm);
-void dvs_test_sincosf(float a, float* s, float* c);
-/* the PnP stage's quartic (Ferrari + Newton) and P3P (Grunert) routines on the host: real roots (unordered) / up to 4 poses x 12 */
-int32_t dvs_test_quartic_roots(double a4, double a3, double a2, double a1, double a0, double* roots4);
-int32_t dvs_test_p3p(const double* P9, const double* j9, double* poses48);
-/* (needs a GPU) hold `stream` for the given time with one idle wavefront (<= 200 000 us): lets a test delay an event */
-dvs_status dvs_test_stream_delay(void* stream, int32_t microseconds);
-/* KeyPointsFilter::retainBest on bare responses: perm[i] = original index of the i-th survivor.  _host: csrc/lsort.h's sequential
- * restatement of std::nth_element + std::partition (no GPU); _device: the wavefront routine the cv::ORB kernels run */
-void dvs_test_retain_best_host(const float* responses, int32_t n, int32_t n_points, int32_t* perm, int32_t* n_kept);
-dvs_status dvs_test_retain_best_device(const float* responses, int32_t n, int32_t n_points, int32_t* perm, int32_t* n_kept);
-dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t cols, int32_t* level_w, int32_t* level_h,
-                             int32_t* ncells, int32_t* quota, int32_t* wcell, int32_t* hcell);
 
 #ifdef __cplusplus
 }

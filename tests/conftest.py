@@ -34,6 +34,14 @@ def hiplib():
 
 
 @pytest.fixture(scope="session")
+def hooks(hiplib):
+    """lib/libdvslam_hip_test.so (-DDVS_TEST_HOOKS): the dvs_test_* entry points of include/dvslam_hip_test.h, which the product library
+    does not export"""
+    from dvslam_amd import _lib
+    return _lib.test_lib()
+
+
+@pytest.fixture(scope="session")
 def gpu(hiplib):
     from dvslam_amd import device_count
     n = device_count()

@@ -6,6 +6,7 @@ import json
 import os
 import numpy as np
 import pytest
+from dvslam_amd._lib import test_lib as _hooks   # lib/libdvslam_hip_test.so: the dvs_test_* hooks (not in the product library)
 from dvslam_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -194,7 +195,7 @@ def test_workgroup_sort_matches_std_sort(gpu, hiplib, oracle):
         count = np.ascontiguousarray(count, np.int32); ulx = np.ascontiguousarray(ulx, np.int32)
         m = len(count)
         a = np.zeros(m, np.int32); b = np.zeros(m, np.int32)
-        assert hiplib.dvs_test_sort_nodes_device(count.ctypes.data, ulx.ctypes.data, m, a.ctypes.data) == 0
+        assert _hooks().dvs_test_sort_nodes_device(count.ctypes.data, ulx.ctypes.data, m, a.ctypes.data) == 0
         oracle.lib().orc_std_sort_nodes(count.ctypes.data, ulx.ctypes.data, m, b.ctypes.data)
         assert (a == b).all(), f"n={m}"
 
@@ -440,7 +441,7 @@ def test_deferred_stage_held_back_two_steps(gpu):
         k, d, n = outs[b]
         g.set_output_event(ev_out[b], defer=True)
         if b == held:
-            assert L.dvs_test_stream_delay(side, 50000) == 0      # 50 ms: hundreds of calls of this size
+            assert _hooks().dvs_test_stream_delay(side, 50000) == 0      # 50 ms: hundreds of calls of this size
             assert L.dvs_event_record(ev_slow, side) == 0
             g.set_reuse_guard_event(ev_slow)
         if b + 1 < NBATCH:

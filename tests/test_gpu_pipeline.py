@@ -99,7 +99,16 @@ def test_lane_schedule_for_small_batches(gpu, oracle, B, lanes, nsets, steps):
     assert p == (lanes or 3)                                              # lanes = 0: three lanes (and six sets) up to 4 frames per step
 
 
-def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0):
+@pytest.mark.parametrize("B,rows,cols,nf,nsets,steps", [(8, 720, 1280, 2000, 4, 7), (12, 480, 640, 800, 3, 7), (40, 360, 1000, 700, 4, 6), (7, 250, 332, 200, 3, 6)])
+def test_four_stream_schedule(gpu, oracle, B, rows, cols, nf, nsets, steps):
+    """dvs_pipeline_params::quadtree_async = 1: the quad-tree on the auxiliary stream beside the next FAST (three candidate sets), the
+    descriptor stage on the match stream, the blur on the main stream ahead of FAST (three blurred blocks).  40 frames: more than one
+    quad-tree workgroup per CU, launched per level class with graded LDS; 332 columns: rows that are not dword aligned keep the plain
+    path although the switch is on"""
+    _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=1, quadtree_async=1)
+
+
+def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=0):
     from dvslam_amd import _lib
     from dvslam_amd.pipeline import StreamingPipeline
     NB = 3
@@ -107,7 +116,8 @@ def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0):
     o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
     ref = [[o.extract(f) for f in batch] for batch in frames]
     d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
-    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True, lanes=lanes)
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True, lanes=lanes, quadtree_async=quadtree_async)
+    assert quadtree_async == 0 or pipe.quadtree_async == (quadtree_async == 1)
     used, nsets = pipe.lanes, pipe.nsets
     for i in range(steps):
         pipe.step(d_img[i % NB].ptr, d_img[(i + 1) % NB].ptr)

@@ -6,6 +6,7 @@ import os
 import re
 import numpy as np
 import pytest
+from dvslam_amd._lib import test_lib as _hooks   # lib/libdvslam_hip_test.so: the dvs_test_* hooks (not in the product library)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,6 +18,13 @@ def test_exports_every_declared_symbol(hiplib):
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(hiplib, n)]
     assert not missing, f"declared in include/dvslam_hip.h but not exported: {missing}"
+    # the test hooks are declared in their own header and exported by the -DDVS_TEST_HOOKS build only
+    assert not [n for n in names if n.startswith("dvs_test_")]
+    thdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dvslam_hip_test.h")).read(), flags=re.S)
+    tnames = sorted(set(re.findall(r"\b(dvs_test_[a-z0-9_]+)\s*\(", thdr)))
+    assert len(tnames) == 10
+    assert not [n for n in tnames if hasattr(hiplib, n)], "the product library must not export test hooks"
+    assert not [n for n in tnames if not hasattr(_hooks(), n)]
 
 
 def test_no_gpu_means_error_not_fallback(hiplib):
@@ -35,9 +43,9 @@ def _sort_both(hiplib, oracle, count, ulx):
     count = np.ascontiguousarray(count, np.int32); ulx = np.ascontiguousarray(ulx, np.int32)
     n = len(count)
     a = np.zeros(n, np.int32); b = np.zeros(n, np.int32); c = np.zeros(n, np.int32)
-    hiplib.dvs_test_sort_nodes(count.ctypes.data, ulx.ctypes.data, n, a.ctypes.data)
+    _hooks().dvs_test_sort_nodes(count.ctypes.data, ulx.ctypes.data, n, a.ctypes.data)
     oracle.lib().orc_std_sort_nodes(count.ctypes.data, ulx.ctypes.data, n, b.ctypes.data)
-    hiplib.dvs_test_sort_nodes_ranked(count.ctypes.data, ulx.ctypes.data, n, c.ctypes.data)
+    _hooks().dvs_test_sort_nodes_ranked(count.ctypes.data, ulx.ctypes.data, n, c.ctypes.data)
     assert (c == b).all(), "rank-pairing restatement differs from std::sort"
     return a, b
 
@@ -92,7 +100,7 @@ def test_sincosf_restatement_sample(hiplib, oracle):
     xs = np.concatenate([rng.uniform(0, 6.4, 20000), [0.0, 1e-5, 0.785398, 0.7853982, 1.5707964, 3.1415927, 4.712389, 6.2831855]]).astype(np.float32)
     s1, c1, s2, c2 = (C.c_float() for _ in range(4))
     for x in xs:
-        hiplib.dvs_test_sincosf(float(x), C.byref(s1), C.byref(c1))
+        _hooks().dvs_test_sincosf(float(x), C.byref(s1), C.byref(c1))
         oracle.lib().orc_sincosf(float(x), C.byref(s2), C.byref(c2))
         assert s1.value == s2.value and c1.value == c2.value, x
 
@@ -103,7 +111,7 @@ def test_geometry_matches_oracle(hiplib, oracle, rows, cols, nf, nl):
     p = OrbParams(nf, 1.2, nl, 20, 7, (C.c_int32 * 7)(*([0] * 7)), 1)
     w = np.zeros(nl, np.int32); h = np.zeros(nl, np.int32); nc = np.zeros(nl, np.int32); q = np.zeros(nl, np.int32)
     wc = np.zeros(nl, np.int32); hc = np.zeros(nl, np.int32)
-    assert hiplib.dvs_test_geometry(C.byref(p), rows, cols, w.ctypes.data, h.ctypes.data, nc.ctypes.data, q.ctypes.data,
+    assert _hooks().dvs_test_geometry(C.byref(p), rows, cols, w.ctypes.data, h.ctypes.data, nc.ctypes.data, q.ctypes.data,
                                     wc.ctypes.data, hc.ctypes.data) == 0
     o = oracle.OracleORB(nf, 1.2, nl, 20, 7)
     assert [o.level_size(cols, rows, l) for l in range(nl)] == list(zip(w.tolist(), h.tolist()))
@@ -115,7 +123,7 @@ def test_geometry_matches_oracle(hiplib, oracle, rows, cols, nf, nl):
 def test_geometry_rejects_sizes_the_reference_divides_by_zero_on(hiplib):
     from dvslam_amd._lib import OrbParams
     p = OrbParams(500, 1.2, 8, 20, 7, (C.c_int32 * 7)(*([0] * 7)), 1)
-    assert hiplib.dvs_test_geometry(C.byref(p), 120, 160, None, None, None, None, None, None) == -2
+    assert _hooks().dvs_test_geometry(C.byref(p), 120, 160, None, None, None, None, None, None) == -2
 
 
 def test_pipelined_schedule_refuses_two_output_sets():

@@ -8,6 +8,7 @@ oracle, which share the sampler but not their numerical routines.  And cv::findF
 unpinned like everything else here (no OpenCV in the image)."""
 import numpy as np
 import pytest
+from dvslam_amd._lib import test_lib as _hooks   # lib/libdvslam_hip_test.so: the dvs_test_* hooks (not in the product library)
 import ransac_scenes as rs
 
 
@@ -69,7 +70,7 @@ def test_product_quartic_and_p3p_on_the_host(hiplib):
             continue
         c = c * rng.uniform(0.5, 2.0)
         out = np.zeros(4)
-        n = hiplib.dvs_test_quartic_roots(*[float(v) for v in c], out.ctypes.data)
+        n = _hooks().dvs_test_quartic_roots(*[float(v) for v in c], out.ctypes.data)
         assert n == len(want) and np.allclose(np.sort(out[:n]), want, rtol=1e-7, atol=1e-7), (c, out[:n], want)
     bad = 0
     for planar in (False, True):
@@ -80,7 +81,7 @@ def test_product_quartic_and_p3p_on_the_host(hiplib):
             Q = P @ R.T + t
             j = Q / np.linalg.norm(Q, axis=1)[:, None]
             out = np.zeros(48)
-            n = hiplib.dvs_test_p3p(np.ascontiguousarray(P).ctypes.data, np.ascontiguousarray(j).ctypes.data, out.ctypes.data)
+            n = _hooks().dvs_test_p3p(np.ascontiguousarray(P).ctypes.data, np.ascontiguousarray(j).ctypes.data, out.ctypes.data)
             sols = [(out[12 * i:12 * i + 9].reshape(3, 3), out[12 * i + 9:12 * i + 12]) for i in range(n)]
             bad += min([np.abs(Rs - R).max() + np.abs(ts - t).max() for Rs, ts in sols] or [9.0]) > 1e-6
     assert bad <= 6, f"{bad} of 400 exact triangles not recovered"

@@ -187,6 +187,25 @@ class BatchedFrontEnd:
         self.f_k = [D(B * cap * 28) for _ in range(2)]; self.f_d = [D(B * cap * 32) for _ in range(2)]; self.f_n = [D(B * 4) for _ in range(2)]
         self.d_idx, self.d_dist = D(B * cap * 4), D(B * cap * 4)
 
+    def run_into_block(self, frames, depth, blk):
+        """phase 1 of a contiguous run of frames with the results left ON THE DEVICE in `blk` (a RankBlock: frame slots in structure-of-arrays
+        form, the send block of the multi-rank gather): every batch writes its filtered keypoints / descriptors / counts and its matches
+        straight into its slots, the first frame of a batch reads its predecessor from the slot before.  Asynchronous but for the uploads."""
+        B, cap, rows, cols = self.B, self.cap, self.rows, self.cols
+        assert len(frames) <= blk.slots and cap == blk.cap
+        self.d_depth.upload(np.ascontiguousarray(depth, np.uint16))
+        for b0 in range(0, len(frames), B):
+            nb = min(B, len(frames) - b0)
+            self.orb.synchronize()                    # the image slots are reused: the previous batch's extraction has read them
+            for i in range(nb):
+                fr = np.ascontiguousarray(frames[b0 + i])
+                self._lib.check(self.L.dvs_memcpy_h2d(self.device, self.d_img.ptr + i * rows * cols, self._lib.ptr(fr), fr.nbytes))
+            self.orb.extract_batch_device(self.d_img.ptr, nb, rows, cols, cols, rows * cols, self.d_k.ptr, self.d_d.ptr, cap, self.d_n.ptr)
+            self._lib.check(self.L.dvs_filter_depth_batch_device(self.mat._h, self.d_k.ptr, self.d_d.ptr, self.d_n.ptr, cap, nb, self.d_depth.ptr, rows, cols,
+                                                                 cols * 2, 0, 0.3, 3.0, blk.kps(b0), blk.desc(b0), None, blk.n(b0)))
+            prev = (blk.desc(b0 - 1), blk.n(b0 - 1)) if b0 else (0, 0)
+            self.mat.match_sequence_device(blk.desc(b0), blk.n(b0), cap, nb, prev[0], prev[1], blk.idx(b0), blk.dist(b0))
+
     def run(self, frames, depth):
         C, B, cap, rows, cols = self.C, self.B, self.cap, self.rows, self.cols
         self.d_depth.upload(np.ascontiguousarray(depth, np.uint16))
@@ -211,6 +230,112 @@ class BatchedFrontEnd:
                 first = b0 + f == 0
                 out.append((k[f, :n[f]].copy(), d[f, :n[f]].copy(), None if first else idx[f, :n[f]].copy(), None if first else dist[f, :n[f]].copy()))
         return out
+
+
+class RankBlock:
+    """One rank's phase-1 results as ONE device block — what dvs_comm_all_gather moves: `slots` frame slots in structure-of-arrays form
+    {int32 n[slots]; keypoints[slots][cap] x 28 B; descriptors[slots][cap][32]; int32 trainIdx[slots][cap]; int32 distance[slots][cap]},
+    every array 256-byte aligned.  Same layout on every rank (slots = the longest shard + the one re-extracted frame before it)."""
+
+    def __init__(self, slots, cap):
+        up = lambda v: (v + 255) // 256 * 256
+        self.slots, self.cap = slots, cap
+        self.o_n = 0
+        self.o_k = up(slots * 4)
+        self.o_d = self.o_k + up(slots * cap * 28)
+        self.o_i = self.o_d + up(slots * cap * 32)
+        self.o_s = self.o_i + up(slots * cap * 4)
+        self.nbytes = self.o_s + up(slots * cap * 4)
+        self.base = 0
+
+    def at(self, base):
+        self.base = base
+        return self
+
+    def n(self, f): return self.base + self.o_n + 4 * f
+    def kps(self, f): return self.base + self.o_k + f * self.cap * 28
+    def desc(self, f): return self.base + self.o_d + f * self.cap * 32
+    def idx(self, f): return self.base + self.o_i + f * self.cap * 4
+    def dist(self, f): return self.base + self.o_s + f * self.cap * 4
+
+    def unpack(self, raw, nframes, first_has_match):
+        """host bytes of one block -> per frame (keypoints, descriptors, trainIdx, distance)"""
+        from dvslam_amd._lib import KP_DTYPE
+        S, cap = self.slots, self.cap
+        n = raw[self.o_n:self.o_n + 4 * S].view(np.int32)
+        k = raw[self.o_k:self.o_k + S * cap * 28].view(KP_DTYPE).reshape(S, cap)
+        d = raw[self.o_d:self.o_d + S * cap * 32].reshape(S, cap, 32)
+        ii = raw[self.o_i:self.o_i + S * cap * 4].view(np.int32).reshape(S, cap)
+        dd = raw[self.o_s:self.o_s + S * cap * 4].view(np.int32).reshape(S, cap)
+        out = []
+        for f in range(nframes):
+            m = int(n[f])
+            nomatch = f == 0 and not first_has_match
+            out.append((k[f, :m].copy(), d[f, :m].copy(), None if nomatch else ii[f, :m].copy(), None if nomatch else dd[f, :m].copy()))
+        return out
+
+
+def shard_bounds(n, world, r):
+    return r * n // world, (r + 1) * n // world
+
+
+def sharded_front_end_rank(frames_of, n, depth, nfeatures, rank, world, comm, device=0, B=64, fe=None):
+    """BASELINE configs[4] across `world` ranks (bag_playback.launch.xml:1-8 starts ONE frontend; here its pose-independent half,
+    frontend.cpp:1084-1132, is sharded): this rank runs phase 1 on its contiguous frame range [a, b) — re-extracting frame a - 1 instead of
+    receiving it — with the results left on the device, then ONE dvs_comm_all_gather of the per-rank blocks brings every shard to every
+    rank (the tracking rank needs them all; RCCL has no gather-to-one cheaper than this at 8 ranks x ~9 MB).  `frames_of(t)` yields frame t.
+    Returns the per-frame list of the whole sequence (on every rank)."""
+    from dvslam_amd import _lib
+    rows, cols = depth.shape
+    fe = fe or BatchedFrontEnd(nfeatures, rows, cols, B, device)
+    slots = max(shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)) + 1
+    blk = RankBlock(slots, fe.cap)
+    gather = _lib.DeviceBuffer(world * blk.nbytes, device)
+    _lib.check(_lib.lib().dvs_memset(device, gather.ptr, 0, gather.nbytes))
+    a, b = shard_bounds(n, world, rank)
+    lo = max(a - 1, 0)
+    mine = gather.ptr + rank * blk.nbytes
+    if b > a:
+        fe.run_into_block([frames_of(t) for t in range(lo, b)], depth, blk.at(mine))
+    if world > 1:
+        comm.all_gather(fe.orb.get_stream(), mine, gather.ptr, blk.nbytes)      # in place: this rank's block already sits in its slot
+    fe.orb.synchronize()
+    raw = gather.download(np.uint8, world * blk.nbytes)
+    out = []
+    for r in range(world):
+        ra, rb = shard_bounds(n, world, r)
+        if rb <= ra:
+            continue
+        rlo = max(ra - 1, 0)
+        part = blk.unpack(raw[r * blk.nbytes:(r + 1) * blk.nbytes], rb - rlo, first_has_match=False)
+        out += part[ra - rlo:]
+    return out
+
+
+def sharded_front_end_loopback(frames, depth, nfeatures, world, B=64):
+    """the same on ONE GPU: `world` logical ranks of this process (dvs_comm_create_loopback), one host thread, extractor and communicator
+    each — the collective path of the multi-rank program without the second GPU.  Returns rank 0's view."""
+    import threading
+    from dvslam_amd import dist as dvdist
+    rows, cols = depth.shape
+    comms = dvdist.Comm.loopback(0, world)
+    fes = [BatchedFrontEnd(nfeatures, rows, cols, B, 0) for _ in range(world)]
+    res, err = [None] * world, []
+
+    def work(r):
+        try:
+            res[r] = sharded_front_end_rank(lambda t: frames[t], len(frames), depth, nfeatures, r, world, comms[r], 0, B, fes[r])
+        except Exception as e:   # noqa: BLE001
+            err.append((r, repr(e)))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in comms:
+        c.close()
+    assert not err, err
+    return res
 
 
 def batched_front_end(frames, depth, nfeatures, shards=1, B=64, fe=None):
@@ -571,8 +696,96 @@ def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_e
     return res
 
 
+def summarize_hip(hip, n_frames, gt, t_phase1, wall):
+    return dict(wall_s=wall, ms_per_frame_in_stages=1e3 * hip["seconds_in_stages"] / n_frames, ms_per_frame_phase1=1e3 * t_phase1 / n_frames,
+                keyframes=len(hip["keyframes"]), rmse_vs_ground_truth=rmse(hip["poses"], gt),
+                median_matches=float(np.median(hip["stats"]["matches"])), median_geometric=float(np.median(hip["stats"]["geometric"])),
+                median_pnp_inliers=float(np.median(hip["stats"]["pnp_inliers"])), pose_updates=hip["stats"]["pose_updates"],
+                motion_outliers=hip["stats"]["motion_outliers"], pnp_failures=hip["stats"]["pnp_failures"],
+                landmarks=hip["backend"]["landmarks"], ba_runs=len(hip["backend"]["ba"]),
+                ba_converged=sum(1 for b in hip["backend"]["ba"] if b["termination"] == 0))
+
+
+def compare_with_golden(hip, path):
+    """the CPU oracle pipeline's recorded run of the same sequence (tools/gen_replay_golden.py)"""
+    g = np.load(path)
+    e = rmse(hip["poses"], list(zip(g["R"], g["t"])))
+    return dict(file=os.path.relpath(path, ROOT), same_match_counts=hip["stats"]["matches"] == g["matches"].tolist(),
+                same_keyframes=hip["keyframes"] == g["keyframes"].tolist(), pose_rmse_vs_cpu_pipeline=e,
+                landmarks_cpu=int(g["landmarks"]), landmarks_hip=int(hip["backend"]["landmarks"]))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(gpus, argv):
+    """`replay_tracking.py --gpus N` outside a launcher: start the N ranks (one process per GPU) as a CHILD process — nothing in this
+    process has touched the GPU or imported torch — and exit with its code (as bench.py does)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def run_ranks(a):
+    """one process per GPU (BASELINE configs[4] "across 8 GPUs"): phase 1 sharded over the ranks, ONE dvs_comm_all_gather, the sequential
+    tracking + backend on rank 0"""
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local, "pid": os.getpid()}), flush=True)
+        return
+    import torch  # noqa: F401  (one ROCm stack per process: tests/conftest.py)
+    import torch.distributed as dist
+    from dvslam_amd import synth
+    from dvslam_amd import dist as dvdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")                                     # only the hand-over of the RCCL unique id and the final barrier
+    n, cols, rows, nf, f, z0 = a.frames, a.cols, a.rows, a.nfeatures, 600.0, 1.5
+    depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    fe = BatchedFrontEnd(nf, rows, cols, 64, local)                      # handles (and their streams) before the communicator comes up
+    fe.run([synth.make_traj_frame(t, cols, rows) for t in range(2)], depth)
+
+    def bcast_id(ident):
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    comm = dvdist.Comm(local, rank, world, bcast_id)
+    dist.barrier()
+    t0 = time.perf_counter()
+    pre = sharded_front_end_rank(lambda t: synth.make_traj_frame(t, cols, rows), n, depth, nf, rank, world, comm, local, 64, fe)
+    t_phase1 = time.perf_counter() - t0                                  # includes this rank's share of the frame synthesis
+    if rank == 0:
+        hip = track_batched(HipStages(nf), n, cols, rows, f, z0, nf, a.ba_every, None, pre)
+        hip["seconds_in_stages"] += t_phase1
+        r = dict(config=dict(frames=n, resolution=[cols, rows], nfeatures=nf, gpus=world, rccl_version=comm.rccl_version,
+                             phases=f"phase 1 sharded over {world} ranks (one process per GPU), one dvs_comm_all_gather (ncclAllGather), tracking on rank 0"),
+                 hip=summarize_hip(hip, n, ground_truth(n, f, z0), t_phase1, time.perf_counter() - t0))
+        if a.golden:
+            r["golden"] = compare_with_golden(hip, a.golden)
+        print(json.dumps(r, indent=1), flush=True)
+        if a.out:
+            json.dump(r, open(a.out, "w"), indent=1)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="N >= 1: one process per GPU (self-launched through torch.distributed.run unless already "
+                                                        "under a launcher): phase 1 sharded over the ranks, one all-gather, tracking on rank 0")
+    ap.add_argument("--loopback", type=int, default=0, help="N logical ranks of ONE process on one GPU (dvs_comm_create_loopback) instead of N processes")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus: only start the ranks and report them (launcher self-test, no GPU work)")
+    ap.add_argument("--golden", default="", help="npz of the CPU oracle pipeline's recorded run to compare with (tests/golden/replay_1000_cpu.npz)")
+    ap.add_argument("--ba-every", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--rows", type=int, default=480)
@@ -582,7 +795,26 @@ if __name__ == "__main__":
     ap.add_argument("--shards", type=int, default=1, help="contiguous frame ranges of phase 1 (one per rank on a multi-GPU node)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    if a.gpus >= 1:
+        if "WORLD_SIZE" not in os.environ:
+            sys.exit(self_launch(a.gpus, sys.argv[1:]))
+        run_ranks(a)
+        sys.exit(0)
     import torch  # noqa: F401  (one ROCm stack per process: tests/conftest.py)
+    if a.loopback >= 1:
+        from dvslam_amd import synth
+        frames = [synth.make_traj_frame(t, a.cols, a.rows) for t in range(a.frames)]
+        depth = np.full((a.rows, a.cols), 1500, np.uint16)
+        t0 = time.perf_counter()
+        pre = sharded_front_end_loopback(frames, depth, a.nfeatures, a.loopback)[0]
+        t1 = time.perf_counter() - t0
+        hip = track_batched(HipStages(a.nfeatures), a.frames, a.cols, a.rows, 600.0, 1.5, a.nfeatures, a.ba_every, None, pre)
+        hip["seconds_in_stages"] += t1
+        r = dict(config=dict(frames=a.frames, loopback_ranks=a.loopback), hip=summarize_hip(hip, a.frames, ground_truth(a.frames, 600.0, 1.5), t1, time.perf_counter() - t0))
+        if a.golden:
+            r["golden"] = compare_with_golden(hip, a.golden)
+        print(json.dumps(r, indent=1))
+        sys.exit(0)
     r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True, batched=not a.per_frame, shards=a.shards)
     r.pop("_raw")
     print(json.dumps(r, indent=1))
