@@ -566,12 +566,20 @@ __global__ __launch_bounds__(256) void k_lm_schur(int K, int L, int n, const int
   }
 }
 
-// Dense Cholesky + two triangular solves of the n x n reduced system, one workgroup, everything in LDS.
-// Right-looking on the matrix AUGMENTED by the right-hand side as row n: at column j the scaled column l_ij = a_ij / sqrt(a_jj) is
-// written to a second array, then the threads subtract l_ij l_kj from the trailing lower triangle — element (i, k) thus receives the
-// subtractions j = 0, 1, ... in the same order as the host routine's dot products (chol_solve), i.e. the factor is bit-identical to
-// it (one barrier per column, see the look-ahead below; every thread scaling the entries it needs itself, the other way to save
-// the second barrier, costs more in redundant f64 divisions: 72 us against 58).
+// Dense Cholesky + two triangular solves of the n x n reduced system (n = 6 per free camera), one workgroup, everything in LDS.
+// Right-looking on the matrix AUGMENTED by the right-hand side as row n, in place, BLOCKED by the 6 columns of a camera (round 4; the
+// column-at-a-time form of rounds 1-3 paid one workgroup barrier and three LDS round trips per column: 31.7 us for n = 54):
+//   * the first wavefront is the PANEL: lane = row (two rows per lane past 64), the row's six entries of the block column in registers.
+//     It factors the 6 x 6 diagonal block and scales the rows below in one go — pivots and the block's l_tj broadcast by readlane, no
+//     LDS and no barrier inside the chain of six dependent sqrt / divide steps — and writes the finished columns to LDS;
+//   * the other fifteen wavefronts subtract the panel's rank-6 product from the trailing triangle, six mul + sub per element IN COLUMN
+//     ORDER, so element (i, k) receives the subtractions j = 0, 1, ... exactly as the host routine's dot products do (chol_solve): the
+//     factor is bit-identical to it;
+//   * look-ahead: while they do, the panel wavefront applies the same update to the NEXT block column only and factors it straight from
+//     its registers.  One barrier per block column (n / 6 + 1 in all).  Measured: 31.7 -> 27.4 us for n = 54 (the chain of 54 dependent
+//     f64 sqrt + divide + broadcast steps of ONE wavefront is what is left: ~0.4 us each).  Keeping the next block column in registers as
+//     well and subtracting every finished column from it inside the chain — bit-identical — runs 55.8 us: the fully unrolled body with
+//     run-time lane indices for the broadcasts and a third register set serialises more than it hides (profiles/r04_ba_lm_kernel_stats.csv).
 // Row n undergoes exactly the host's forward substitution (y_j = (b_j - sum_k l_jk y_k) / l_jj, same order), so L y = b costs nothing
 // extra.  The backward substitution applies its updates from the last unknown down (a different association from the host's:
 // rounding-level) — for n <= 64 in the registers of one wavefront (x_j broadcast by readlane, the factor's row prefetched: no LDS
@@ -580,8 +588,7 @@ constexpr int kCholThreads = 1024;   // one panel wavefront + fifteen for the tr
 __global__ __launch_bounds__(kCholThreads) void k_lm_chol(int K, int n, const int* __restrict__ slotCam, const double* __restrict__ S,
                                                  const double* __restrict__ rhs, double* __restrict__ step, LmStatus* __restrict__ st) {
   extern __shared__ double lds[];
-  double* A = lds;                             // working lower triangle, row-major (n + 1) x n: row n = the right-hand side
-  double* Lm = lds + (size_t)(n + 1) * n;      // the factor, same shape: row n = y
+  double* A = lds;                             // lower triangle, row-major (n + 1) x n, factored in place: row n = the right-hand side -> y
   __shared__ int bad;
   const int tid = threadIdx.x;
   // the system from k_lm_schur's pieces: the H_pp part minus the kSchurSplit landmark sums in split order (block lower triangle)
@@ -611,70 +618,110 @@ __global__ __launch_bounds__(kCholThreads) void k_lm_chol(int K, int n, const in
   for (int i = tid; i < 6 * K; i += kCholThreads) step[i] = 0.0;
   if (tid == 0) bad = 0;
   __syncthreads();
-  // Look-ahead: the first wavefront is the panel — at step j it applies column j's update to column j + 1 only, takes the square
-  // root of the new pivot and scales that column (the chain of dependent f64 sqrt / divide the factorisation is bound by) — while the
-  // other three subtract l_ij l_kj from the rest of the trailing triangle.  One barrier per column.
   const int wave = tid >> 6, lane = tid & 63;
   auto bcast = [](double v, int src) -> double {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
   };
-  // scale column c from the values a0 (row c + lane) / a1 (row c + lane + 64); lane 0 holds the pivot
-  auto panel = [&](int c, double a0, double a1) {
-    const double piv = bcast(a0, 0);
-    if (!(piv > 0) && lane == 0) bad = 1;   // the factorisation runs on (NaNs from here): no flag to poll on the chain of columns
-    const double d = sqrt(piv);
-    if (lane == 0) Lm[(size_t)c * n + c] = d;
-    else if (c + lane <= n) Lm[(size_t)(c + lane) * n + c] = a0 / d;
-    if (c + 64 <= n && c + lane + 64 <= n) Lm[(size_t)(c + lane + 64) * n + c] = a1 / d;
+  // panel wavefront: a0 / a1 = the six entries of block column c of rows c + lane / c + lane + 64 (all earlier updates applied).
+  // Factors the diagonal block, scales the rows below, writes columns c .. c + 5.
+  auto panel = [&](int c, double (&a0)[6], double (&a1)[6]) {
+    const int r0 = c + lane, r1 = c + lane + 64;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double piv = bcast(a0[j], j);
+      if (!(piv > 0) && lane == 0) bad = 1;   // the factorisation runs on (NaNs from here): no flag to poll on the chain of columns
+      const double d = sqrt(piv);
+      a0[j] = lane == j ? d : a0[j] / d;
+      a1[j] = a1[j] / d;
+#pragma unroll
+      for (int t = j + 1; t < 6; t++) {
+        const double lt = bcast(a0[j], t);    // l of row c + t, column c + j
+        a0[t] -= a0[j] * lt;
+        a1[t] -= a1[j] * lt;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      if (lane >= j && r0 <= n) A[(size_t)r0 * n + c + j] = a0[j];
+      if (r1 <= n) A[(size_t)r1 * n + c + j] = a1[j];
+    }
   };
-  if (wave == 0) panel(0, A[(size_t)min(lane, n) * n], A[(size_t)min(lane + 64, n) * n]);
+  double a0[6], a1[6];
+  if (wave == 0) {
+    const int r0 = min(lane, n), r1 = min(lane + 64, n);
+#pragma unroll
+    for (int j = 0; j < 6; j++) { a0[j] = A[(size_t)r0 * n + j]; a1[j] = A[(size_t)r1 * n + j]; }
+    panel(0, a0, a1);
+  }
   __syncthreads();
   constexpr int kTy = (kCholThreads - 64) / 16;
   const int t3 = tid - 64, ty = t3 >> 4, tx = t3 & 15;   // the other wavefronts: kTy x 16 tiling of the trailing block
-  for (int j = 0; j < n; j++) {
-    const int m = n - j;                 // rows j+1 .. n (the right-hand side included) of the trailing block; columns j+1 .. n-1
+  for (int c0 = 0; c0 < n; c0 += 6) {
+    const int c1 = c0 + 6;
     if (wave == 0) {
-      const int c = j + 1;
-      if (c < n) {
-        const double lc = Lm[(size_t)c * n + j];
-        const int r0 = min(c + lane, n), r1 = min(c + lane + 64, n);
-        double a1 = 0.0;
-        if (c + 64 <= n) a1 = A[(size_t)r1 * n + c] - Lm[(size_t)r1 * n + j] * lc;
-        panel(c, A[(size_t)r0 * n + c] - Lm[(size_t)r0 * n + j] * lc, a1);
+      if (c1 < n) {
+        // look-ahead: block column c1 of rows c1 + lane (+ 64) minus the panel's product, then its factorisation from the registers
+        const int r0 = min(c1 + lane, n), r1 = min(c1 + lane + 64, n);
+        double l0[6], l1[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          l0[j] = A[(size_t)r0 * n + c0 + j]; l1[j] = A[(size_t)r1 * n + c0 + j];
+          a0[j] = A[(size_t)r0 * n + c1 + j]; a1[j] = A[(size_t)r1 * n + c1 + j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++)
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const double lk = bcast(l0[j], kk);   // l of row c1 + kk, column c0 + j
+            a0[kk] -= l0[j] * lk;
+            a1[kk] -= l1[j] * lk;
+          }
+        panel(c1, a0, a1);
       }
     } else {
-      for (int i = 1 + ty; i < m; i += kTy) {
-        const double li = Lm[(size_t)(j + 1 + i) * n + j];
-        const int kmax = min(i, m - 2);  // the right-hand side row has no diagonal element
-        for (int k = 1 + tx; k <= kmax; k += 16) A[(size_t)(j + 1 + i) * n + j + 1 + k] -= li * Lm[(size_t)(j + 1 + k) * n + j];
+      const int s0 = c1 + 6;               // first row / column the look-ahead does not cover
+      for (int i = s0 + ty; i <= n; i += kTy) {
+        double li[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) li[j] = A[(size_t)i * n + c0 + j];
+        const int kmax = min(i, n - 1);    // the right-hand side row has no diagonal element
+        for (int k = s0 + tx; k <= kmax; k += 16) {
+          double acc = A[(size_t)i * n + k];
+#pragma unroll
+          for (int j = 0; j < 6; j++) acc -= li[j] * A[(size_t)k * n + c0 + j];
+          A[(size_t)i * n + k] = acc;
+        }
       }
     }
     __syncthreads();
   }
-  __syncthreads();
   if (bad) { if (tid == 0) st->ok = 0; return; }
   if (tid >= 64) return;
-  const double* y = Lm + (size_t)n * n;
+  const double* Lm = A;
+  const double* y = A + (size_t)n * n;
   if (n <= 64) {
     // backward: L^T x = y with x in registers (lane i holds unknown i)
     const int li = min(lane, n - 1);
     double bi = y[li];
-    double lrow = Lm[(size_t)(n - 1) * n + li], dj = Lm[(size_t)(n - 1) * n + (n - 1)];
+    // (x_j = b_j * (1 / l_jj): the reciprocal is formed one step ahead, off the chain of n dependent steps — one rounding more than the
+    // host's division, in a substitution whose association already differs from the host's)
+    double lrow = Lm[(size_t)(n - 1) * n + li], rj = 1.0 / Lm[(size_t)(n - 1) * n + (n - 1)];
     for (int j = n - 1; j >= 0; j--) {
-      const double lcur = lrow, dcur = dj;
-      if (j > 0) { lrow = Lm[(size_t)(j - 1) * n + min(li, j - 1)]; dj = Lm[(size_t)(j - 1) * n + (j - 1)]; }   // next step's row, off the chain
+      const double lcur = lrow, rcur = rj;
+      if (j > 0) { lrow = Lm[(size_t)(j - 1) * n + min(li, j - 1)]; rj = 1.0 / Lm[(size_t)(j - 1) * n + (j - 1)]; }   // next step's row, off the chain
       const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(bi) & 0xffffffffll), j);
       const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(bi) >> 32), j);
-      const double xj = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) / dcur;
+      const double xj = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) * rcur;
       if (lane == j) bi = xj;
       else if (lane < j) bi -= lcur * xj;
     }
     if (lane < n) step[6 * slotCam[lane / 6] + lane % 6] = bi;
   } else {
     // the same chain through LDS for larger systems: wave-level fences instead of workgroup barriers
-    double* b = A;                       // the working triangle is dead: reuse its first row
+    __shared__ double bsh[128];
+    double* b = bsh;
     for (int i = lane; i < n; i += 64) b[i] = y[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     for (int j = n - 1; j >= 0; j--) {
@@ -1558,7 +1605,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
       h->d_status = (LmStatus*)(B + o_status);
       if (!h->h_status) {
         DVS_HIP(hipHostMalloc((void**)&h->h_status, 2 * sizeof(LmStatus)));   // [0]: the trial's record (k_lm_norms), [1]: the point's (k_lm_gmax)
-        DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 97 * 96 * 8));
+        DVS_HIP(hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 97 * 96 * 8));
       }
       const size_t outBytes = ((size_t)7 * Kz + 3 * Lz) * 8;
       if (outBytes > h->h_out_cap) {
@@ -1647,7 +1694,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
     reuse_diagonal = true;
     hipLaunchKernelGGL(k_lm_schur, dim3(nc, nc, kSchurSplit), dim3(256), 0, st, K, L, n, h->d_slotCam, h->d_obsOf, h->d_active, h->d_Hpp, h->d_g, h->d_scale,
                        h->d_diag, radius, h->d_Ws, h->d_Y, h->d_S, h->d_rhs);
-    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(kCholThreads), 2 * (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
+    hipLaunchKernelGGL(k_lm_chol, dim3(1), dim3(kCholThreads), (size_t)(n + 1) * n * 8, st, K, n, h->d_slotCam, h->d_S, h->d_rhs, h->d_step, h->d_status);
     hipLaunchKernelGGL(k_lm_backsub, dim3((4 * L + 255) / 256), dim3(256), 0, st, K, L, h->d_Hll, h->d_g, h->d_lmStart, h->d_lmObs, h->d_cam,
                        h->d_scale, h->d_active, h->d_Vinv, h->d_Ws, h->d_step, h->d_lmPart, h->d_status);
     hipLaunchKernelGGL(k_lm_candidate, dim3(nparts), dim3(256), 0, st, K, L, h->d_q0, h->d_t0, h->d_X0, h->d_step, h->d_scale, h->d_active,

@@ -1126,7 +1126,25 @@ struct FmSubset {
 
 }  // namespace dvs
 
+#include "pnp_cv.h"   // cv::solvePnPRansac by OpenCV's procedure: EPnP hypotheses, float scoring, solvePnP(ITERATIVE) refit (needs RansacProb, block_count256)
+
 using namespace dvs;
+
+// the 5-point samples of cv::solvePnPRansac's RANSAC stage: getSubset without a checkSubset (host: the sequence is sequential by nature)
+static void cv_subsets_nocheck(int n, int modelPoints, int iters, int32_t* idx_out) {
+  CvRng rng(~0ull);
+  for (int it = 0; it < iters; it++)
+    for (int i = 0; i < modelPoints; i++) {
+      int v;
+      bool dup;
+      do {
+        v = rng.uniform(0, n);
+        dup = false;
+        for (int j = 0; j < i; j++) dup = dup || idx_out[(size_t)it * modelPoints + j] == v;
+      } while (dup);
+      idx_out[(size_t)it * modelPoints + i] = v;
+    }
+}
 
 extern "C" {
 
@@ -1262,9 +1280,97 @@ dvs_status dvs_find_fundamental_cv(dvs_matcher* ctx, const float* pts1, const fl
 
 // host only (no GPU): the sample sequence of the call above — iteration it draws idx[7 it .. 7 it + 6]; *found = iterations that have one
 dvs_status dvs_cv_ransac_subsets(const float* pts1, const float* pts2, int32_t n, int32_t model_points, int32_t iterations, int32_t* idx, int32_t* found) {
-  DVS_ARG(pts1 && pts2 && idx && found && n >= model_points && model_points >= 1 && model_points <= 16 && iterations >= 0);
-  *found = cv_subsets(pts1, pts2, n, model_points, iterations, idx);
+  DVS_ARG(idx && found && n >= model_points && model_points >= 1 && model_points <= 16 && iterations >= 0 && (pts1 == nullptr) == (pts2 == nullptr));
+  if (!pts1) { cv_subsets_nocheck(n, model_points, iterations, idx); *found = iterations; }   // a callback without checkSubset (solvePnPRansac)
+  else *found = cv_subsets(pts1, pts2, n, model_points, iterations, idx);
   return DVS_OK;
+}
+
+// cv::solvePnPRansac(obj, img, K, no distortion, rvec, tvec, false, iterations, reproj_err, confidence, inliers) as OpenCV 4.x runs it with
+// its default flags (csrc/pnp_cv.h).  Problems with fewer than 6 points are refused per problem (success 0; the reference returns before
+// the call, frontend.cpp:900).  iterations_run[b] = iterations the adaptive loop used (may be NULL).
+dvs_status dvs_solve_pnp_ransac_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts3d, const float* pts2d, const double* K4,
+                                         int32_t iterations, double reproj_err, double confidence, double* rvec3, double* tvec3, int32_t* inliers,
+                                         int32_t* n_inliers, int32_t* success, int32_t* iterations_run) {
+  DVS_ARG(ctx && nprob >= 0 && iterations >= 1 && iterations <= 1024 && K4 && reproj_err > 0 && confidence > 0 && confidence < 1);
+  if (nprob == 0) return DVS_OK;
+  DVS_ARG(offsets && rvec3 && tvec3 && success && offsets[0] == 0);
+  for (int b = 0; b < nprob; b++) DVS_ARG(offsets[b + 1] >= offsets[b]);
+  const int total = offsets[nprob];
+  DVS_ARG(total == 0 || (pts3d && pts2d));
+  memset(success, 0, (size_t)nprob * 4);
+  if (n_inliers) memset(n_inliers, 0, (size_t)nprob * 4);
+  if (iterations_run) memset(iterations_run, 0, (size_t)nprob * 4);
+  memset(rvec3, 0, (size_t)nprob * 24); memset(tvec3, 0, (size_t)nprob * 24);
+  DVS_HIP(hipSetDevice(matcher_device(ctx)));
+  hipStream_t st = matcher_stream(ctx);
+  const int H = iterations;
+  const size_t hb = ((size_t)nprob * sizeof(RansacProb) + 15) & ~(size_t)15, ob = ((size_t)total * 12 + 15) & ~(size_t)15, ib = ((size_t)total * 8 + 15) & ~(size_t)15;
+  const size_t sb = ((size_t)nprob * H * 5 * 4 + 15) & ~(size_t)15;
+  const size_t inb = hb + ob + ib + sb;
+  const size_t mb = (size_t)nprob * H * 18 * 8, vb = (size_t)nprob * H * 4, selb = (size_t)nprob * 16;
+  const size_t outb = (size_t)nprob * 64 + (size_t)total * 4 + selb;      // [result records 64 x nprob | inlier lists 4 x total | select records]
+  uint8_t* base;
+  DVS_TRY(matcher_scratch(ctx, 0, inb + mb + vb + outb + 64, (void**)&base));
+  const RansacProb* d_probs = (const RansacProb*)base;
+  float* d_obj = (float*)(base + hb); float* d_img = (float*)(base + hb + ob);
+  const int* d_samples = (const int*)(base + hb + ob + ib);
+  double* d_models = (double*)(base + inb);
+  int* d_counts = (int*)(base + inb + mb);
+  uint8_t* d_out = base + inb + mb + vb;
+  int* d_inl = (int*)(d_out + (size_t)nprob * 64);
+  int* d_sel = (int*)(d_out + (size_t)nprob * 64 + (size_t)total * 4);
+  uint8_t* hio; int *hseq, *counter;
+  DVS_TRY(matcher_pinned(ctx, inb + outb, (void**)&hio, &hseq, &counter));
+  RansacProb* hp = (RansacProb*)hio;
+  int32_t* hs = (int32_t*)(hio + hb + ob + ib);
+  memset(hs, 0, sb);
+  for (int b = 0; b < nprob; b++) {
+    const int n = offsets[b + 1] - offsets[b];
+    const bool run = n >= 6;     // (n == 5 would be solvePnP on all points, n == 4 the P3P kernel: not what the reference can reach)
+    if (run) cv_subsets_nocheck(n, 5, H, hs + (size_t)b * H * 5);
+    hp[b] = RansacProb{offsets[b], n, (unsigned long long)(run ? H : 0)};   // the seed field: iterations that have a sample
+  }
+  memcpy(hio + hb, pts3d, (size_t)total * 12); memcpy(hio + hb + ob, pts2d, (size_t)total * 8);
+  const int ndw_in = (int)(inb / 4);
+  hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
+  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+  const float thr = (float)(reproj_err * reproj_err);
+  hipLaunchKernelGGL(k_epnp_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_obj, d_img, d_probs, d_samples, H, fx, fy, cx, cy, d_models);
+  hipLaunchKernelGGL(k_pnpcv_score, dim3(H, nprob), dim3(256), 0, st, d_obj, d_img, d_probs, H, d_models, fx, fy, cx, cy, thr, d_counts);
+  hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H, d_probs, 5, confidence, 1, d_sel, 1, H);
+  hipLaunchKernelGGL(k_pnpcv_refit, dim3(nprob), dim3(64), 0, st, d_obj, d_img, d_probs, H, d_models, d_sel, fx, fy, cx, cy, thr, d_inl, d_out);
+  uint8_t* hout = hio + inb;
+  if (outb <= 65536) {
+    const int seq = ++*counter;
+    hipLaunchKernelGGL(k_io_export, dim3(1), dim3(256), 0, st, (const uint32_t*)d_out, (uint32_t*)hout, (int)(outb / 4), hseq, seq);
+    DVS_HIP(hipGetLastError());
+    DVS_TRY(io_wait(hseq, seq, st));
+  } else {
+    DVS_HIP(hipGetLastError());
+    DVS_HIP(hipMemcpyAsync(hout, d_out, outb, hipMemcpyDeviceToHost, st));
+    DVS_HIP(hipStreamSynchronize(st));
+  }
+  const int* hsel = (const int*)(hout + (size_t)nprob * 64 + (size_t)total * 4);
+  for (int b = 0; b < nprob; b++) {
+    int nin = 0, succ = 0;
+    memcpy(&nin, hout + 64 * (size_t)b, 4); memcpy(&succ, hout + 64 * (size_t)b + 4, 4);
+    if (n_inliers) n_inliers[b] = nin;
+    if (iterations_run) iterations_run[b] = hsel[4 * b + 1];
+    success[b] = succ;
+    if (hsel[4 * b] >= 0) { memcpy(rvec3 + 3 * (size_t)b, hout + 64 * (size_t)b + 16, 24); memcpy(tvec3 + 3 * (size_t)b, hout + 64 * (size_t)b + 40, 24); }
+    if (inliers && nin > 0) memcpy(inliers + offsets[b], hout + (size_t)nprob * 64 + 4 * (size_t)offsets[b], (size_t)nin * 4);
+  }
+  return DVS_OK;
+}
+
+dvs_status dvs_solve_pnp_ransac_cv(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
+                                   double reproj_err, double confidence, double* rvec3, double* tvec3, int32_t* inliers, int32_t* n_inliers,
+                                   int32_t* success, int32_t* iterations_run) {
+  DVS_ARG(ctx && n >= 0 && rvec3 && tvec3 && success);
+  const int32_t offsets[2] = {0, n};
+  return dvs_solve_pnp_ransac_cv_batch(ctx, 1, offsets, pts3d, pts2d, K4, iterations, reproj_err, confidence, rvec3, tvec3, inliers, n_inliers, success,
+                                       iterations_run);
 }
 
 dvs_status dvs_find_fundamental_ransac(dvs_matcher* ctx, const float* pts1, const float* pts2, int32_t n, double threshold, double confidence,

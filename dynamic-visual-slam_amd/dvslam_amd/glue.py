@@ -59,6 +59,28 @@ class FrontendGlue:
                                            ptr(inl), C.byref(nin), C.byref(ok)))
         return bool(ok.value), rvec, tvec, inl[:nin.value].copy()
 
+    def solve_pnp_ransac_cv(self, pts3d, pts2d, K4, iterations=100, reproj_err=4.0, confidence=0.99):
+        """cv::solvePnPRansac as OpenCV 4.x runs it with its default flags (dvs_solve_pnp_ransac_cv): EPnP on cv::RNG's 5-point samples,
+        float scoring, adaptive stop, solvePnP(ITERATIVE) refit -> (success, rvec, tvec, inlier indices, iterations run)"""
+        return self.solve_pnp_ransac_cv_batch([pts3d], [pts2d], K4, iterations, reproj_err, confidence)[0]
+
+    def solve_pnp_ransac_cv_batch(self, pts3d_list, pts2d_list, K4, iterations=100, reproj_err=4.0, confidence=0.99):
+        nprob = len(pts3d_list)
+        off = np.zeros(nprob + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in pts3d_list])
+        o = (np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 3) for p in pts3d_list]), np.float32) if off[-1]
+             else np.zeros((1, 3), np.float32))
+        i2 = (np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in pts2d_list]), np.float32) if off[-1]
+              else np.zeros((1, 2), np.float32))
+        K = np.ascontiguousarray(K4, np.float64)
+        rv = np.zeros((max(nprob, 1), 3)); tv = np.zeros((max(nprob, 1), 3)); inl = np.zeros(max(int(off[-1]), 1), np.int32)
+        nin = np.zeros(max(nprob, 1), np.int32); ok = np.zeros(max(nprob, 1), np.int32); its = np.zeros(max(nprob, 1), np.int32)
+        self._L.dvs_solve_pnp_ransac_cv_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.dvs_solve_pnp_ransac_cv_batch(self._h, nprob, ptr(off), ptr(o), ptr(i2), ptr(K), iterations, reproj_err, confidence, ptr(rv), ptr(tv),
+                                                    ptr(inl), ptr(nin), ptr(ok), ptr(its)))
+        return [(bool(ok[b]), rv[b].copy(), tv[b].copy(), inl[off[b]:off[b] + nin[b]].copy(), int(its[b])) for b in range(nprob)]
+
     def find_fundamental_ransac_batch(self, pts1_list, pts2_list, seeds, threshold=2.0, confidence=0.99, max_iters=1000):
         """many independent problems in one launch sequence -> list of (mask uint8[n_b], inliers of the model)"""
         nprob = len(pts1_list)
@@ -191,6 +213,13 @@ def unpack_keyframe(payload, cap_n=4096):
                 translation=np.array(hdr.translation[:]), rotation_xyzw=np.array(hdr.rotation_xyzw[:]),
                 landmark_ids=lid[:nl.value], landmark_xyz=xyz[:nl.value], obs_landmark_ids=oid[:no.value], obs_pixels=px[:no.value],
                 obs_desc=desc[:no.value])
+
+
+def cv_ransac_subsets_nocheck(n, model_points, iterations):
+    """host only: the samples of a RANSAC callback WITHOUT checkSubset (cv::solvePnPRansac's 5-point samples): dvs_cv_ransac_subsets(NULL, NULL, ...)"""
+    idx = np.zeros((max(iterations, 1), model_points), np.int32); found = C.c_int32()
+    check(lib().dvs_cv_ransac_subsets(None, None, n, model_points, iterations, ptr(idx), C.byref(found)))
+    return idx[:found.value]
 
 
 def cv_ransac_subsets(pts1, pts2, model_points, iterations):

@@ -422,7 +422,8 @@ dvs_status dvs_find_fundamental_cv(dvs_matcher* ctx, const float* pts1, const fl
 dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
                                          double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations);
 /* host only (works without a GPU): the sample sequence of the call above — iteration i drew idx[model_points i ..]; *found =
- * iterations that have a sample (cv::RNG((uint64)-1), uniform(0, n) = next() % n, repeats and collinear samples drawn again) */
+ * iterations that have a sample (cv::RNG((uint64)-1), uniform(0, n) = next() % n, repeats and collinear samples drawn again).
+ * pts1 = pts2 = NULL: a callback WITHOUT checkSubset — the 5-point samples of dvs_solve_pnp_ransac_cv (model_points = 5). */
 dvs_status dvs_cv_ransac_subsets(const float* pts1, const float* pts2, int32_t n, int32_t model_points, int32_t iterations, int32_t* idx, int32_t* found);
 /* cv::solvePnPRansac(obj, img, K, noArray, rvec, tvec, false, iterations = 100, reproj_err = 4.0, confidence = 0.99, inliers)
  * (frontend.cpp:911-921; zero distortion): obj n x 3 float (camera frame of the previous image), img n x 2 float,
@@ -436,6 +437,23 @@ dvs_status dvs_solve_pnp_ransac(dvs_matcher* ctx, const float* pts3d, const floa
 dvs_status dvs_solve_pnp_ransac_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts3d, const float* pts2d, const double* K4,
                                       int32_t iterations, double reproj_err, double confidence, const uint64_t* seeds, double* rvec3, double* tvec3,
                                       int32_t* inliers /* offsets[nprob] or NULL */, int32_t* n_inliers /* nprob or NULL */, int32_t* success /* nprob */);
+
+/* cv::solvePnPRansac(points3d, points2d, K, no distortion, rvec, tvec, false, iterations, reproj_err, confidence, inliers) AS OPENCV 4.x
+ * RUNS IT with its default flags for the reference's call (frontend.cpp:911-921: 100, 4.0, 0.99) — csrc/pnp_cv.h: the 5-point samples of
+ * ONE cv::RNG((uint64)-1), the EPnP minimal solver, projectPoints + squared error + threshold in float, the adaptive iteration count
+ * (RANSACUpdateNumIters, 5 model points), then solvePnP(SOLVEPNP_ITERATIVE) on the inliers of the best model (planar / DLT initialisation
+ * + CvLevMarq, 20 iterations, FLT_EPSILON).  inliers: the best model's inlier indices in index order (capacity n), as OpenCV returns them.
+ * success = 0 with a model: the refit could not be initialised, rvec / tvec are the RANSAC stage's (OpenCV returns false there too).
+ * Fewer than 6 points: success 0, nothing else written (the reference returns before the call, frontend.cpp:900).  PARITY UNPINNED:
+ * restated from the published sources; every SVD is a Jacobi eigen-decomposition here (same models to rounding).  On an EXACTLY planar
+ * point set EPnP's fourth control point coincides with the centroid and M^T M gains a trivial three-dimensional null space that its
+ * N <= 3 approximations cannot leave — in OpenCV as here; dvs_solve_pnp_ransac (P3P) has no such case. */
+dvs_status dvs_solve_pnp_ransac_cv(dvs_matcher* ctx, const float* pts3d, const float* pts2d, int32_t n, const double* K4, int32_t iterations,
+                                   double reproj_err, double confidence, double* rvec3, double* tvec3, int32_t* inliers, int32_t* n_inliers,
+                                   int32_t* success, int32_t* iterations_run);
+dvs_status dvs_solve_pnp_ransac_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts3d, const float* pts2d, const double* K4,
+                                         int32_t iterations, double reproj_err, double confidence, double* rvec3, double* tvec3, int32_t* inliers,
+                                         int32_t* n_inliers, int32_t* success, int32_t* iterations_run);
 
 /* Harris corner measure as cv::ORB scores keypoints (ORB::HARRIS_SCORE, the mode test_dbow2_integration.cpp:19 runs with:
  * OpenCV features2d orb.cpp HarrisResponses — integer 3x3 gradients over a block_size^2 window, response = (ab - c^2 - k(a+b)^2)

@@ -398,6 +398,11 @@ def _ransac_lib():
     L.orc_find_fundamental_cv.argtypes = [vp, vp, i32, dbl, dbl, i32, vp, vp, vp]
     L.orc_solve_pnp_ransac.restype = i32
     L.orc_solve_pnp_ransac.argtypes = [vp, vp, i32, vp, i32, dbl, dbl, u64, vp, vp, vp, vp, vp]
+    L.orc_solve_pnp_ransac_cv.restype = i32
+    L.orc_solve_pnp_ransac_cv.argtypes = [vp, vp, i32, vp, i32, dbl, dbl, vp, vp, vp, vp, vp, vp]
+    L.orc_cv_subsets_nocheck.restype = i32; L.orc_cv_subsets_nocheck.argtypes = [i32, i32, i32, vp]
+    L.orc_epnp.argtypes = [vp, vp, i32, vp, vp, vp]; L.orc_epnp.restype = None
+    L.orc_solve_pnp_iterative.restype = i32; L.orc_solve_pnp_iterative.argtypes = [vp, vp, i32, vp, vp, vp]
     return L
 
 
@@ -458,6 +463,37 @@ def find_fundamental_cv(p1, p2, threshold=2.0, confidence=0.99, max_iters=1000):
     F = np.zeros(9); mask = np.zeros(max(len(p1), 1), np.uint8); sel = np.zeros(3, np.int32)
     _ransac_lib().orc_find_fundamental_cv(_p(p1), _p(p2), len(p1), threshold, confidence, max_iters, _p(F), _p(mask), _p(sel))
     return F.reshape(3, 3), mask[:len(p1)], sel
+
+
+def solve_pnp_ransac_cv(obj, img, K4, iterations=100, reproj_err=4.0, confidence=0.99):
+    """cv::solvePnPRansac by OpenCV's procedure (oracle/pnp_cv_oracle.cpp) -> (ok, rvec, tvec, inliers, sel = (best iteration, iterations run,
+    best count), the RANSAC stage's model (rvec, tvec))"""
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3); img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    K4 = np.ascontiguousarray(K4, np.float64)
+    rvec = np.zeros(3); tvec = np.zeros(3); inl = np.zeros(max(len(obj), 1), np.int32); nin = C.c_int(); sel = np.zeros(3, np.int32); m6 = np.zeros(6)
+    ok = _ransac_lib().orc_solve_pnp_ransac_cv(_p(obj), _p(img), len(obj), _p(K4), iterations, reproj_err, confidence, _p(rvec), _p(tvec), _p(inl),
+                                               C.byref(nin), _p(sel), _p(m6))
+    return bool(ok), rvec, tvec, inl[:nin.value].copy(), sel, m6
+
+
+def cv_subsets_nocheck(n, k, iters):
+    idx = np.zeros((iters, k), np.int32)
+    _ransac_lib().orc_cv_subsets_nocheck(n, k, iters, _p(idx))
+    return idx
+
+
+def epnp(obj, img, K4):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3); img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    r = np.zeros(3); t = np.zeros(3)
+    _ransac_lib().orc_epnp(_p(obj), _p(img), len(obj), _p(np.ascontiguousarray(K4, np.float64)), _p(r), _p(t))
+    return r, t
+
+
+def solve_pnp_iterative(obj, img, K4):
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3); img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    r = np.zeros(3); t = np.zeros(3)
+    ok = _ransac_lib().orc_solve_pnp_iterative(_p(obj), _p(img), len(obj), _p(np.ascontiguousarray(K4, np.float64)), _p(r), _p(t))
+    return bool(ok), r, t
 
 
 def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_err=4.0, confidence=0.99, seed=1):

@@ -409,3 +409,108 @@ def test_gpu_fundamental_lmeds_below_fifteen_points(gpu, oracle, n, seed):
     assert (fb[1][0] == mask).all() and fb[1][1] == nin and fb[1][2] == 300
     Fs, ms, ns, it_s = g.find_fundamental_cv(big["pts1"], big["pts2"])
     assert (fb[0][0] == ms).all() and fb[0][2] == it_s
+
+
+# ---------------------------------------------------------------- cv::solvePnPRansac as OpenCV itself runs it (dvs_solve_pnp_ransac_cv)
+def _pnp_scene(n, seed, outliers, noise=0.5, planar=False):
+    sc = rs.two_view(n, outliers, noise, seed, planar=planar)
+    return sc["X"], sc["pts2"], sc["K4"], sc                        # camera-1 points against their (noisy, partly wrong) image in view 2
+
+
+def test_cv_pnp_subsets_three_statements(hiplib, oracle):
+    """the RANSAC stage's 5-point samples: product host routine, oracle and a Python statement of cv::RNG + getSubset (no checkSubset)"""
+    from dvslam_amd import glue
+    for n, iters in ((6, 40), (37, 100), (600, 100)):
+        g = _py_cv_rng(0xffffffffffffffff)
+        want = []
+        for _ in range(iters):
+            idx = []
+            for i in range(5):
+                v = next(g) % n
+                while v in idx:
+                    v = next(g) % n
+                idx.append(v)
+            want.append(idx)
+        assert glue.cv_ransac_subsets_nocheck(n, 5, iters).tolist() == want
+        assert oracle.cv_subsets_nocheck(n, 5, iters).tolist() == want
+
+
+def test_oracle_epnp_and_iterative_refit_on_exact_data(oracle):
+    """the two solvers of the OpenCV procedure on noise-free data: EPnP on 5 general points and solvePnP(ITERATIVE) on many points,
+    planar (homography initialisation) and not (DLT initialisation), recover the pose"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    K4 = np.array([600.0, 610.0, 320.0, 240.0])
+    for trial in range(20):
+        R = rs.rot(rng.normal(size=3), np.deg2rad(rng.uniform(1, 25))); t = rng.normal(size=3) * 0.2
+        w = np.array(rs_rodrigues(R))
+        X = np.stack([rng.uniform(-1, 1, 60), rng.uniform(-0.8, 0.8, 60), rng.uniform(1.5, 3.0, 60)], 1)
+        Xc = X @ R.T + t
+        uv = np.stack([K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2], K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3]], 1)
+        r5, t5 = oracle.epnp(X[:5], uv[:5], K4)
+        assert np.abs(r5 - w).max() < 1e-4 and np.abs(t5 - t).max() < 1e-4, (trial, r5, w)       # float image points: ~1e-7 relative
+        ok, ri, ti = oracle.solve_pnp_iterative(X, uv, K4)
+        assert ok and np.abs(ri - w).max() < 1e-6 and np.abs(ti - t).max() < 1e-6   # CvLevMarq stops on a relative step below FLT_EPSILON
+        Xp = X.copy(); Xp[:, 2] = 2.0
+        Xc = Xp @ R.T + t
+        uvp = np.stack([K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2], K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3]], 1)
+        ok, ri, ti = oracle.solve_pnp_iterative(Xp, uvp, K4)
+        assert ok and np.abs(ri - w).max() < 1e-6 and np.abs(ti - t).max() < 1e-6   # CvLevMarq stops on a relative step below FLT_EPSILON
+
+
+def rs_rodrigues(R):
+    """rotation matrix -> Rodrigues vector (angle < pi)"""
+    th = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return v * (th / (2 * np.sin(th))) if th > 1e-12 else v * 0.5
+
+
+@pytest.mark.parametrize("seed,outliers", [(0, 0.0), (1, 0.2), (2, 0.4), (3, 0.45)])
+def test_oracle_pnp_cv_against_ground_truth(oracle, seed, outliers):
+    X, uv, K4, sc = _pnp_scene(500, seed, outliers)
+    ok, rvec, tvec, inl, sel, m6 = oracle.solve_pnp_ransac_cv(X, uv, K4, 100, 4.0, 0.99)
+    assert ok and sel[0] >= 0 and sel[1] <= 100
+    got = np.zeros(len(X), bool); got[inl] = True
+    assert rs.iou(got, sc["truth"]) > 0.93                                              # 0.5 px noise against a 4 px gate
+    R = rs.rodrigues_to_R(rvec)
+    assert np.abs(R - sc["R"]).max() < 2e-3 and np.abs(tvec - sc["t"]).max() < 4e-3
+    if outliers == 0.0:
+        assert sel[1] <= 3                                                             # RANSACUpdateNumIters stops a clean problem at once
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,outliers", [(600, 0, 0.0), (600, 1, 0.3), (300, 2, 0.5), (120, 3, 0.2), (40, 4, 0.25), (12, 5, 0.0), (6, 6, 0.0), (1500, 7, 0.35)])
+def test_gpu_pnp_cv(gpu, oracle, n, seed, outliers):
+    """dvs_solve_pnp_ransac_cv against the oracle's statement of the same OpenCV procedure: the SAME samples (host-made on both sides, checked
+    above), the loop stops at the SAME iteration, the SAME inlier list — index for index — and the refitted pose to 1e-6 (Jacobi
+    eigen-decompositions with different orderings / thresholds on the two sides; CvLevMarq ends on a relative step below FLT_EPSILON)"""
+    from dvslam_amd import FrontendGlue
+    X, uv, K4, sc = _pnp_scene(n, seed, outliers)
+    ok2, r2, t2, inl2, sel2, m6 = oracle.solve_pnp_ransac_cv(X, uv, K4, 100, 4.0, 0.99)
+    g = FrontendGlue()
+    ok, r, t, inl, its = g.solve_pnp_ransac_cv(X, uv, K4, 100, 4.0, 0.99)
+    assert ok == ok2 and its == sel2[1], (ok, ok2, its, sel2)
+    assert inl.tolist() == inl2.tolist()
+    assert np.abs(r - r2).max() < 1e-6 and np.abs(t - t2).max() < 1e-6, (r, r2, t, t2)
+    if n >= 40:
+        got = np.zeros(len(X), bool); got[inl] = True
+        assert rs.iou(got, sc["truth"]) > 0.9 and np.abs(rs.rodrigues_to_R(r) - sc["R"]).max() < 5e-3
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pnp_cv_batch_and_refusals(gpu, oracle):
+    """many problems in one launch sequence = the single calls bit for bit; fewer than 6 points are refused per problem; an exactly planar
+    point set (EPnP's degenerate case, in OpenCV as here) must not fault or hang"""
+    from dvslam_amd import FrontendGlue
+    g = FrontendGlue()
+    scenes = [_pnp_scene(n, 10 + i, o) for i, (n, o) in enumerate([(400, 0.3), (5, 0.0), (90, 0.1), (0, 0.0), (700, 0.45)])]
+    singles = [g.solve_pnp_ransac_cv(X, uv, K4) if len(X) else (False, np.zeros(3), np.zeros(3), np.zeros(0, np.int32), 0) for X, uv, K4, _ in scenes]
+    batch = g.solve_pnp_ransac_cv_batch([s[0] for s in scenes], [s[1] for s in scenes], scenes[0][2])
+    for a, b in zip(singles, batch):
+        assert a[0] == b[0] and a[4] == b[4] and a[3].tolist() == b[3].tolist()
+        assert (a[1].view(np.uint64) == b[1].view(np.uint64)).all() and (a[2].view(np.uint64) == b[2].view(np.uint64)).all()
+    assert not batch[1][0] and len(batch[1][3]) == 0 and not batch[3][0]               # 5 and 0 points: refused
+    Xp, uvp, K4, _ = _pnp_scene(300, 3, 0.2, planar=True)
+    ok, r, t, inl, its = g.solve_pnp_ransac_cv(Xp, uvp, K4)
+    assert 1 <= its <= 100 and np.isfinite(r).all() and np.isfinite(t).all()
+    g.close()
