@@ -89,6 +89,9 @@ struct dvs_orb {
   int env_oct_threads = 0;         // DVS_OCT_T=256 / 512: quad-tree workgroup size for every batch size (0 = by batch size)
   int env_host_poll = 1;           // DVS_HOST_POLL=0: three device-to-host copy commands and a stream wait instead of k_export_host
   uint32_t *d_cand = nullptr, *d_pts = nullptr, *d_lvlkp = nullptr;
+  uint32_t* d_kpident = nullptr;   // idx[slot] = slot's position in its level's list: the visiting order of DVS_DESC_ORDER=0
+  int env_desc_order = 1;          // DVS_DESC_ORDER=0: the descriptor stage visits a level's keypoints in list order instead of tile by tile (k_kp_order)
+  uint32_t *d_kpsorted = nullptr, *d_kpsortidx = nullptr;   // a level's keypoints in the descriptor stage's visiting order + their list positions (k_kp_order)
   // level keypoint lists, three sets in rotation: deferred descriptor stages k - 1 and k - 2 may both still read theirs when call k's
   // quad-tree writes (stage k - 3 precedes the level chain call k's FAST waited for) — no wait on the main stream in front of it
   uint32_t* d_lvlkp3[3] = {nullptr, nullptr, nullptr};
@@ -138,7 +141,7 @@ namespace {
 void free_workspace(dvs_orb* h) {
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur3[0],
                   h->d_pyr_alt, h->d_pyr_3rd, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_celloff, h->d_candtotal,
-                  h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_kps, h->d_desc, h->d_nout, h->d_ticket};
+                  h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_kps, h->d_desc, h->d_nout, h->d_ticket, h->d_kpsorted, h->d_kpsortidx, h->d_kpident};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 1; k < 3; k++) { if (h->d_blur3[k]) (void)hipFree(h->d_blur3[k]); h->d_blur3[k] = nullptr; }   // ([0] = the workspace's block, freed above)
   h->d_blur3[0] = nullptr; h->bset = 0;
@@ -158,6 +161,7 @@ void free_workspace(dvs_orb* h) {
   for (int k = 0; k < 3; k++) { h->d_lvlkp3[k] = nullptr; h->d_lvlcount3[k] = nullptr; }
   h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->out_gen = 0; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
+  h->d_kpsorted = nullptr; h->d_kpsortidx = nullptr; h->d_kpident = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
   h->rows = h->cols = 0;
 }
@@ -552,6 +556,17 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
     DVS_HIP(hipMalloc((void**)&h->d_lvlkp3[k], B * (size_t)G.kpBlock * 4));
   }
   h->lset = 0; h->d_lvlcount = h->d_lvlcount3[0]; h->d_lvlkp = h->d_lvlkp3[0];
+  DVS_HIP(hipMalloc((void**)&h->d_kpsorted, B * (size_t)G.kpBlock * 4));
+  DVS_HIP(hipMalloc((void**)&h->d_kpsortidx, B * (size_t)G.kpBlock * 4));
+  {
+    std::vector<uint32_t> ident(B * (size_t)G.kpBlock);
+    for (size_t f = 0; f < B; f++)
+      for (int l = 0; l < G.nlevels; l++) {
+        const int end = l + 1 < G.nlevels ? G.lv[l + 1].kpOff : G.kpBlock;
+        for (int sl = G.lv[l].kpOff; sl < end; sl++) ident[f * G.kpBlock + sl] = (uint32_t)(sl - G.lv[l].kpOff);
+      }
+    DVS_TRY(upload(&h->d_kpident, ident));
+  }
   DVS_HIP(hipMalloc((void**)&h->d_kps, B * (size_t)G.outCap * sizeof(dvs_keypoint)));
   DVS_HIP(hipMalloc((void**)&h->d_desc, B * (size_t)G.outCap * 32));
   DVS_HIP(hipMalloc((void**)&h->d_nout, B * 4));
@@ -913,8 +928,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));
   }
   h->timer.begin(DVS_STAGE_DESCRIBE, dst);
-  hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, dst, h->d_geom, src, h->d_blur,
-                     h->d_lvlkp, h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
+  if (h->env_desc_order) {
+    hipLaunchKernelGGL(k_kp_order, dim3(nimg, G.nlevels), dim3(256), 0, dst, h->d_geom, h->d_lvlkp, h->d_lvlcount, h->d_kpsorted, h->d_kpsortidx);
+    hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, dst, h->d_geom, src, h->d_blur,
+                       h->d_kpsorted, h->d_kpsortidx, h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
+  } else {   // list order: the identity index table
+    hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, dst, h->d_geom, src, h->d_blur,
+                       h->d_lvlkp, h->d_kpident, h->d_lvlcount, d_kps, d_desc, d_nout, capacity);
+  }
   h->timer.end(dst);
   if (will_defer) {
     h->ev_out = h->ev_outs[h->out_gen & 1];
@@ -973,6 +994,7 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
   h->env_oct_threads = env_int("DVS_OCT_T", 0);
+  h->env_desc_order = env_int("DVS_DESC_ORDER", 1);
   if (h->env_oct_threads != 0 && h->env_oct_threads != kOctT && h->env_oct_threads != kOctTMax) h->env_oct_threads = 0;
   // byte-aligned tile origin (probed once per process and device): every cell's interior then starts on a dword of the tile, so a
   // 36-pixel interior is always 9 column groups = 7 rows per trip of the rejection loop (aligned origin: 9 or 10 groups by the

@@ -1917,8 +1917,37 @@ constexpr int kDescKP = 8;
 constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinPitch = 48;
 // (Round 1 split the kernel at the angle so that the orientation half could run beside the blur; with the deferred descriptor
 // stage of the pipelined schedule that bought nothing — 0.686 vs 0.681 ms per step — and the split was removed.)
+// Spatial visiting order for the descriptor stage (round 4): the quad-tree leaves a level's keypoints in LIST order (reverse creation
+// order of the nodes, ORBextractor.cpp:639-674), i.e. scattered over the level, and a wavefront of k_describe takes eight consecutive
+// ones — eight 37 x 48-byte windows and eight 31 x 31 patches in eight different places: 382 MB of L2-miss fetch per 64 frames for 7.7 MB
+// of distinct lines per frame.  This kernel ranks the keypoints of a (frame, level) by (tile row, tile column) of 128-byte x 32-row tiles,
+// list order within a tile (a stable rank: N <= ~450 per level, every thread counts the keys in front of its own in LDS), and writes the
+// packed keypoint and its LIST index in visiting order.  The output position of a keypoint stays its list position: results unchanged.
+__global__ __launch_bounds__(256) void k_kp_order(const Geom* __restrict__ g, const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
+                                                  uint32_t* __restrict__ sortedKp, uint32_t* __restrict__ sortedIdx) {
+  __shared__ uint32_t key[kMaxQuota + 8];
+  const int f = blockIdx.x, level = blockIdx.y;
+  const LevelGeom& L = g->lv[level];
+  const int n = min(lvlKpCount[f * g->nlevels + level], min(L.N + 4, kMaxQuota + 8));
+  const uint32_t* in = lvlKp + (uint64_t)f * g->kpBlock + L.kpOff;
+  uint32_t* outK = sortedKp + (uint64_t)f * g->kpBlock + L.kpOff;
+  uint32_t* outI = sortedIdx + (uint64_t)f * g->kpBlock + L.kpOff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t pk = in[i];
+    key[i] = ((uint32_t)(pt_y(pk) >> 5) << 20) | ((uint32_t)(pt_x(pk) >> 7) << 12) | (uint32_t)i;   // tile row, tile column, list index (< 4096)
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t k = key[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += key[j] < k ? 1 : 0;     // keys are distinct (the list index is part of them)
+    outK[rank] = in[i];
+    outI[rank] = (uint32_t)i;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, ImgSrc src, const u8* __restrict__ blur,
-                                                  const uint32_t* __restrict__ lvlKp, const int* __restrict__ lvlKpCount,
+                                                  const uint32_t* __restrict__ lvlKp, const uint32_t* __restrict__ lvlKpIdx, const int* __restrict__ lvlKpCount,
                                                   dvs_keypoint* __restrict__ outKp, u8* __restrict__ outDesc,
                                                   int* __restrict__ nOut, int capacity) {
   typedef uint4 __attribute__((aligned(1))) uint4u;
@@ -1943,16 +1972,19 @@ __global__ __launch_bounds__(256) void k_describe(const Geom* __restrict__ g, Im
   if (slot0 >= g->kpBlock) return;
   // ---- slot resolve (lane & 7 = keypoint of the wave; lanes >= 8 repeat lanes 0..7)
   const int slot = min(slot0 + (lane & 7), g->kpBlock - 1);
+  // (lvlKp / lvlKpIdx: the level's keypoints in VISITING order and their list positions, k_kp_order)
   const uint32_t pkRaw = lvlKp[(uint64_t)f * g->kpBlock + slot];  // requested before the counts it is validated against
+  const uint32_t idxRaw = lvlKpIdx[(uint64_t)f * g->kpBlock + slot];
   int level = 0, pre = 0, acc = 0;
   for (int l = 0; l < nl; l++) {
     if (slot >= g->lv[l].kpOff) { level = l; pre = acc; }
     acc += cnt[l];
   }
   const LevelGeom& L = g->lv[level];
-  const int idx = slot - L.kpOff;
-  const int gi = src.slotted ? slot : pre + idx;
-  const bool valid = slot0 + (lane & 7) < g->kpBlock && idx < cnt[level] && gi < capacity;
+  const bool inlist = slot - L.kpOff < cnt[level];
+  const int idx = inlist ? (int)idxRaw : slot - L.kpOff;          // list position of the keypoint visited at this slot
+  const int gi = src.slotted ? L.kpOff + idx : pre + idx;
+  const bool valid = slot0 + (lane & 7) < g->kpBlock && inlist && gi < capacity;
   if ((__ballot(valid) & 0xffull) == 0) return;
   const uint32_t pk = valid ? pkRaw : 0u;
   // an empty slot reads the patch of (level 0, first legal position): in bounds, result discarded

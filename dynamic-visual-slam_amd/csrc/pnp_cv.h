@@ -24,7 +24,7 @@ __device__ inline void jacobi_eig(double* A, double* V) {
   for (int sweep = 0; sweep < 64; sweep++) {
     double off = 0.0, dg = 0.0;
     for (int p = 0; p < N; p++) { dg += A[p * N + p] * A[p * N + p]; for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q]; }
-    if (!(off > 1e-58 * dg)) break;
+    if (!(off > 1e-28 * dg)) break;   // sums of squares: off-diagonal norm below 1e-14 of the diagonal's; Jacobi converges quadratically
     for (int p = 0; p < N - 1; p++)
       for (int q = p + 1; q < N; q++) {
         const double apq = A[p * N + q];
@@ -248,7 +248,10 @@ __device__ inline double epnp_R_and_t(Epnp5& e, const double* ut, const double* 
 }
 
 // solvePnP(SOLVEPNP_EPNP) on 5 float correspondences -> rvec, tvec
-__device__ inline void epnp5(const float* obj, const float* img, const int* idx, double fx, double fy, double cx, double cy, double* rvec, double* tvec) {
+// wsA / wsV: two 144-double work arrays (LDS: the 12 x 12 eigen-decomposition is a long chain of dependent loads and stores — in
+// private (scratch) memory the whole call took 19 ms per 100 hypotheses)
+__device__ inline void epnp5(const float* obj, const float* img, const int* idx, double fx, double fy, double cx, double cy, double* rvec, double* tvec,
+                             double* wsA, double* wsV) {
   Epnp5 e;
   e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
   const double ifx = 1. / fx, ify = 1. / fy;
@@ -299,9 +302,10 @@ __device__ inline void epnp5(const float* obj, const float* img, const int* idx,
     }
   }
   // M^T M and its eigenvectors, smallest last (rows of ut)
-  double ut[144];
+  double* ut = wsA;
   {
-    double mtm[144], V[144];
+    double* mtm = wsA;
+    double* V = wsV;
     for (int k = 0; k < 144; k++) mtm[k] = 0.0;
     for (int i = 0; i < 5; i++) {
       double M1[12], M2[12];
@@ -315,7 +319,7 @@ __device__ inline void epnp5(const float* obj, const float* img, const int* idx,
     jacobi_eig<12>(mtm, V);
     int o[12];
     order_desc<12>(mtm, o);
-    for (int i = 0; i < 12; i++) for (int k = 0; k < 12; k++) ut[12 * i + k] = V[12 * k + o[i]];
+    for (int i = 0; i < 12; i++) for (int k = 0; k < 12; k++) ut[12 * i + k] = V[12 * k + o[i]];   // (the eigenvalues are used up: ut overwrites mtm)
   }
   double L[60], rho[6];
   {
@@ -390,10 +394,12 @@ __device__ inline float proj_err_f(const double* R, const double* t, double fx, 
 }  // namespace pnpcv
 
 // one thread per RANSAC iteration: EPnP on its 5-point sample -> model (rvec, tvec) and the model's rotation matrix
-__global__ __launch_bounds__(64) void k_epnp_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs,
+constexpr int kEpnpThreads = 16;   // per workgroup: 16 x 2 x 145 doubles of LDS work arrays (odd pitch: the threads' arrays fall on different banks)
+__global__ __launch_bounds__(kEpnpThreads) void k_epnp_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs,
                                                         const int* __restrict__ samples, int H, double fx, double fy, double cx, double cy,
                                                         double* __restrict__ models /* [H][18]: rvec, tvec, R, pad */) {
-  const int h = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double wsA[kEpnpThreads][145], wsV[kEpnpThreads][145];
+  const int h = blockIdx.x * kEpnpThreads + threadIdx.x;
   if (h >= H) return;
   const RansacProb pb = probs[blockIdx.y];
   obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off;
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(64) void k_epnp_hypotheses(const float* __restrict_
   int idx[5];
   for (int k = 0; k < 5; k++) idx[k] = samples[k];
   double rv[3], tv[3], R[9];
-  pnpcv::epnp5(obj, img, idx, fx, fy, cx, cy, rv, tv);
+  pnpcv::epnp5(obj, img, idx, fx, fy, cx, cy, rv, tv, wsA[threadIdx.x], wsV[threadIdx.x]);
   pnpcv::rodrigues_vec(rv, R, nullptr);     // projectPoints starts from the ROTATION VECTOR of the model
   for (int k = 0; k < 3; k++) { m[k] = rv[k]; m[3 + k] = tv[k]; }
   for (int k = 0; k < 9; k++) m[6 + k] = R[k];
@@ -449,6 +455,7 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
                                                     const double* __restrict__ models, const int* __restrict__ sel, double fx, double fy, double cx,
                                                     double cy, float thr, int* __restrict__ inl, unsigned char* __restrict__ out) {
   using namespace pnpcv;
+  __shared__ double wsA[145], wsV[145], wsOut[16];   // the 9 x 9 / 12 x 12 eigen-decompositions of the initialisation: lane 0, in LDS
   const RansacProb pb = probs[blockIdx.x];
   const int n = pb.n, lane = threadIdx.x;
   obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off; inl += pb.off;
@@ -526,12 +533,17 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
         for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) LtL[9 * j + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
       }
       for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) { LtL[9 * j + k] = wave_allsum(LtL[9 * j + k]); LtL[9 * k + j] = LtL[9 * j + k]; }
-      double V9[81];
-      int o9[9];
-      jacobi_eig<9>(LtL, V9);
-      order_desc<9>(LtL, o9);
+      if (lane == 0) {
+        for (int k = 0; k < 81; k++) wsA[k] = LtL[k];
+        int o9[9];
+        jacobi_eig<9>(wsA, wsV);
+        order_desc<9>(wsA, o9);
+        for (int k = 0; k < 9; k++) wsOut[k] = wsV[9 * k + o9[8]];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       double H0[9], Ht[9], h[9];
-      for (int k = 0; k < 9; k++) H0[k] = V9[9 * k + o9[8]];
+      for (int k = 0; k < 9; k++) H0[k] = wsOut[k];
       const double invHnorm[9] = {1. / s4[0], 0, c4[0], 0, 1. / s4[1], c4[1], 0, 0, 1};
       const double Hnorm2[9] = {s4[2], 0, -c4[2] * s4[2], 0, s4[3], -c4[3] * s4[3], 0, 0, 1};
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Ht[3 * a + b] = invHnorm[3 * a] * H0[b] + invHnorm[3 * a + 1] * H0[3 + b] + invHnorm[3 * a + 2] * H0[6 + b];
@@ -562,12 +574,17 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
         for (int j = 0; j < 12; j++) for (int k = j; k < 12; k++) LL[12 * j + k] += L0[j] * L0[k] + L1[j] * L1[k];
       }
       for (int j = 0; j < 12; j++) for (int k = j; k < 12; k++) { LL[12 * j + k] = wave_allsum(LL[12 * j + k]); LL[12 * k + j] = LL[12 * j + k]; }
-      double V12[144];
-      int o12[12];
-      jacobi_eig<12>(LL, V12);
-      order_desc<12>(LL, o12);
+      if (lane == 0) {
+        for (int k = 0; k < 144; k++) wsA[k] = LL[k];
+        int o12[12];
+        jacobi_eig<12>(wsA, wsV);
+        order_desc<12>(wsA, o12);
+        for (int k = 0; k < 12; k++) wsOut[k] = wsV[12 * k + o12[11]];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       double RRt[12];
-      for (int k = 0; k < 12; k++) RRt[k] = V12[12 * k + o12[11]];
+      for (int k = 0; k < 12; k++) RRt[k] = wsOut[k];
       double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
       if (det3(RR) < 0) { for (int k = 0; k < 12; k++) RRt[k] = -RRt[k]; for (int k = 0; k < 9; k++) RR[k] = -RR[k]; }
       double sc = 0;

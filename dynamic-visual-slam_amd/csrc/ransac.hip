@@ -1222,8 +1222,8 @@ dvs_status dvs_find_fundamental_ransac_batch(dvs_matcher* ctx, int32_t nprob, co
   return DVS_OK;
 }
 
-// cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): every problem needs >= 15 correspondences —
-// below that OpenCV switches to LMedS, which is not restated (DVS_ERR_UNSUPPORTED: the caller keeps dvs_find_fundamental_ransac)
+// cv::findFundamentalMat(FM_RANSAC) the way OpenCV 4.x runs it (see k_f7_hypotheses): RANSAC from 15 correspondences on, LMedS for 8..14
+// (OpenCV switches there: k_lmeds_select); fewer than 8 are DVS_ERR_UNSUPPORTED (the reference calls with >= 8, frontend.cpp:627)
 dvs_status dvs_find_fundamental_cv_batch(dvs_matcher* ctx, int32_t nprob, const int32_t* offsets, const float* pts1, const float* pts2, double threshold,
                                          double confidence, int32_t max_iters, double* F9, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iterations) {
   DVS_ARG(ctx && nprob >= 0 && max_iters >= 1 && max_iters <= 4096);
@@ -1336,7 +1336,7 @@ dvs_status dvs_solve_pnp_ransac_cv_batch(dvs_matcher* ctx, int32_t nprob, const 
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
   const float thr = (float)(reproj_err * reproj_err);
-  hipLaunchKernelGGL(k_epnp_hypotheses, dim3((H + 63) / 64, nprob), dim3(64), 0, st, d_obj, d_img, d_probs, d_samples, H, fx, fy, cx, cy, d_models);
+  hipLaunchKernelGGL(k_epnp_hypotheses, dim3((H + kEpnpThreads - 1) / kEpnpThreads, nprob), dim3(kEpnpThreads), 0, st, d_obj, d_img, d_probs, d_samples, H, fx, fy, cx, cy, d_models);
   hipLaunchKernelGGL(k_pnpcv_score, dim3(H, nprob), dim3(256), 0, st, d_obj, d_img, d_probs, H, d_models, fx, fy, cx, cy, thr, d_counts);
   hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H, d_probs, 5, confidence, 1, d_sel, 1, H);
   hipLaunchKernelGGL(k_pnpcv_refit, dim3(nprob), dim3(64), 0, st, d_obj, d_img, d_probs, H, d_models, d_sel, fx, fy, cx, cy, thr, d_inl, d_out);

@@ -5,6 +5,13 @@
 // never calls (frontend.cpp:627 `if (... size() >= 8)`): an all-zero mask and an empty F.
 //   dvslam::findFundamentalMat(matcher, pts1, pts2, n, mask, F9)                       plain pointers (n x 2 floats)
 //   (DVSLAM_WITH_OPENCV) findFundamentalMat(matcher, vector<cv::Point2f>, vector<cv::Point2f>, vector<uchar>& mask, method, ...)
+// and of
+//   cv::solvePnPRansac(points3d, points2d, K, dist, rvec, tvec, false, 100, 4.0, 0.99, inliers)                        src/frontend.cpp:911-921
+// (dvs_solve_pnp_ransac_cv — OpenCV's procedure with its default flags: cv::RNG 5-point samples, EPnP, float scoring, adaptive stop,
+// solvePnP(ITERATIVE) on the inliers; distortion coefficients must be empty / zero: the reference's synthetic and RealSense colour streams
+// are rectified).  Fewer than 6 correspondences: false (the reference returns before the call, frontend.cpp:900).
+//   dvslam::solvePnPRansac(matcher, obj, img, n, K4, rvec, tvec, inliers)                plain pointers (n x 3 / n x 2 floats)
+//   (DVSLAM_WITH_OPENCV) solvePnPRansac(matcher, vector<cv::Point3f>, vector<cv::Point2f>, cv::Mat K, cv::Mat dist, cv::Mat& rvec, ...)
 // `matcher` is the dvslam::BFMatcher the node already owns (frontend.cpp:220): the stage shares its handle, stream and scratch.
 #pragma once
 #include <stdexcept>
@@ -30,7 +37,37 @@ inline bool findFundamentalMat(BFMatcher& matcher, const float* pts1, const floa
   return any;   // false: OpenCV would return an empty matrix (the mask is written either way)
 }
 
+// returns OpenCV's return value; rvec / tvec as it leaves them (the RANSAC stage's model when only the refit failed); inliers in index order
+inline bool solvePnPRansac(BFMatcher& matcher, const float* objectPoints, const float* imagePoints, int n, const double K4[4] /* fx fy cx cy */, double rvec[3],
+                           double tvec[3], std::vector<int>& inliers, int iterationsCount = 100, float reprojectionError = 8.0f, double confidence = 0.99) {
+  inliers.assign((size_t)(n > 0 ? n : 0), 0);
+  int32_t nin = 0, ok = 0;
+  if (n > 0 && dvs_solve_pnp_ransac_cv(matcher.handle(), objectPoints, imagePoints, n, K4, iterationsCount, reprojectionError, confidence, rvec, tvec,
+                                       inliers.data(), &nin, &ok, nullptr) != DVS_OK)
+    throw std::runtime_error(dvs_last_error());
+  inliers.resize((size_t)nin);
+  return ok != 0;
+}
+
 #ifdef DVSLAM_WITH_OPENCV
+// the reference's call with the matcher in front; K: 3 x 3 CV_64F, distCoeffs: empty or all zero; rvec / tvec: 3 x 1 CV_64F
+inline bool solvePnPRansac(BFMatcher& matcher, const std::vector<cv::Point3f>& objectPoints, const std::vector<cv::Point2f>& imagePoints, const cv::Mat& cameraMatrix,
+                           const cv::Mat& distCoeffs, cv::Mat& rvec, cv::Mat& tvec, bool useExtrinsicGuess = false, int iterationsCount = 100,
+                           float reprojectionError = 8.0f, double confidence = 0.99, std::vector<int>* inliers = nullptr) {
+  CV_Assert(!useExtrinsicGuess && objectPoints.size() == imagePoints.size() && cameraMatrix.rows == 3 && cameraMatrix.cols == 3 && cameraMatrix.type() == CV_64F);
+  for (int i = 0; i < (int)distCoeffs.total(); i++) CV_Assert(distCoeffs.at<double>(i) == 0.0);   // rectified input only
+  static_assert(sizeof(cv::Point3f) == 3 * sizeof(float), "cv::Point3f is three packed floats");
+  const double K4[4] = {cameraMatrix.at<double>(0, 0), cameraMatrix.at<double>(1, 1), cameraMatrix.at<double>(0, 2), cameraMatrix.at<double>(1, 2)};
+  double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+  std::vector<int> inl;
+  const bool ok = solvePnPRansac(matcher, objectPoints.empty() ? nullptr : &objectPoints[0].x, imagePoints.empty() ? nullptr : &imagePoints[0].x,
+                                 (int)objectPoints.size(), K4, r, t, inl, iterationsCount, reprojectionError, confidence);
+  rvec = cv::Mat(3, 1, CV_64F); tvec = cv::Mat(3, 1, CV_64F);
+  for (int k = 0; k < 3; k++) { rvec.at<double>(k, 0) = r[k]; tvec.at<double>(k, 0) = t[k]; }
+  if (inliers) *inliers = ok ? inl : std::vector<int>();      // OpenCV releases the inlier array when it returns false
+  return ok;
+}
+
 // the reference's call, with the matcher in front: `cv::findFundamentalMat(a, b, mask, cv::FM_RANSAC, 2.0, 0.99)` becomes
 // `dvslam::findFundamentalMat(matcher_, a, b, mask, cv::FM_RANSAC, 2.0, 0.99)`; returns F as a 3 x 3 CV_64F matrix (empty: none)
 inline cv::Mat findFundamentalMat(BFMatcher& matcher, const std::vector<cv::Point2f>& points1, const std::vector<cv::Point2f>& points2,

@@ -56,7 +56,7 @@ void symEigDesc(const double* Ain, int n, double* w, double* Vt) {
   for (int sweep = 0; sweep < 80; sweep++) {
     double off = 0, diag = 0;
     for (int p = 0; p < n; p++) { diag += A[(size_t)p * n + p] * A[(size_t)p * n + p]; for (int q = p + 1; q < n; q++) off += A[(size_t)p * n + q] * A[(size_t)p * n + q]; }
-    if (off <= 1e-60 * diag || off == 0) break;
+    if (off <= 1e-29 * diag || off == 0) break;   // sum of squares: off-diagonal norm below 3e-15 of the diagonal's (one more sweep squares it)
     for (int p = 0; p < n - 1; p++)
       for (int q = p + 1; q < n; q++) {
         const double apq = A[(size_t)p * n + q];

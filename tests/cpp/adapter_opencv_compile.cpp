@@ -118,6 +118,26 @@ int main() {
     if (kf_inliers_mask.size() != 10) return 1;
     std::printf("dvslam::findFundamentalMat: %d of 120 kept\n", kept);
   }
+  {  // frontend.cpp:905-925 with cv::solvePnPRansac -> dvslam::solvePnPRansac(matcher_, ...): a small known motion, every sixth correspondence wrong
+    std::vector<cv::Point3f> points3d; std::vector<cv::Point2f> points2d;
+    uint32_t s = 7;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.f; };
+    for (int i = 0; i < 150; i++) {
+      const float X = rnd() * 2.f - 1.f, Y = rnd() * 1.4f - 0.7f, Z = 1.2f + 1.5f * rnd();
+      points3d.push_back(cv::Point3f(X, Y, Z));
+      if (i % 6 == 5) points2d.push_back(cv::Point2f(rnd() * 640.f, rnd() * 480.f));
+      else points2d.push_back(cv::Point2f(600.f * (X + 0.04f) / (Z - 0.03f) + 320.f, 600.f * (Y - 0.02f) / (Z - 0.03f) + 240.f));   // t = (0.04, -0.02, -0.03), R = I
+    }
+    cv::Mat K(3, 3, CV_64F), dist, rvec, tvec;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K.at<double>(i, j) = 0.0;
+    K.at<double>(0, 0) = 600; K.at<double>(1, 1) = 600; K.at<double>(0, 2) = 320; K.at<double>(1, 2) = 240; K.at<double>(2, 2) = 1;
+    std::vector<int> inliers;
+    const bool success = dvslam::solvePnPRansac(matcher_, points3d, points2d, K, dist, rvec, tvec, false, 100, 4.0, 0.99, &inliers);
+    const double et = std::fabs(tvec.at<double>(0, 0) - 0.04) + std::fabs(tvec.at<double>(1, 0) + 0.02) + std::fabs(tvec.at<double>(2, 0) + 0.03);
+    const double er = std::fabs(rvec.at<double>(0, 0)) + std::fabs(rvec.at<double>(1, 0)) + std::fabs(rvec.at<double>(2, 0));
+    if (!success || inliers.size() < 120 || inliers.size() > 130 || et > 1e-3 || er > 1e-3) { std::printf("solvePnPRansac: %d, %zu inliers, |dt| %.2e |r| %.2e\n", (int)success, inliers.size(), et, er); return 1; }
+    std::printf("dvslam::solvePnPRansac: %zu of 150 inliers\n", inliers.size());
+  }
   std::printf("opencv-typed adapters ok: %d keypoints, BA cost %.3e in %d steps\n", n, result.final_cost, result.iterations_completed);
   return 0;
 }

@@ -37,6 +37,7 @@ class Mat {
   }
   void release() { buf_.reset(); data = nullptr; rows = cols = 0; step = 0; }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  size_t total() const { return (size_t)rows * cols; }
   int type() const { return type_; }
   bool isContinuous() const { return step == (size_t)cols * esz(); }
   Mat clone() const {
@@ -78,6 +79,7 @@ inline const _InputArray& noArray() { static _InputArray none; return none; }
 
 struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float a, float b) : x(a), y(b) {} };
 struct Point3d { double x = 0, y = 0, z = 0; Point3d() {} Point3d(double a, double b, double c) : x(a), y(b), z(c) {} };
+struct Point3f { float x = 0, y = 0, z = 0; Point3f() {} Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
 struct KeyPoint {
   Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1;
   KeyPoint() {}

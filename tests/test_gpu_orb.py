@@ -380,12 +380,12 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
 
 
 @pytest.mark.parametrize("env", [{"DVS_BLUR_MFMA": "1"}, {"DVS_BLUR_MFMA": "2"}, {"DVS_FAST_BYTE_DMA": "0"}, {"DVS_BLUR_MFMA": "1", "DVS_CASCADE": "0"}, {"DVS_CASCADE": "1"},
-                                 {"DVS_HOST_POLL": "0"}, {"DVS_OCT_T": "256"}, {"DVS_OCT_T": "512", "DVS_CASCADE": "0"}, {"DVS_NO_OVERLAP": "1"}])
+                                 {"DVS_HOST_POLL": "0"}, {"DVS_OCT_T": "256"}, {"DVS_OCT_T": "512", "DVS_CASCADE": "0"}, {"DVS_NO_OVERLAP": "1"}, {"DVS_DESC_ORDER": "0"}])
 @pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 500, 8), (720, 1280, 2000, 8), (360, 1000, 700, 6), (250, 332, 200, 4), (200, 136, 150, 3)])
 def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, nf, nl):
     """Every switch dvs_orb_create reads from the environment (csrc/orb.hip: the matrix-core blur, the dword-aligned FAST tile origin,
     the one-launch pyramid cascade on / off, the copy-command result path of the host entry points, the quad-tree workgroup size,
-    no stream overlap) must reproduce the oracle bit for bit — blurred levels, candidates and the final result — including widths
+    no stream overlap, the descriptor stage visiting keypoints in list order instead of tile by tile) must reproduce the oracle bit for bit — blurred levels, candidates and the final result — including widths
     that are not a multiple of the 32-column strips / 128-column super-strips and rows not a multiple of 32"""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
