@@ -702,6 +702,8 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
   ImgSrc nsrc = src;
   nsrc.img0 = next_img0;
   h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
+  // (the seven launches of the chain also for few frames: all levels in one launch — k_pyr_cascade — on this stream was measured at 6 / 8
+  // frames per step: 0.103 / 0.119 ms against 0.092 / 0.103, its LDS tiles take FAST's workgroup slots; EXPERIMENTS.md)
   DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
   h->timer.end(h->pf_stream);
   h->pf_idx ^= 1;
@@ -852,7 +854,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   const bool tail = async && h->tail_stream != nullptr;
   if (tail) {
     h->timer.begin(DVS_STAGE_BLUR, st);
-    launch_blur(h, src, nimg, st, false);
+    launch_blur(h, src, nimg, st, cascade);
     h->timer.end(st);
   }
 
@@ -928,7 +930,8 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipStreamWaitEvent(st, h->ev_blur, 0));
   }
   h->timer.begin(DVS_STAGE_DESCRIBE, dst);
-  if (h->env_desc_order) {
+  // tile-by-tile visiting order from 16 frames on: below, the descriptor stage is latency and the ranking kernel's 12 us count
+  if (h->env_desc_order && nimg >= 16) {
     hipLaunchKernelGGL(k_kp_order, dim3(nimg, G.nlevels), dim3(256), 0, dst, h->d_geom, h->d_lvlkp, h->d_lvlcount, h->d_kpsorted, h->d_kpsortidx);
     hipLaunchKernelGGL(k_describe, dim3((G.kpBlock + 4 * kDescKP - 1) / (4 * kDescKP), nimg), dim3(256), 0, dst, h->d_geom, src, h->d_blur,
                        h->d_kpsorted, h->d_kpsortidx, h->d_lvlcount, d_kps, d_desc, d_nout, capacity);

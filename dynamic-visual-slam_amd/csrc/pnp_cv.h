@@ -38,6 +38,48 @@ __device__ inline void jacobi_eig(double* A, double* V) {
       }
   }
 }
+// The same decomposition by a GROUP of 16 lanes of one wavefront on matrices in LDS (N <= 16): lane k < N carries index k of the three
+// inner loops of a rotation (columns p, q of A; rows p, q of A; columns p, q of V) — the 66 rotations of a sweep stay sequential, each
+// costs three LDS round trips instead of 3 N.  Element for element the arithmetic of jacobi_eig: the same eigenvectors bit for bit.
+// gl = lane & 15; every lane of the group must call it (lanes of other groups of the wavefront may diverge).
+__device__ __forceinline__ void group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 16);
+  return v;
+}
+template <int N>
+__device__ inline void jacobi_eig_group(double* A, double* V, int gl) {
+  for (int i = gl; i < N * N; i += 16) V[i] = (i / N == i % N) ? 1.0 : 0.0;
+  group_sync();
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0.0, dg = 0.0;
+    if (gl < N) { dg = A[gl * N + gl] * A[gl * N + gl]; for (int q = gl + 1; q < N; q++) off += A[gl * N + q] * A[gl * N + q]; }
+    off = group16_sum(off); dg = group16_sum(dg);
+    if (!(off > 1e-28 * dg)) break;
+    for (int p = 0; p < N - 1; p++)
+      for (int q = p + 1; q < N; q++) {
+        const double apq = A[p * N + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        group_sync();     // every lane has read the three entries the rotation is made of
+        if (gl < N) { const double a = A[gl * N + p], b = A[gl * N + q]; A[gl * N + p] = c * a - s * b; A[gl * N + q] = s * a + c * b; }
+        group_sync();
+        if (gl < N) {
+          const double a = A[p * N + gl], b = A[q * N + gl]; A[p * N + gl] = c * a - s * b; A[q * N + gl] = s * a + c * b;
+          const double va = V[gl * N + p], vb = V[gl * N + q]; V[gl * N + p] = c * va - s * vb; V[gl * N + q] = s * va + c * vb;
+        }
+        group_sync();
+      }
+  }
+  group_sync();
+}
+
 // order[i] = index of the i-th LARGEST diagonal entry (stable)
 template <int N>
 __device__ inline void order_desc(const double* A, int* order) {
@@ -50,6 +92,46 @@ __device__ inline void order_desc(const double* A, int* order) {
     order[j + 1] = oi;
   }
 }
+// 6 x 6 symmetric positive definite solve, fully unrolled (registers); false when a pivot is not safely positive
+__device__ inline bool chol6_solve(const double* A, const double* b, double* x) {
+  double L[6][6], y[6];
+  double dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) dmax = fmax(dmax, A[7 * i]);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double d = A[7 * j];
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < j) d -= L[j][k] * L[j][k];
+    if (!(d > 1e-13 * dmax)) return false;
+    d = sqrt(d);
+    L[j][j] = d;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      if (i > j) {
+        double s = A[6 * i + j];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < j) s -= L[i][k] * L[j][k];
+        L[i][j] = s / d;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < i) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k > i) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+  return true;
+}
+
 // minimum-norm least squares of the M x N system (N <= 6) through the eigen-decomposition of A^T A: x = sum_k v_k (v_k . A^T b) / lambda_k over
 // singular values sqrt(lambda_k) above 2 eps sum(w) (cvSolve(CV_SVD) / SVD::backSubst's threshold)
 template <int M, int N>
@@ -250,9 +332,11 @@ __device__ inline double epnp_R_and_t(Epnp5& e, const double* ut, const double* 
 // solvePnP(SOLVEPNP_EPNP) on 5 float correspondences -> rvec, tvec
 // wsA / wsV: two 144-double work arrays (LDS: the 12 x 12 eigen-decomposition is a long chain of dependent loads and stores — in
 // private (scratch) memory the whole call took 19 ms per 100 hypotheses)
+// gl: the lane's index in its group of 16 — lane 0 runs the (serial) algorithm, all 16 the 12 x 12 eigen-decomposition
 __device__ inline void epnp5(const float* obj, const float* img, const int* idx, double fx, double fy, double cx, double cy, double* rvec, double* tvec,
-                             double* wsA, double* wsV) {
+                             double* wsA, double* wsV, int gl) {
   Epnp5 e;
+  if (gl == 0) {
   e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
   const double ifx = 1. / fx, ify = 1. / fy;
   for (int i = 0; i < 5; i++) {
@@ -302,10 +386,8 @@ __device__ inline void epnp5(const float* obj, const float* img, const int* idx,
     }
   }
   // M^T M and its eigenvectors, smallest last (rows of ut)
-  double* ut = wsA;
   {
     double* mtm = wsA;
-    double* V = wsV;
     for (int k = 0; k < 144; k++) mtm[k] = 0.0;
     for (int i = 0; i < 5; i++) {
       double M1[12], M2[12];
@@ -316,10 +398,15 @@ __device__ inline void epnp5(const float* obj, const float* img, const int* idx,
       }
       for (int a = 0; a < 12; a++) for (int b = 0; b < 12; b++) mtm[12 * a + b] += M1[a] * M1[b] + M2[a] * M2[b];
     }
-    jacobi_eig<12>(mtm, V);
+  }
+  }   // gl == 0
+  jacobi_eig_group<12>(wsA, wsV, gl);
+  if (gl != 0) return;
+  double* ut = wsA;
+  {
     int o[12];
-    order_desc<12>(mtm, o);
-    for (int i = 0; i < 12; i++) for (int k = 0; k < 12; k++) ut[12 * i + k] = V[12 * k + o[i]];   // (the eigenvalues are used up: ut overwrites mtm)
+    order_desc<12>(wsA, o);
+    for (int i = 0; i < 12; i++) for (int k = 0; k < 12; k++) ut[12 * i + k] = wsV[12 * k + o[i]];   // (the eigenvalues are used up: ut overwrites mtm)
   }
   double L[60], rho[6];
   {
@@ -394,22 +481,24 @@ __device__ inline float proj_err_f(const double* R, const double* t, double fx, 
 }  // namespace pnpcv
 
 // one thread per RANSAC iteration: EPnP on its 5-point sample -> model (rvec, tvec) and the model's rotation matrix
-constexpr int kEpnpThreads = 16;   // per workgroup: 16 x 2 x 145 doubles of LDS work arrays (odd pitch: the threads' arrays fall on different banks)
-__global__ __launch_bounds__(kEpnpThreads) void k_epnp_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs,
+constexpr int kEpnpGroups = 4;   // hypotheses per workgroup (one wavefront): 16 lanes and 2 x 145 doubles of LDS each
+__global__ __launch_bounds__(64) void k_epnp_hypotheses(const float* __restrict__ obj, const float* __restrict__ img, const RansacProb* __restrict__ probs,
                                                         const int* __restrict__ samples, int H, double fx, double fy, double cx, double cy,
                                                         double* __restrict__ models /* [H][18]: rvec, tvec, R, pad */) {
-  __shared__ double wsA[kEpnpThreads][145], wsV[kEpnpThreads][145];
-  const int h = blockIdx.x * kEpnpThreads + threadIdx.x;
+  __shared__ double wsA[kEpnpGroups][145], wsV[kEpnpGroups][145];
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+  const int h = blockIdx.x * kEpnpGroups + grp;
   if (h >= H) return;
   const RansacProb pb = probs[blockIdx.y];
   obj += 3 * (size_t)pb.off; img += 2 * (size_t)pb.off;
   samples += 5 * ((size_t)H * blockIdx.y + h);
   double* m = models + 18 * ((size_t)H * blockIdx.y + h);
-  if (h >= (int)pb.seed) { for (int k = 0; k < 18; k++) m[k] = 0.0; return; }   // (the seed field: iterations that have a sample)
+  if (h >= (int)pb.seed) { if (gl == 0) for (int k = 0; k < 18; k++) m[k] = 0.0; return; }   // (the seed field: iterations that have a sample)
   int idx[5];
   for (int k = 0; k < 5; k++) idx[k] = samples[k];
   double rv[3], tv[3], R[9];
-  pnpcv::epnp5(obj, img, idx, fx, fy, cx, cy, rv, tv, wsA[threadIdx.x], wsV[threadIdx.x]);
+  pnpcv::epnp5(obj, img, idx, fx, fy, cx, cy, rv, tv, wsA[grp], wsV[grp], gl);
+  if (gl != 0) return;
   pnpcv::rodrigues_vec(rv, R, nullptr);     // projectPoints starts from the ROTATION VECTOR of the model
   for (int k = 0; k < 3; k++) { m[k] = rv[k]; m[3 + k] = tv[k]; }
   for (int k = 0; k < 9; k++) m[6 + k] = R[k];
@@ -533,15 +622,15 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
         for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) LtL[9 * j + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
       }
       for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) { LtL[9 * j + k] = wave_allsum(LtL[9 * j + k]); LtL[9 * k + j] = LtL[9 * j + k]; }
+      if (lane == 0) for (int k = 0; k < 81; k++) wsA[k] = LtL[k];
+      group_sync();
+      if (lane < 16) jacobi_eig_group<9>(wsA, wsV, lane);
       if (lane == 0) {
-        for (int k = 0; k < 81; k++) wsA[k] = LtL[k];
         int o9[9];
-        jacobi_eig<9>(wsA, wsV);
         order_desc<9>(wsA, o9);
         for (int k = 0; k < 9; k++) wsOut[k] = wsV[9 * k + o9[8]];
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      group_sync();
       double H0[9], Ht[9], h[9];
       for (int k = 0; k < 9; k++) H0[k] = wsOut[k];
       const double invHnorm[9] = {1. / s4[0], 0, c4[0], 0, 1. / s4[1], c4[1], 0, 0, 1};
@@ -574,15 +663,15 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
         for (int j = 0; j < 12; j++) for (int k = j; k < 12; k++) LL[12 * j + k] += L0[j] * L0[k] + L1[j] * L1[k];
       }
       for (int j = 0; j < 12; j++) for (int k = j; k < 12; k++) { LL[12 * j + k] = wave_allsum(LL[12 * j + k]); LL[12 * k + j] = LL[12 * j + k]; }
+      if (lane == 0) for (int k = 0; k < 144; k++) wsA[k] = LL[k];
+      group_sync();
+      if (lane < 16) jacobi_eig_group<12>(wsA, wsV, lane);
       if (lane == 0) {
-        for (int k = 0; k < 144; k++) wsA[k] = LL[k];
         int o12[12];
-        jacobi_eig<12>(wsA, wsV);
         order_desc<12>(wsA, o12);
         for (int k = 0; k < 12; k++) wsOut[k] = wsV[12 * k + o12[11]];
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      group_sync();
       double RRt[12];
       for (int k = 0; k < 12; k++) RRt[k] = wsOut[k];
       double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
@@ -647,7 +736,9 @@ __global__ __launch_bounds__(64) void k_pnpcv_refit(const float* __restrict__ ob
       double A[36], d[6];
       for (int k = 0; k < 36; k++) A[k] = JtJ[k];
       for (int k = 0; k < 6; k++) A[7 * k] *= 1. + lambda;
-      lstsq_svd<6, 6>(A, JtErr, d);     // solve(JtJN, JtErr, ., DECOMP_SVD)
+      // solve(JtJN, JtErr, ., DECOMP_SVD): the system is symmetric positive definite but for degenerate point sets — Cholesky (in
+      // registers) gives the SVD's solution to rounding; a failed pivot falls back to the eigen-decomposition (minimum-norm solution)
+      if (!chol6_solve(A, JtErr, d)) lstsq_svd<6, 6>(A, JtErr, d);
       for (int k = 0; k < 6; k++) param[k] = prevParam[k] - d[k];
     };
     double curNorm = evaluate(true);    // STARTED: J and err at the initial parameters

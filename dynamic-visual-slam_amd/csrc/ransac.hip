@@ -1336,7 +1336,7 @@ dvs_status dvs_solve_pnp_ransac_cv_batch(dvs_matcher* ctx, int32_t nprob, const 
   hipLaunchKernelGGL(k_io_import, dim3((ndw_in + 255) / 256), dim3(256), 0, st, (const uint32_t*)hio, (uint32_t*)base, ndw_in);
   const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
   const float thr = (float)(reproj_err * reproj_err);
-  hipLaunchKernelGGL(k_epnp_hypotheses, dim3((H + kEpnpThreads - 1) / kEpnpThreads, nprob), dim3(kEpnpThreads), 0, st, d_obj, d_img, d_probs, d_samples, H, fx, fy, cx, cy, d_models);
+  hipLaunchKernelGGL(k_epnp_hypotheses, dim3((H + kEpnpGroups - 1) / kEpnpGroups, nprob), dim3(64), 0, st, d_obj, d_img, d_probs, d_samples, H, fx, fy, cx, cy, d_models);
   hipLaunchKernelGGL(k_pnpcv_score, dim3(H, nprob), dim3(256), 0, st, d_obj, d_img, d_probs, H, d_models, fx, fy, cx, cy, thr, d_counts);
   hipLaunchKernelGGL(k_ransac_select, dim3(nprob), dim3(1), 0, st, d_counts, H, d_probs, 5, confidence, 1, d_sel, 1, H);
   hipLaunchKernelGGL(k_pnpcv_refit, dim3(nprob), dim3(64), 0, st, d_obj, d_img, d_probs, H, d_models, d_sel, fx, fy, cx, cy, thr, d_inl, d_out);

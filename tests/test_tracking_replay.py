@@ -55,6 +55,27 @@ def test_hip_pipeline_against_cpu_pipeline_and_ground_truth(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_hip_pipeline_with_opencvs_pnp_procedure_on_a_scene_with_relief(gpu, oracle):
+    """the tracking replay with cv::solvePnPRansac BY OPENCV'S PROCEDURE in the pose stage (dvs_solve_pnp_ransac_cv: cv::RNG samples, EPnP, float
+    scoring, adaptive stop, iterative refit) on both sides — HIP library and CPU oracle — over 60 frames whose depth image carries a 200 mm checker
+    relief, so that a frame's 3D points are not coplanar (on the exactly planar scene EPnP is rank-deficient, in OpenCV as here).  Both pipelines
+    draw the same samples.  The scene stays close to a plane: a 5-point sample from ONE depth layer is a degenerate EPnP problem whose answer
+    depends on the eigen-solver's rounding, so the two statements (different Jacobi orderings) do not count the same inliers in every frame
+    — on general 3D scenes they do, index for index: tests/test_ransac.py::test_gpu_pnp_cv.  Bars here: same keyframes, poses within
+    5 mm / 0.2 deg RMS of each other (1.3 mm / 0.05 deg measured), inlier counts equal in >= 75 % of the frames and within 5 % elsewhere."""
+    import replay_tracking as rt
+    r = rt.run(n_frames=60, ba_every=2, with_cpu=True, pnp="cv", relief_mm=200)
+    raw = r.pop("_raw")
+    assert r["hip_vs_cpu"]["same_keyframes"] and r["hip"]["keyframes"] >= 2
+    assert r["hip_vs_cpu"]["rmse"]["translation_m"] < 5e-3 and r["hip_vs_cpu"]["rmse"]["rotation_deg"] < 0.2, r["hip_vs_cpu"]
+    assert r["hip"]["pose_updates"] == 59 and r["hip"]["pnp_failures"] == 0 and r["hip"]["motion_outliers"] == 0
+    assert raw["hip"]["stats"]["matches"] == raw["cpu"]["stats"]["matches"]
+    a, b = np.array(raw["hip"]["stats"]["pnp_inliers"]), np.array(raw["cpu"]["stats"]["pnp_inliers"])
+    assert len(a) == len(b) == 59 and (a == b).mean() >= 0.75 and (np.abs(a - b) <= 0.05 * b).all(), (a - b).tolist()
+    assert rt.PNP_MODE == "own" and rt.RELIEF_MM == 0                                        # the switches are restored
+
+
+@pytest.mark.gpu
 def test_batched_phase_one_equals_per_frame_calls_and_shards(gpu):
     """phase 1 (64 frames per call, device-resident between extraction, depth filter and match) gives every frame the bytes of the
     one-frame-per-call host entry points; 8 contiguous shards (each re-extracting the frame before its range) give the same again"""

@@ -35,6 +35,24 @@ sys.path.insert(0, os.path.join(ROOT, "dynamic-visual-slam_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# Variant switches of the replay (set by run() / the command line; both pipelines read the same ones):
+#   PNP_MODE "own": dvs_solve_pnp_ransac — P3P + LM with the library's documented sampler (the default: valid on the exactly planar scene);
+#            "cv":  dvs_solve_pnp_ransac_cv — cv::solvePnPRansac by OpenCV's procedure (EPnP on cv::RNG's 5-point samples + iterative refit).
+#   RELIEF_MM: the depth image becomes plane + a 64-pixel checker of this height (SURVEY.md section 8d's "50 mm checker"), so that the 3D
+#            points of a frame are NOT coplanar — EPnP's 4-control-point formulation is rank-deficient on an exactly planar set, in
+#            OpenCV as here.  The frames stay renderings of the plane: a 3 % depth error moves a reprojection by < 0.25 px per frame.
+PNP_MODE = "own"
+RELIEF_MM = 0
+
+
+def make_depth(rows, cols, z0):
+    d = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    if RELIEF_MM:
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        d[((yy // 64 + xx // 64) & 1) == 1] += np.uint16(RELIEF_MM)
+    return d
+
+
 def rodrigues_to_R(w):
     th = np.linalg.norm(w)
     if th < 1e-15:
@@ -80,6 +98,9 @@ class HipStages:
         return self.g.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
 
     def pnp(self, obj, img, K4, seed):
+        if PNP_MODE == "cv":
+            ok, rvec, tvec, inl, _ = self.g.solve_pnp_ransac_cv(obj, img, K4, 100, 4.0, 0.99)
+            return ok, rvec, tvec, len(inl)
         ok, rvec, tvec, inl = self.g.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
         return ok, rvec, tvec, len(inl)
 
@@ -91,6 +112,8 @@ class HipStages:
         return [m.astype(bool) for m, _, _ in self.g.find_fundamental_cv_batch(p1_list, p2_list, 2.0, 0.99, 1000)]
 
     def pnp_batch(self, obj_list, img_list, K4, seeds):
+        if PNP_MODE == "cv":
+            return [(ok, rvec, tvec, len(inl)) for ok, rvec, tvec, inl, _ in self.g.solve_pnp_ransac_cv_batch(obj_list, img_list, K4, 100, 4.0, 0.99)]
         return [(ok, rvec, tvec, len(inl)) for ok, rvec, tvec, inl in self.g.solve_pnp_ransac_batch(obj_list, img_list, K4, seeds, 100, 4.0, 0.99)]
 
     def match_many_vs_one(self, q_list, train):
@@ -146,6 +169,9 @@ class CpuStages:
         return self.ob.find_fundamental_cv(p1, p2, 2.0, 0.99, 1000)[1].astype(bool)
 
     def pnp(self, obj, img, K4, seed):
+        if PNP_MODE == "cv":
+            ok, rvec, tvec, inl, sel, _ = self.ob.solve_pnp_ransac_cv(obj, img, K4, 100, 4.0, 0.99)
+            return ok, rvec, tvec, len(inl)
         ok, rvec, tvec, inl, sel = self.ob.solve_pnp_ransac(obj, img, K4, 100, 4.0, 0.99, seed)
         return ok, rvec, tvec, len(inl)
 
@@ -365,7 +391,7 @@ def track(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every=10, verbose=F
     from dvslam_amd import synth
     cx, cy = cols / 2.0, rows / 2.0
     K4 = np.array([f, f, cx, cy])
-    depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    depth = make_depth(rows, cols, z0)
     R_, t_ = np.eye(3), np.zeros(3)                       # Frontend::R_, t_ (frontend.cpp:162-163)
     poses = []
     prev_k = prev_d = None
@@ -467,7 +493,7 @@ def track_batched(stages, n_frames, cols, rows, f, z0, nfeatures, ba_every, fram
     Results are those of track() with the same stages, bit for bit (every problem gets what its single call gives)."""
     cx, cy = cols / 2.0, rows / 2.0
     K4 = np.array([f, f, cx, cy])
-    depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    depth = make_depth(rows, cols, z0)
     t0w = time.perf_counter()
     stats = dict(matches=[], geometric=[], pnp_inliers=[], pose_updates=0, motion_outliers=0, pnp_failures=0)
     # ---- A: distance filter + fundamental-matrix gate for every frame pair
@@ -651,16 +677,29 @@ def rmse(a, b):
                 max_translation_m=float(np.max(e)), max_rotation_deg=float(np.max(r)))
 
 
-def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_every=5, with_cpu=True, verbose=False, batched=True, shards=1):
+def run(n_frames=1000, cols=640, rows=480, f=600.0, z0=1.5, nfeatures=1000, ba_every=5, with_cpu=True, verbose=False, batched=True, shards=1, pnp="own",
+        relief_mm=0):
+    global PNP_MODE, RELIEF_MM
+    saved = (PNP_MODE, RELIEF_MM)
+    PNP_MODE, RELIEF_MM = pnp, relief_mm
+    try:
+        return _run(n_frames, cols, rows, f, z0, nfeatures, ba_every, with_cpu, verbose, batched, shards, pnp, relief_mm)
+    finally:
+        PNP_MODE, RELIEF_MM = saved
+
+
+def _run(n_frames, cols, rows, f, z0, nfeatures, ba_every, with_cpu, verbose, batched, shards, pnp, relief_mm):
     from dvslam_amd import synth
     frames = [synth.make_traj_frame(t, cols, rows) for t in range(n_frames)]
     gt = ground_truth(n_frames, f, z0)
     res = dict(config=dict(frames=n_frames, resolution=[cols, rows], nfeatures=nfeatures, focal_px=f, plane_depth_m=z0, ba_every_keyframes=ba_every,
-                           ransac="findFundamentalMat(RANSAC, 2 px, 0.99) / solvePnPRansac(100, 4 px, 0.99), seeds = frame index"))
+                           ransac="findFundamentalMat(RANSAC, 2 px, 0.99) / solvePnPRansac(100, 4 px, 0.99), seeds = frame index",
+                           pnp=("cv::solvePnPRansac by OpenCV's procedure (EPnP + iterative refit)" if pnp == "cv" else "P3P + LM, own sampler"),
+                           depth_relief_mm=relief_mm))
     t0 = time.perf_counter()
     pre, t_phase1 = None, 0.0
     if batched:
-        depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+        depth = make_depth(rows, cols, z0)
         fe = BatchedFrontEnd(nfeatures, rows, cols)          # handles and buffers: set up once, like the stages' (not per frame)
         fe.run(frames[:2], depth)                            # ... and the first call's lazy workspace allocation / kernel load
         t0 = time.perf_counter()
@@ -749,7 +788,7 @@ def run_ranks(a):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")                                     # only the hand-over of the RCCL unique id and the final barrier
     n, cols, rows, nf, f, z0 = a.frames, a.cols, a.rows, a.nfeatures, 600.0, 1.5
-    depth = np.full((rows, cols), int(round(z0 * 1000)), np.uint16)
+    depth = make_depth(rows, cols, z0)
     fe = BatchedFrontEnd(nf, rows, cols, 64, local)                      # handles (and their streams) before the communicator comes up
     fe.run([synth.make_traj_frame(t, cols, rows) for t in range(2)], depth)
 
@@ -793,6 +832,8 @@ if __name__ == "__main__":
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--per-frame", action="store_true", help="round 2's form: one frame per call through the host entry points")
     ap.add_argument("--shards", type=int, default=1, help="contiguous frame ranges of phase 1 (one per rank on a multi-GPU node)")
+    ap.add_argument("--pnp", choices=("own", "cv"), default="own", help="cv: dvs_solve_pnp_ransac_cv (OpenCV's procedure); use with --relief-mm")
+    ap.add_argument("--relief-mm", type=int, default=0, help="depth = plane + a 64-px checker of this height: non-coplanar 3D points (EPnP needs them)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     if a.gpus >= 1:
@@ -815,7 +856,8 @@ if __name__ == "__main__":
             r["golden"] = compare_with_golden(hip, a.golden)
         print(json.dumps(r, indent=1))
         sys.exit(0)
-    r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True, batched=not a.per_frame, shards=a.shards)
+    r = run(a.frames, a.cols, a.rows, nfeatures=a.nfeatures, with_cpu=not a.no_cpu, verbose=True, batched=not a.per_frame, shards=a.shards, pnp=a.pnp,
+            relief_mm=a.relief_mm)
     r.pop("_raw")
     print(json.dumps(r, indent=1))
     if a.out:
