@@ -28,6 +28,8 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 using namespace dvs;
 
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 struct dvs_orb {
   dvs_orb_params prm;
   int device = 0;
@@ -232,6 +234,9 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
   memset(&G, 0, sizeof(G));
   const int nl = h->prm.nlevels;
   G.nlevels = nl; G.rows = rows; G.cols = cols;
+  // the streaming blur's band: a wavefront walks its rows one after the other, so a few frames get shorter bands (more wavefronts, 6 halo
+  // rows each): 16 rows up to 2 frames per launch sequence, 32 up to 8, kBlurBand beyond (128 measured slower than 64 at 64 frames, round 3)
+  G.blurBand = h->max_batch <= 2 ? 16 : (h->max_batch <= 8 ? 32 : kBlurBand);
   G.iniTh = std::min(std::max(h->prm.ini_th_fast, 0), 255);  // cv::FAST clamps the threshold
   G.minTh = std::min(std::max(h->prm.min_th_fast, 0), 255);
   G.outCap = h->prm.nfeatures + 3 * nl;
@@ -320,7 +325,7 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     {  // streaming blur: equal-width strips of <= 248 columns (multiples of 4), bands of kBlurBand rows
       const int ns = (L.w + 247) / 248;  // 62 output lanes + 2 halo lanes per wavefront
       const int sw = ((L.w + ns - 1) / ns + 3) / 4 * 4;
-      for (int y0 = 0; y0 < L.h; y0 += kBlurBand)
+      for (int y0 = 0; y0 < L.h; y0 += G.blurBand)
         for (int x0 = 0; x0 < L.w; x0 += sw) strips.push_back(BlurStrip{(int16_t)l, (int16_t)x0, (int16_t)std::min(sw, L.w - x0), (int16_t)y0});
     }
     if (l > 0) {
@@ -358,10 +363,14 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     auto srcy = [&](int k, int y) { return std::min(std::max(yofs[G.lv[k].ytab + y], 0), G.lv[k - 1].h - 1); };  // top tap
     int maxBytes = 0;
     bool cascade_ok = true;
-    // tile = the level-1 pixels a workgroup owns (results do not depend on the tiling).  Smaller tiles = more, shorter workgroups were
-    // measured for the few-frame case the cascade serves (profiles/r04_batch_sweep.json): 1 frame 0.057 -> 0.053 ms per step at 64 x 16,
-    // 8 frames 0.118 -> 0.142: its latency is the seven dependent levels, not the tile's size.  128 x 64 stays.
-    const int tileW = kPyrTileW, tileH = kPyrTileH;
+    // tile = the level-1 pixels a workgroup owns (results do not depend on the tiling).  The cascade's latency is its seven dependent levels
+    // plus a fixed part per workgroup (tile record -> tables -> staging), so the tile follows the batch the handle is built for: a
+    // one-frame handle (a lane of dvs_pipeline at 1 frame per step) takes 64 x 16 — 32 -> 22 us for the launch, 18.6 -> 20.1 k frames/s
+    // in the three-lane schedule — and everything else 128 x 64 (64 x 16 at 2 frames per step: 34.7 -> 31.7 k, at 8: 45.8 -> 91.7 us;
+    // 512 / 1024 threads per workgroup with 256 x 64 tiles: +1 % at 4 and 8 frames, not kept).  DVS_CASC_TW / DVS_CASC_TH override
+    // (tools/time_cascade_variants.py).  EXPERIMENTS.md, round 4.
+    const int cascT = 256;   // threads per workgroup of k_pyr_cascade
+    const int tileW = env_int("DVS_CASC_TW", h->max_batch <= 1 ? 64 : kPyrTileW), tileH = env_int("DVS_CASC_TH", h->max_batch <= 1 ? 16 : kPyrTileH);
     for (int ty = 0; ty < G.lv[1].h; ty += tileH)
       for (int tx = 0; tx < G.lv[1].w; tx += tileW) {
         PyrTile T{};
@@ -405,7 +414,11 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
         T.sy1 = (int16_t)(std::min(srcy(1, cyb - 1) + 1, G.lv[0].h - 1) + 1);
         maxBytes = std::max(maxBytes, (((T.sx1 - T.sx0) + 3) & ~3) * (T.sy1 - T.sy0));
         int tabx = 0, taby = 0;
-        for (int k = 1; k < nl; k++) { tabx += ((T.lv[k].cx1 - T.lv[k].cx0) + 3) & ~3; taby += T.lv[k].cy1 - T.lv[k].cy0; }
+        for (int k = 1; k < nl; k++) {
+          const int cwp = ((T.lv[k].cx1 - T.lv[k].cx0) + 3) & ~3, chh = T.lv[k].cy1 - T.lv[k].cy0;
+          tabx += cwp; taby += chh;
+          if (cwp > cascT || chh > cascT) cascade_ok = false;   // k_pyr_cascade: one table entry per thread and level
+        }
         if (tabx > kPyrTabX || taby > kPyrTabY) cascade_ok = false;
         ptiles.push_back(T);
       }
@@ -540,7 +553,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   }
   DVS_TRY(upload(&h->d_rgroups, rgroups));
   DVS_TRY(upload(&h->d_pyrtiles, ptiles));
-  if (G.pyrLds > 0) DVS_HIP(hipFuncSetAttribute((const void*)k_pyr_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G.pyrLds));
+  if (G.pyrLds > 0) DVS_HIP(hipFuncSetAttribute((const void*)k_pyr_cascade<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G.pyrLds));
   DVS_TRY(upload(&h->d_xofs, xofs)); DVS_TRY(upload(&h->d_alpha, alpha));
   DVS_TRY(upload(&h->d_yofs, yofs)); DVS_TRY(upload(&h->d_beta, beta));
   DVS_HIP(hipMalloc((void**)&h->d_pyr, B * G.frameBytes + 256));   // + slack: k_resize4 reads whole 12-byte windows at a row's end
@@ -823,7 +836,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   const bool ov = !prefetched && !cascade && !sharded && h->overlap && G.nlevels >= 2;   // in-step chain beside FAST
   if (cascade) {
     h->timer.begin(DVS_STAGE_PYRAMID, st);
-    hipLaunchKernelGGL(k_pyr_cascade, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
+    hipLaunchKernelGGL(k_pyr_cascade<256>, dim3(G.pyrTiles, nimg), dim3(256), 2 * (size_t)G.pyrLds, st, h->d_geom, h->d_pyrtiles, src,
                        h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, G.pyrLds);
     h->timer.end(st);
   } else if (!prefetched) {
@@ -990,7 +1003,6 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->stream = h->own_stream;
   // The switches of this handle, read once (see the struct).  DVS_NO_OVERLAP=1 = dvs_orb_set_overlap(h, 0) from the start: every
   // stage alone on the main stream.
-  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   h->single_stream = single_stream;
   h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0 && !single_stream;
   h->env_cascade = env_int("DVS_CASCADE", -1);

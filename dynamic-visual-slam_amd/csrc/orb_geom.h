@@ -40,6 +40,7 @@ struct Geom {
   int32_t outCap;       // nfeatures + 3 * nlevels
   int32_t blurTiles;    // tiles of the (generic) blur launch over all levels
   int32_t blurStrips;   // wave work items of the streaming blur
+  int32_t blurBand;     // rows per work item: kBlurBand for batches, fewer for a few frames (a wavefront walks its rows one after the other)
   int32_t pyrTiles;     // workgroups of the pyramid cascade
   int32_t pyrLds;       // bytes of ONE of its two LDS buffers
   int32_t fastP;        // LDS tile pitch of the wave-per-cell FAST kernel (48 / 64 / 80)
@@ -78,7 +79,7 @@ struct BlurTile { int16_t level, tx, ty, pad; };
 // halves, and the Q11 coefficient pairs (a0 | a1 << 16) for v_dot2_u32_u16
 struct ResizeGroup { int32_t base; uint32_t shift; uint32_t sel[4]; int32_t alpha[4]; };
 
-// streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x kBlurBand rows
+// streaming blur work item: one wavefront filters a strip of `w` columns (4 per lane) x Geom::blurBand rows
 constexpr int kBlurBand = 64;
 struct BlurStrip { int16_t level, x0, w, y0; };
 

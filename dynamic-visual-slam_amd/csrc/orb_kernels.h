@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void k_resize4(const u8* __restrict__ src, uin
 // integer arithmetic as k_resize (OpenCV's Q11 INTER_LINEAR), level 0 is read ~1.1x, every level is written once.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPyrTabX = 1024, kPyrTabY = 640;  // LDS table entries over all levels of one tile (checked on the host)
-__global__ __launch_bounds__(256) void k_pyr_cascade(const Geom* __restrict__ g, const PyrTile* __restrict__ tiles, ImgSrc src,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pyr_cascade(const Geom* __restrict__ g, const PyrTile* __restrict__ tiles, ImgSrc src,
                                                      const int* __restrict__ xofs, const int* __restrict__ alpha,
                                                      const int* __restrict__ yofs, const int* __restrict__ beta, int bufBytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -358,38 +359,52 @@ __global__ __launch_bounds__(256) void k_pyr_cascade(const Geom* __restrict__ g,
     const int n = wpr * shh;
     const float inv = 1.0f / (float)wpr;
     const int W0 = g->lv[0].w;
-    for (int i = tid; i < n; i += 256) {
+    // four words per thread and trip, all requested before the first is stored (a trip per word paid the global latency a dozen times)
+    auto fetch = [&](int i) -> uint32_t {
       const int r = (int)(((float)i + 0.5f) * inv);
       const int c = i - r * wpr;
       const u8* p = img + (uint64_t)r * src.step0 + 4 * c;
-      uint32_t v;
-      if (T.sx0 + 4 * c + 3 < W0) v = *reinterpret_cast<const uint32_t*>(p);
-      else {  // last word of a row whose width is not a multiple of 4: never read past the image
-        v = 0;
-        for (int b = 0; b < 4; b++) if (T.sx0 + 4 * c + b < W0) v |= (uint32_t)p[b] << (8 * b);
-      }
-      d32[i] = v;
+      if (T.sx0 + 4 * c + 3 < W0) return *reinterpret_cast<const uint32_t*>(p);
+      uint32_t v = 0;   // last word of a row whose width is not a multiple of 4: never read past the image
+      for (int b = 0; b < 4; b++) if (T.sx0 + 4 * c + b < W0) v |= (uint32_t)p[b] << (8 * b);
+      return v;
+    };
+    for (int i0 = tid; i0 < n; i0 += 4 * NT) {
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = i0 + NT * u < n ? fetch(i0 + NT * u) : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (i0 + NT * u < n) d32[i0 + NT * u] = v[u];
     }
-    // tables
+    // tables: every level's entries are REQUESTED before any is stored (one global round trip for the whole cascade — level by level the
+    // two dependent trips per level, tile record -> table entry, were most of the kernel's 35 us on one frame).  A thread holds one x and
+    // one y entry per level: regions are at most 256 wide and high (checked on the host); up to 15 levels below level 0.
+    constexpr int kLv = DVS_MAX_LEVELS - 1;
+    int xv[kLv], av[kLv], yv[kLv], bv[kLv], xoK[kLv], yoK[kLv], oxK[kLv], oyK[kLv], swK[kLv], shK[kLv];
+    bool hx[kLv], hy[kLv];
     int xo = 0, yo = 0, ox = T.sx0, oy = T.sy0;
-    for (int k = 1; k < nl; k++) {
-      const PyrTileLevel R = T.lv[k];
-      const int cw = R.cx1 - R.cx0, chh = R.cy1 - R.cy0;
-      if (cw <= 0 || chh <= 0) break;
-      const LevelGeom& L = g->lv[k];
-      const int SW = g->lv[k - 1].w, SH = g->lv[k - 1].h;
-      const int cwp = (cw + 3) & ~3;
-      for (int i = tid; i < cwp; i += 256) {
-        const int x = min(R.cx0 + i, L.w - 1);
-        const int o = xofs[L.xtab + x];
-        tx[xo + i] = make_uint2((uint32_t)(o - ox) | ((uint32_t)(min(o + 1, SW - 1) - ox) << 16), (uint32_t)alpha[L.xtab + x]);
+    bool live = true;
+#pragma unroll
+    for (int k = 1; k <= kLv; k++) {
+      hx[k - 1] = hy[k - 1] = false;
+      if (k < nl && live) {
+        const PyrTileLevel R = T.lv[k];
+        const int cw = R.cx1 - R.cx0, chh = R.cy1 - R.cy0;
+        if (cw <= 0 || chh <= 0) live = false;
+        else {
+          const LevelGeom& L = g->lv[k];
+          const int cwp = (cw + 3) & ~3;
+          xoK[k - 1] = xo; yoK[k - 1] = yo; oxK[k - 1] = ox; oyK[k - 1] = oy; swK[k - 1] = g->lv[k - 1].w - 1; shK[k - 1] = g->lv[k - 1].h - 1;
+          if (tid < cwp) { const int x = min(R.cx0 + tid, L.w - 1); xv[k - 1] = xofs[L.xtab + x]; av[k - 1] = alpha[L.xtab + x]; hx[k - 1] = true; }
+          if (tid < chh) { yv[k - 1] = yofs[L.ytab + R.cy0 + tid]; bv[k - 1] = beta[L.ytab + R.cy0 + tid]; hy[k - 1] = true; }
+          xo += cwp; yo += chh; ox = R.cx0; oy = R.cy0;
+        }
       }
-      for (int i = tid; i < chh; i += 256) {
-        const int sy = yofs[L.ytab + R.cy0 + i];
-        ty[yo + i] = make_uint2((uint32_t)(min(max(sy, 0), SH - 1) - oy) | ((uint32_t)(min(max(sy + 1, 0), SH - 1) - oy) << 16),
-                                (uint32_t)beta[L.ytab + R.cy0 + i]);
-      }
-      xo += cwp; yo += chh; ox = R.cx0; oy = R.cy0;
+    }
+#pragma unroll
+    for (int k = 0; k < kLv; k++) {
+      if (hx[k]) { const int o = xv[k]; tx[xoK[k] + tid] = make_uint2((uint32_t)(o - oxK[k]) | ((uint32_t)(min(o + 1, swK[k]) - oxK[k]) << 16), (uint32_t)av[k]); }
+      if (hy[k]) { const int sy = yv[k]; ty[yoK[k] + tid] = make_uint2((uint32_t)(min(max(sy, 0), shK[k]) - oyK[k]) | ((uint32_t)(min(max(sy + 1, 0), shK[k]) - oyK[k]) << 16), (uint32_t)bv[k]); }
     }
   }
   __syncthreads();
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(256) void k_pyr_cascade(const Geom* __restrict__ g,
     const u8* sb = buf[cur];
     u8* db = buf[cur ^ 1];
     const int ng = dP >> 2;
-    const int rpp = 256 / ng;  // rows per pass
+    const int rpp = NT / ng;  // rows per pass
     const int gx = tid % ng, ry = tid / ng;
     u8* gdst = src.pyr + (uint64_t)f * g->frameBytes + L.off;
     if (ry < rpp) {
@@ -1591,7 +1606,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
   }
   const uint32_t kv[7] = {(uint32_t)g->gk[0], (uint32_t)g->gk[1], (uint32_t)g->gk[2], (uint32_t)g->gk[3],
                           (uint32_t)g->gk[4], (uint32_t)g->gk[5], (uint32_t)g->gk[6]};
-  const int rows = min(kBlurBand, H - s.y0);
+  const int rows = min(g->blurBand, H - s.y0);
   const int T = rows + 6;
 
   auto load_own = [&](int k) -> uint32_t {
