@@ -82,6 +82,14 @@ struct dvs_orb {
   hipEvent_t gate_event = nullptr;         // = ev_end or the caller's output event, whichever the last call recorded at its end
   bool pf_joined = false;                  // the prefetched pyramid's completion already precedes the main stream (joined through the blur)
   const u8* next_hint = nullptr;           // one-shot, set by the hint call, consumed by the next extract_batch_device
+  // The announced batch's level chain as ONE graph launch (launch_prefetch): the chain is 7 dependent launches whose arguments depend only on
+  // (source block, frame count, destination pyramid); callers stream from a ring of device buffers, so the same few argument sets come
+  // back — the second time a set is seen its chain is captured, from then on it costs one hipGraphLaunch (4 us of host time against 17:
+  // tools/probe/graph_launch_cost.hip).  Used where the host's enqueue is the limit (<= 12 frames per step; DVS_CHAIN_GRAPH=1 / 0 always / never).
+  struct ChainGraph { const u8* img0; uint64_t step0, fstride0; int nimg; u8* pyr; hipGraph_t graph; hipGraphExec_t exec; };
+  std::vector<ChainGraph> chain_graphs;
+  int env_chain_graph = -1;
+  int64_t chain_graph_launches = 0;
   bool pf_valid = false;                   // d_pyr_alt holds (or is being filled with) the pyramid of exactly this announced batch:
   const u8* pf_img = nullptr; uint64_t pf_step = 0, pf_fstride = 0; int pf_nimg = 0;
   // switches read ONCE at creation (dvs_orb_create); each is covered by tests/test_gpu_orb.py::test_opt_in_kernel_variants_are_bit_identical
@@ -140,6 +148,14 @@ struct dvs_orb {
 
 namespace {
 
+void drop_chain_graphs(dvs_orb* h) {
+  for (auto& c : h->chain_graphs) {
+    if (c.exec) (void)hipGraphExecDestroy(c.exec);
+    if (c.graph) (void)hipGraphDestroy(c.graph);
+  }
+  h->chain_graphs.clear();
+}
+
 void free_workspace(dvs_orb* h) {
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur3[0],
                   h->d_pyr_alt, h->d_pyr_3rd, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_celloff, h->d_candtotal,
@@ -153,6 +169,7 @@ void free_workspace(dvs_orb* h) {
     h->d_cand2[k] = nullptr; h->d_cellcount2[k] = nullptr; h->octdone_valid[k] = false;
   }
   h->cset = 0;
+  drop_chain_graphs(h);
   void* pinned[] = {h->h_kps, h->h_desc, h->h_nout, h->h_seq};
   for (void* p : pinned) if (p) (void)hipHostFree(p);
   h->h_seq = nullptr; h->d_ticket = nullptr;
@@ -717,7 +734,31 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
   h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
   // (the seven launches of the chain also for few frames: all levels in one launch — k_pyr_cascade — on this stream was measured at 6 / 8
   // frames per step: 0.103 / 0.119 ms against 0.092 / 0.103, its LDS tiles take FAST's workgroup slots; EXPERIMENTS.md)
-  DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+  const bool want_graph = h->env_chain_graph >= 0 ? h->env_chain_graph == 1 : nimg <= 12;
+  if (!want_graph) {
+    DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+  } else {
+    dvs_orb::ChainGraph* cg = nullptr;
+    for (auto& c : h->chain_graphs)
+      if (c.img0 == next_img0 && c.step0 == src.step0 && c.fstride0 == src.fstride0 && c.nimg == nimg && c.pyr == h->d_pyr_alt) { cg = &c; break; }
+    if (cg && cg->exec) {
+      DVS_HIP(hipGraphLaunch(cg->exec, h->pf_stream));
+      h->chain_graph_launches++;
+    } else if (cg) {   // second time: capture (nothing runs), instantiate, launch
+      DVS_HIP(hipStreamBeginCapture(h->pf_stream, hipStreamCaptureModeThreadLocal));
+      const dvs_status cs = launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false);
+      const hipError_t ce = hipStreamEndCapture(h->pf_stream, &cg->graph);
+      if (cs != DVS_OK) return cs;
+      DVS_HIP(ce);
+      DVS_HIP(hipGraphInstantiate(&cg->exec, cg->graph, nullptr, nullptr, 0));
+      DVS_HIP(hipGraphLaunch(cg->exec, h->pf_stream));
+      h->chain_graph_launches++;
+    } else {           // first time: plain launches, remember the argument set
+      if (h->chain_graphs.size() >= 48) drop_chain_graphs(h);   // a caller whose buffers never come back: stay bounded
+      h->chain_graphs.push_back({next_img0, src.step0, src.fstride0, nimg, h->d_pyr_alt, nullptr, nullptr});
+      DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
+    }
+  }
   h->timer.end(h->pf_stream);
   h->pf_idx ^= 1;
   h->ev_prefetch = h->ev_pf2[h->pf_idx];
@@ -1006,6 +1047,7 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->single_stream = single_stream;
   h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0 && !single_stream;
   h->env_cascade = env_int("DVS_CASCADE", -1);
+  h->env_chain_graph = env_int("DVS_CHAIN_GRAPH", -1);
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
   h->env_oct_threads = env_int("DVS_OCT_T", 0);
@@ -1089,6 +1131,8 @@ dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on) {
   h->async_oct = on != 0;
   return DVS_OK;
 }
+int64_t dvs_orb_chain_graph_launches(const dvs_orb* h) { return h ? h->chain_graph_launches : 0; }
+
 dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));

@@ -101,6 +101,7 @@ def lib():
     L.dvs_orb_set_reuse_guard_event.argtypes = [vp, vp]
     L.dvs_orb_set_async_quadtree.argtypes = [vp, i32]
     L.dvs_orb_set_tail_stream.argtypes = [vp, vp]
+    L.dvs_orb_chain_graph_launches.argtypes = [vp]; L.dvs_orb_chain_graph_launches.restype = C.c_int64
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]

@@ -161,6 +161,11 @@ dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on);
 /* ... and its descriptor stage on a stream of the caller (NULL: the auxiliary stream): with the quad-tree and the blur on the auxiliary
  * stream that stream alone would carry a whole step; a pipelined caller hands over its match stream (dvs_pipeline does). */
 dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream);
+/* Diagnostics: how many announced level chains (dvs_orb_hint_next_batch_device) were enqueued as ONE hipGraphLaunch instead of one launch
+ * per level.  The chain's arguments depend only on (source block, frame count, destination pyramid); the second time an argument set is
+ * seen its chain is captured into a graph, from then on it is one runtime call (4 us of host time against 17).  Automatic up to 12 frames
+ * per call, where the host's enqueue bounds the step (DVS_CHAIN_GRAPH=1 / 0: always / never). */
+int64_t dvs_orb_chain_graph_launches(const dvs_orb* h);
 
 /* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
  * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per

@@ -108,7 +108,30 @@ def test_four_stream_schedule(gpu, oracle, B, rows, cols, nf, nsets, steps):
     _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=1, quadtree_async=1)
 
 
-def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=0):
+@pytest.mark.parametrize("B,rows,cols,nf,qa", [(8, 720, 1280, 2000, 1), (6, 480, 640, 600, -1), (20, 360, 500, 400, -1)])
+def test_level_chain_as_graph_launch(gpu, oracle, monkeypatch, B, rows, cols, nf, qa):
+    """the announced batch's level chain enqueued as one hipGraphLaunch once its argument set (source block, frame count, destination
+    pyramid) has come back (dvs_orb_chain_graph_launches): the bytes of the steps that ran on graphs equal the oracle's.  Automatic up to
+    12 frames per step (first two cases: four-stream and two-stream form); forced on for 20."""
+    if B > 12:
+        monkeypatch.setenv("DVS_CHAIN_GRAPH", "1")
+    graphs = []
+    _run_shape(oracle, B, rows, cols, nf, 4, 22, lanes=1, quadtree_async=qa, probe=lambda pipe: graphs.append(
+        _lib_mod().lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
+    assert graphs[0] >= 8, graphs                                      # 3 resident batches x 2 or 3 pyramids: every set seen twice by step 13
+    monkeypatch.setenv("DVS_CHAIN_GRAPH", "0")
+    graphs.clear()
+    _run_shape(oracle, B, rows, cols, nf, 4, 5, lanes=1, quadtree_async=qa, probe=lambda pipe: graphs.append(
+        _lib_mod().lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
+    assert graphs == [0]
+
+
+def _lib_mod():
+    from dvslam_amd import _lib
+    return _lib
+
+
+def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=0, probe=None):
     from dvslam_amd import _lib
     from dvslam_amd.pipeline import StreamingPipeline
     NB = 3
@@ -132,6 +155,8 @@ def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=
             t = ref[i % NB][f - 1] if f else ref[(i - 1) % NB][B - 1]
             i2, d2 = oracle.match(ref[i % NB][f][2], t[2])
             assert (idx[f, :n[f]] == i2).all() and (dist[f, :n[f]] == d2).all(), (i, f)
+    if probe:
+        probe(pipe)
     pipe.close()
     return used
 
