@@ -68,9 +68,16 @@ struct dvs_orb {
   // pyramid blocks: d_pyr = this batch; d_pyr_alt = the announced next batch (built on pf_stream beside this batch's FAST, swapped in
   // by the next call); d_pyr_3rd = with deferred descriptor stages the pyramid of the batch before is still being read while the next
   // one is built, so the three rotate.  The last two are allocated on first use.
-  u8 *d_pyr = nullptr, *d_pyr_alt = nullptr, *d_pyr_3rd = nullptr, *d_blur = nullptr;
+  u8 *d_pyr = nullptr, *d_pyr_alt = nullptr, *d_pyr_3rd = nullptr, *d_pyr_4th = nullptr, *d_blur = nullptr;
+  // Depth of the rings a pipelined caller's batches rotate through (pyramids, candidate-list sets, level keypoint sets, blurred blocks): 3, or 4
+  // in the four-stream form (dvs_orb_set_tail_stream).  A batch passes chain -> blur -> FAST -> quad-tree -> descriptors on four streams; the
+  // chain of batch i + 1 waits for the descriptor stage that last read its buffer — batch i + 1 - ring — so ring periods of the schedule
+  // cannot be shorter than that chain of stages: at 8 frames 264 us / 3 = 88 us per step with three buffers, 66 with four (EXPERIMENTS.md).
+  int ring = 3;
+  int async_run = 0;               // consecutive asynchronous (prefetched + deferred) calls so far
+  int env_ring = 4;                // DVS_RING=3: keep three in the four-stream form
   // deferred descriptor stage (dvs_orb_set_output_event + dvs_orb_set_defer_outputs): ordered on the auxiliary stream only
-  hipEvent_t ev_outs[2] = {nullptr, nullptr};   // completion of the last two deferred stages (ev_out = the latest)
+  hipEvent_t ev_outs[3] = {nullptr, nullptr, nullptr};   // completion of the last ring - 1 deferred stages (ev_out = the latest)
   hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // ... / quad-tree finished (main stream): the deferred stage's join
   int out_gen = 0;                         // deferred stages enqueued so far
   bool out_pending = false;                // the previous call's descriptor stage has not been joined with the main stream
@@ -104,8 +111,8 @@ struct dvs_orb {
   uint32_t *d_kpsorted = nullptr, *d_kpsortidx = nullptr;   // a level's keypoints in the descriptor stage's visiting order + their list positions (k_kp_order)
   // level keypoint lists, three sets in rotation: deferred descriptor stages k - 1 and k - 2 may both still read theirs when call k's
   // quad-tree writes (stage k - 3 precedes the level chain call k's FAST waited for) — no wait on the main stream in front of it
-  uint32_t* d_lvlkp3[3] = {nullptr, nullptr, nullptr};
-  int* d_lvlcount3[3] = {nullptr, nullptr, nullptr};
+  uint32_t* d_lvlkp3[4] = {nullptr, nullptr, nullptr, nullptr};   // (the fourth of each ring: allocated when first used)
+  int* d_lvlcount3[4] = {nullptr, nullptr, nullptr, nullptr};
   int lset = 0;
   int *d_nodeof = nullptr, *d_cellcount = nullptr, *d_celloff = nullptr, *d_candtotal = nullptr, *d_lvlcount = nullptr;
   dvs_keypoint* d_kps = nullptr;   // internal outputs for the host entry points [max_batch][outCap]
@@ -127,16 +134,16 @@ struct dvs_orb {
   // ... and its blur on the MAIN stream ahead of FAST (main: blur + FAST, prefetch: level chain, auxiliary: quad-tree, tail: descriptors +
   // the caller's match — four streams of similar length for batches whose kernels do not fill the machine).  The blurred block then exists
   // three times: blur k + 1 rewrites the block descriptor stage k - 2 read, which the level chain FAST k + 1 waited for was gated on.
-  u8* d_blur3[3] = {nullptr, nullptr, nullptr};
+  u8* d_blur3[4] = {nullptr, nullptr, nullptr, nullptr};
   int bset = 0;
   // THREE candidate sets in turn (the second and third allocated on first use): FAST k + 1 writes while tree k reads, and the level chain
   // of call k + 2 — launched in call k + 1, ahead of FAST k + 1 — is gated on tree k - 1, the last reader of the set FAST k + 2 will write:
   // a tree that finished a whole step ago (with two sets the gate would be the tree still running beside that FAST)
-  uint32_t* d_cand2[3] = {nullptr, nullptr, nullptr};
-  int* d_cellcount2[3] = {nullptr, nullptr, nullptr};
+  uint32_t* d_cand2[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* d_cellcount2[4] = {nullptr, nullptr, nullptr, nullptr};
   int cset = 0;
-  hipEvent_t ev_octdone[3] = {nullptr, nullptr, nullptr};
-  bool octdone_valid[3] = {false, false, false};
+  hipEvent_t ev_octdone[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool octdone_valid[4] = {false, false, false, false};
   int oct_ncls = 0;                        // level classes of the graded launches (0 = no grading): class c = levels [oct_l0[c], oct_l0[c + 1])
   int oct_l0[4] = {0, 0, 0, 0};
   size_t oct_smem_cls[3] = {0, 0, 0};
@@ -158,12 +165,12 @@ void drop_chain_graphs(dvs_orb* h) {
 
 void free_workspace(dvs_orb* h) {
   void* ptrs[] = {h->d_blurcols, h->d_blurtab, h->d_pyrtiles, h->d_rgroups, h->d_strips, h->d_geom, h->d_cells, h->d_tiles, h->d_xofs, h->d_alpha, h->d_yofs, h->d_beta, h->d_pyr, h->d_blur3[0],
-                  h->d_pyr_alt, h->d_pyr_3rd, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_nodeof, h->d_celloff, h->d_candtotal,
-                  h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_kps, h->d_desc, h->d_nout, h->d_ticket, h->d_kpsorted, h->d_kpsortidx, h->d_kpident};
+                  h->d_pyr_alt, h->d_pyr_3rd, h->d_pyr_4th, h->d_pts, h->d_lvlkp3[0], h->d_lvlkp3[1], h->d_lvlkp3[2], h->d_lvlkp3[3], h->d_nodeof, h->d_celloff, h->d_candtotal,
+                  h->d_lvlcount3[0], h->d_lvlcount3[1], h->d_lvlcount3[2], h->d_lvlcount3[3], h->d_kps, h->d_desc, h->d_nout, h->d_ticket, h->d_kpsorted, h->d_kpsortidx, h->d_kpident};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (int k = 1; k < 3; k++) { if (h->d_blur3[k]) (void)hipFree(h->d_blur3[k]); h->d_blur3[k] = nullptr; }   // ([0] = the workspace's block, freed above)
+  for (int k = 1; k < 4; k++) { if (h->d_blur3[k]) (void)hipFree(h->d_blur3[k]); h->d_blur3[k] = nullptr; }   // ([0] = the workspace's block, freed above)
   h->d_blur3[0] = nullptr; h->bset = 0;
-  for (int k = 0; k < 3; k++) {   // (set 0 is the pair allocated with the workspace; h->d_cand / h->d_cellcount point at the set in use)
+  for (int k = 0; k < 4; k++) {   // (set 0 is the pair allocated with the workspace; h->d_cand / h->d_cellcount point at the set in use)
     if (h->d_cand2[k]) (void)hipFree(h->d_cand2[k]);
     if (h->d_cellcount2[k]) (void)hipFree(h->d_cellcount2[k]);
     h->d_cand2[k] = nullptr; h->d_cellcount2[k] = nullptr; h->octdone_valid[k] = false;
@@ -177,8 +184,8 @@ void free_workspace(dvs_orb* h) {
   h->d_strips = nullptr; h->d_rgroups = nullptr; h->d_pyrtiles = nullptr;
   h->d_geom = nullptr; h->d_cells = nullptr; h->d_tiles = nullptr; h->d_xofs = h->d_alpha = h->d_yofs = h->d_beta = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_cand = h->d_pts = h->d_lvlkp = nullptr;
-  for (int k = 0; k < 3; k++) { h->d_lvlkp3[k] = nullptr; h->d_lvlcount3[k] = nullptr; }
-  h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->out_gen = 0; h->pf_valid = false; h->next_hint = nullptr;
+  for (int k = 0; k < 4; k++) { h->d_lvlkp3[k] = nullptr; h->d_lvlcount3[k] = nullptr; }
+  h->d_pyr_alt = nullptr; h->d_pyr_3rd = nullptr; h->d_pyr_4th = nullptr; h->out_gen = 0; h->pf_valid = false; h->next_hint = nullptr;
   h->d_nodeof = h->d_cellcount = h->d_celloff = h->d_candtotal = h->d_lvlcount = nullptr;
   h->d_kpsorted = nullptr; h->d_kpsortidx = nullptr; h->d_kpident = nullptr;
   h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_nout = nullptr;
@@ -676,7 +683,7 @@ dvs_status launch_pyramid_chain(dvs_orb* h, const ImgSrc& src, int nimg, u8* pyr
       hipLaunchKernelGGL(k_resize4, dim3(tiles, ngroups), block, 0, pst,
                          sp, sfs, S.w, S.h, spitch, pyr + D.off, G.frameBytes, dwp, D.h, D.pitch,
                          h->d_rgroups + D.gtab, h->d_yofs + D.ytab, h->d_beta + D.ytab,
-                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off ? nimg - 1 : -1,   // caller's buffer: no slack behind its last row
+                         l == 1 && sp != h->d_pyr + G.lv[0].off && sp != h->d_pyr_alt + G.lv[0].off && sp != h->d_pyr_3rd + G.lv[0].off && sp != h->d_pyr_4th + G.lv[0].off ? nimg - 1 : -1,   // caller's buffer: no slack behind its last row
                          (int)tx, magic((uint64_t)tiles * ngroups, tiles), magic(tiles, tx), ngx, fpg, magic((uint64_t)tx * 64, (uint32_t)ngx), nimg);
     }
     else
@@ -718,8 +725,14 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
     // deferral (when it waited it ended after FAST and became the critical path).  The third buffer held the pyramid of two batches
     // ago; its last reader is that batch's descriptor stage, whose event is the only gate (nothing on the main stream).
     if (!h->d_pyr_3rd) DVS_HIP(hipMalloc((void**)&h->d_pyr_3rd, (size_t)h->max_batch * G.frameBytes + 256));
-    std::swap(h->d_pyr_alt, h->d_pyr_3rd);
-    if (h->out_gen >= 2) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_outs[h->out_gen & 1], 0));
+    if (h->ring == 4) {   // the oldest of four: alt <- 3rd <- 4th <- alt
+      if (!h->d_pyr_4th) DVS_HIP(hipMalloc((void**)&h->d_pyr_4th, (size_t)h->max_batch * G.frameBytes + 256));
+      u8* a = h->d_pyr_alt; h->d_pyr_alt = h->d_pyr_3rd; h->d_pyr_3rd = h->d_pyr_4th; h->d_pyr_4th = a;
+    } else {
+      std::swap(h->d_pyr_alt, h->d_pyr_3rd);
+    }
+    // its last reader: the descriptor stage of ring - 1 batches ago (the slot the NEXT deferred stage records into)
+    if (h->out_gen >= h->ring - 1) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_outs[h->out_gen % (h->ring - 1)], 0));
   } else {
     // d_pyr_alt's last readers are the previous call's kernels: its end-of-call event if it left one (no extra record), else this
     // point of the main stream
@@ -728,7 +741,9 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
     DVS_HIP(hipStreamWaitEvent(h->pf_stream, gate, 0));
   }
   // asynchronous quad-trees: the FAST that follows this chain writes candidate set cset + 1, last read by the tree of two calls ago
-  if (h->async_oct && h->octdone_valid[(h->cset + 1) % 3]) DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_octdone[(h->cset + 1) % 3], 0));
+  // (after `ring` asynchronous calls in a row the wait above — the descriptor stage of that very batch, which followed its tree — covers it)
+  if (h->async_oct && h->octdone_valid[(h->cset + 1) % h->ring] && !(pend && h->async_run >= h->ring))
+    DVS_HIP(hipStreamWaitEvent(h->pf_stream, h->ev_octdone[(h->cset + 1) % h->ring], 0));
   ImgSrc nsrc = src;
   nsrc.img0 = next_img0;
   h->timer.begin(DVS_STAGE_PYRAMID, h->pf_stream);  // the pyramid stage of the overlapped schedule IS this prefetch chain
@@ -843,14 +858,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // auxiliary work above — its tree included — and keeps the current set.)
   const bool async = h->async_oct && prefetched && will_defer && aligned0;
   if (async) {
-    h->cset = (h->cset + 1) % 3;
+    h->cset = (h->cset + 1) % h->ring;
     if (!h->d_cand2[h->cset]) {
       DVS_HIP(hipMalloc((void**)&h->d_cand2[h->cset], (size_t)h->max_batch * G.candPerFrame * 4));
       DVS_HIP(hipMalloc((void**)&h->d_cellcount2[h->cset], (size_t)h->max_batch * G.totalCells * 4));
     }
     h->d_cand = h->d_cand2[h->cset]; h->d_cellcount = h->d_cellcount2[h->cset];
     if (h->tail_stream) {
-      h->bset = (h->bset + 1) % 3;
+      h->bset = (h->bset + 1) % h->ring;
       if (!h->d_blur3[h->bset]) DVS_HIP(hipMalloc((void**)&h->d_blur3[h->bset], (size_t)h->max_batch * G.frameBytes));
       h->d_blur = h->d_blur3[h->bset];
     }
@@ -858,6 +873,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
     DVS_HIP(hipStreamWaitEvent(st, h->ev_octdone[h->cset], 0));   // this call's FAST rewrites the set the previous call's tree reads
   }
   h->last_async = async;
+  h->async_run = async ? h->async_run + 1 : 0;
 
   // 1. pyramid: level l from level l-1 (serial chain, ORBextractor.cpp:1171-1192)
   //    prefetched: nothing to build (non-deferred calls joined the chain through their blur — no barrier packet at all then);
@@ -944,7 +960,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // 3. quad-tree (latency-bound: launched first so that its workgroups become resident ahead of the blur's).  After a deferred stage
   //    it takes the next of the three level keypoint sets: stages k - 1 and k - 2 may still read theirs; stage k - 3 wrote its event
   //    before the level chain of THIS batch started, which this call's FAST waited for.
-  if (pend) { h->lset = (h->lset + 1) % 3; h->d_lvlkp = h->d_lvlkp3[h->lset]; h->d_lvlcount = h->d_lvlcount3[h->lset]; }
+  if (pend) {
+    h->lset = (h->lset + 1) % h->ring;
+    if (!h->d_lvlkp3[h->lset]) {
+      DVS_HIP(hipMalloc((void**)&h->d_lvlcount3[h->lset], (size_t)h->max_batch * G.nlevels * 4));
+      DVS_HIP(hipMalloc((void**)&h->d_lvlkp3[h->lset], (size_t)h->max_batch * (size_t)G.kpBlock * 4));
+    }
+    h->d_lvlkp = h->d_lvlkp3[h->lset]; h->d_lvlcount = h->d_lvlcount3[h->lset];
+  }
   //    Asynchronous (dvs_orb_set_async_quadtree, pipelined callers): on the auxiliary stream behind this call's FAST — nothing on the main
   //    stream needs it, so the next call's FAST follows this one's immediately and the tree runs beside it.
   hipStream_t qs = async ? bst : st;
@@ -995,7 +1018,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   }
   h->timer.end(dst);
   if (will_defer) {
-    h->ev_out = h->ev_outs[h->out_gen & 1];
+    h->ev_out = h->ev_outs[h->out_gen % (h->ring - 1)];
     h->out_gen++;
     DVS_HIP(hipEventRecord(h->ev_out, dst));
     DVS_HIP(hipEventRecord(h->output_event, dst));
@@ -1048,6 +1071,7 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0 && !single_stream;
   h->env_cascade = env_int("DVS_CASCADE", -1);
   h->env_chain_graph = env_int("DVS_CHAIN_GRAPH", -1);
+  h->env_ring = env_int("DVS_RING", 4);
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
   h->env_oct_threads = env_int("DVS_OCT_T", 0);
@@ -1065,8 +1089,8 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   // 0.628 -> 0.592 ms, neutral below 64)
   bool ok = single_stream || (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
                               hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_hi) == hipSuccess);
-  hipEvent_t* evs[] = {&h->ev_fork, &h->ev_blur, &h->ev_start, &h->ev_chain_gate, &h->ev_pf2[0], &h->ev_pf2[1], &h->ev_outs[0], &h->ev_outs[1],
-                       &h->ev_oct, &h->ev_end, &h->ev_octdone[0], &h->ev_octdone[1], &h->ev_octdone[2]};
+  hipEvent_t* evs[] = {&h->ev_fork, &h->ev_blur, &h->ev_start, &h->ev_chain_gate, &h->ev_pf2[0], &h->ev_pf2[1], &h->ev_outs[0], &h->ev_outs[1], &h->ev_outs[2],
+                       &h->ev_oct, &h->ev_end, &h->ev_octdone[0], &h->ev_octdone[1], &h->ev_octdone[2], &h->ev_octdone[3]};
   for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l < params->nlevels; l++) ok = ok && hipEventCreateWithFlags(&h->ev_level[l], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -1089,8 +1113,8 @@ void dvs_orb_destroy(dvs_orb* h) {
   free_workspace(h);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
-  hipEvent_t evs[] = {h->ev_fork, h->ev_blur, h->ev_start, h->ev_chain_gate, h->ev_pf2[0], h->ev_pf2[1], h->ev_outs[0], h->ev_outs[1], h->ev_oct, h->ev_end,
-                      h->ev_octdone[0], h->ev_octdone[1], h->ev_octdone[2]};
+  hipEvent_t evs[] = {h->ev_fork, h->ev_blur, h->ev_start, h->ev_chain_gate, h->ev_pf2[0], h->ev_pf2[1], h->ev_outs[0], h->ev_outs[1], h->ev_outs[2], h->ev_oct, h->ev_end,
+                      h->ev_octdone[0], h->ev_octdone[1], h->ev_octdone[2], h->ev_octdone[3]};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_level) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1138,8 +1162,16 @@ dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   if (h->aux_stream) DVS_HIP(hipStreamSynchronize(h->aux_stream));
+  if (h->pf_stream) DVS_HIP(hipStreamSynchronize(h->pf_stream));
   if (h->out_pending) { DVS_HIP(hipEventSynchronize(h->ev_out)); h->out_pending = false; }
   h->tail_stream = (hipStream_t)hip_stream;
+  // the four-stream form rotates over rings of four (see `ring`); everything is idle here: restart every rotation at its first set
+  h->ring = hip_stream && h->env_ring == 4 ? 4 : 3;
+  h->cset = h->bset = h->lset = 0; h->out_gen = 0; h->async_run = 0;
+  for (bool& v : h->octdone_valid) v = false;
+  h->d_cand = h->d_cand2[0]; h->d_cellcount = h->d_cellcount2[0]; h->d_blur = h->d_blur3[0];
+  h->d_lvlkp = h->d_lvlkp3[0]; h->d_lvlcount = h->d_lvlcount3[0];
+  h->last_async = false;
   return DVS_OK;
 }
 dvs_status dvs_orb_use_own_stream(dvs_orb* h) {

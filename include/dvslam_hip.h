@@ -291,9 +291,9 @@ typedef struct dvs_pipeline_params {
   int32_t quadtree_async; /* two-stream pipeline only.  1: the four-stream form — quad-tree on the extractor's auxiliary stream beside the next
                            step's FAST (dvs_orb_set_async_quadtree), descriptor stage on the match stream (dvs_orb_set_tail_stream), blur on the
                            main stream ahead of FAST; -1: off; 0 = by batch size (on for DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH:
-                           measured +21 % at 8 frames per step, +7 % at 12, a tie at 16, -9 % at 64) */
+                           measured +21 % at 8 frames per step, +13 % at 16, +3.5 % at 24, a tie at 28..32, -4 % at 64: profiles/r04_batch_sweep.json) */
 } dvs_pipeline_params;
-#define DVS_PIPELINE_ASYNC_BATCH 12
+#define DVS_PIPELINE_ASYNC_BATCH 24
 #define DVS_PIPELINE_MAX_LANES 4     /* HIP streams beyond four share hardware queues on this part */
 #define DVS_PIPELINE_LANE_BATCH 4    /* lanes = 0: batches up to this size run on lanes (measured: 8 frames and more tie or lose) */
 /* results of one step's batch (device pointers into the handle's output set; valid until step + nsets is enqueued) */

@@ -126,6 +126,17 @@ def test_level_chain_as_graph_launch(gpu, oracle, monkeypatch, B, rows, cols, nf
     assert graphs == [0]
 
 
+def test_four_stream_is_the_default_from_5_to_24_frames(gpu, oracle):
+    """DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH (4, 24): lanes below, the two-stream pipeline above; one default shape
+    in the upper half of the range against the oracle (rings of four sets: 9 steps go round twice)"""
+    from dvslam_amd.pipeline import StreamingPipeline
+    for B, want_lanes, want_async in [(4, 3, False), (5, 1, True), (24, 1, True), (25, 1, False)]:
+        pipe = StreamingPipeline(B, 240, 320, 300, nsets=0)
+        assert (pipe.lanes, pipe.quadtree_async) == (want_lanes, want_async), B
+        pipe.close()
+    _run_shape(oracle, 18, 480, 640, 700, 4, 9)
+
+
 def _lib_mod():
     from dvslam_amd import _lib
     return _lib

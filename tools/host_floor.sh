@@ -10,8 +10,8 @@ mkdir -p $OUT
 LIBDIR=$R/dynamic-visual-slam_amd/lib
 g++ -std=c++17 -O2 -I$R/include $R/tests/cpp/pipeline_stream.cpp -o /tmp/pipeline_stream -L$LIBDIR -ldvslam_hip -Wl,-rpath,$LIBDIR -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lpthread
 for B in $BS; do
-  for WH in "320 240" "1280 720"; do
-    set -- $WH
+  for WH in ${SIZES:-"320 240" "1280 720"}; do
+    set -- ${WH/x/ }
     python3 - $R $B $1 $2 <<'PY'
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1] + "/dynamic-visual-slam_amd")
