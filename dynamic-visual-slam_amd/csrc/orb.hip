@@ -1485,3 +1485,9 @@ dvs_status dvs_test_geometry(const dvs_orb_params* params, int32_t rows, int32_t
 #endif  // DVS_TEST_HOOKS
 
 }  // extern "C"
+
+#ifdef DVS_QT_PROF   // tools/qt_phase_profile.sh only: never part of the product or test libraries
+extern "C" int dvs_prof_qt(unsigned long long* out96) {
+  return (int)hipMemcpyFromSymbol(out96, HIP_SYMBOL(dvs::g_qt_prof), 96 * sizeof(unsigned long long));
+}
+#endif

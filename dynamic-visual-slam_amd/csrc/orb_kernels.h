@@ -162,6 +162,24 @@ __device__ __forceinline__ int block_excl_scan_rt(int v, int* wsum, int& total) 
   return base + incl - v;
 }
 
+// The same with ONE barrier: the wavefront sums alternate between two buffers (`par`, uniform, flipped by every call), so a call never
+// overwrites what a slower wavefront may still be reading from the call before — the readers of the buffer it writes passed the
+// previous call's barrier.  wsum2 = 2 x (kOctTMax / 64 + 1) ints.  Unlike block_excl_scan_rt this is NOT a barrier in front of the caller's
+// own earlier LDS writes being read by other threads — only behind them.
+__device__ __forceinline__ int block_excl_scan_db(int v, int* wsum2, int& par, int& total) {
+  const int nw = oct_threads() >> 6;
+  const int incl = wave_incl_scan(v);
+  const int w = threadIdx.x >> 6;
+  int* ws = wsum2 + par * (kOctTMax / 64 + 1);
+  par ^= 1;
+  if (lane_id() == 63) ws[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) { const int sv = ws[i]; if (i < w) base += sv; tot += sv; }
+  total = tot;
+  return base + incl - v;
+}
+
 // =============================================================================================
 // pyramid: cv::resize(prev, cur, sz, 0, 0, INTER_LINEAR) on 8UC1 with OpenCV's 11-bit fixed-point
 // coefficients (tables built on the host, orb.hip build_resize_tables).  4 output pixels / thread.
@@ -966,6 +984,12 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
 // response with the lowest candidate index (:757-776), resolved with one atomicMax per point.
 // =============================================================================================
 #define OCT_T (oct_threads())  /* threads of a quad-tree workgroup that take part (see oct_threads) */
+#ifdef DVS_QT_PROF   /* tools/qt_phase_profile.sh: 100 MHz time stamps of the level-0 tree of frame 0, phase by phase */
+__device__ unsigned long long g_qt_prof[96];
+#define QT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (i) < 96) g_qt_prof[i] = wall_clock64(); } while (0)
+#else
+#define QT_STAMP(i) do {} while (0)
+#endif
 struct QNode { int16_t ulx, uly, brx, bry; int32_t cnt; int32_t pt; };
 
 __device__ __forceinline__ int qt_quadrant(const QNode& nd, int x, int y) {
@@ -1037,8 +1061,9 @@ __device__ __forceinline__ int qt_mask(const int* childCnt, int k) {
 
 // After flag[]/posArr[] of split nodes are set (posArr = first child position) and T = number of new
 // children: place unsplit nodes behind the children in old order, write the new node array, re-point
-// the points.  Returns nothing; *pS updated by thread 0.
-__device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, uint32_t* pts, int* nodeOf, int n, int* wsum) {
+// the points.  Returns the number of unsplit nodes (the new list holds T + that many).
+// flag[k] / posArr[k] of a split node must be visible to the thread that owns k (k = tid, tid + OCT_T, ...) on entry.
+__device__ __forceinline__ int qt_rebuild(QtShared& sh, int cur, int S, int T, uint32_t* pts, int* nodeOf, int n, int* wsum2, int& par) {
   const QNode* old = sh.nodes_(cur);
   QNode* nw = sh.nodes_(cur ^ 1);
   // unsplit nodes: stable compaction behind the children block
@@ -1047,11 +1072,11 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
     const int k = b + threadIdx.x;
     const int u = (k < S && !sh.flag[k]) ? 1 : 0;
     int tot;
-    const int ex = block_excl_scan_rt(u, wsum, tot);
+    const int ex = block_excl_scan_db(u, wsum2, par, tot);
     if (u) sh.posArr[k] = -((T + carry + ex) + 1);
     carry += tot;
   }
-  __syncthreads();
+  // (no barrier: a thread reads flag / posArr of its own nodes only — the scan above and the caller's loops map k to threads alike)
   // per node: its successors in the new list, and the 8-byte record its points read below (the sort buffer is dead here):
   //   low word = split point; high word = first child's position | non-empty children << 16 | single-point children << 20 | 1 << 24
   //   (split node), or the node's own new position (unsplit)
@@ -1096,6 +1121,7 @@ __device__ __forceinline__ void qt_rebuild(QtShared& sh, int cur, int S, int T, 
     }
   }
   __syncthreads();
+  return carry;
 }
 
 // creation-ordered list of multi-point nodes among the T freshly created children (positions T-1..0)
@@ -1199,7 +1225,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   DVS_CHAIN_PRIO();
   __shared__ int wsum[kOctTMax / 64 + 1];
-  __shared__ int s_S, s_n, s_T, s_nexp, s_c;
+  __shared__ int wsum2[2 * (kOctTMax / 64 + 1)];   // block_excl_scan_db
+  int par = 0;
+  __shared__ int s_n, s_c;
   __shared__ SortShared s_sort;
   const int tid = threadIdx.x;
   // grid = (frames, levels): the linear workgroup id is frame + frames x level, so the level-0 workgroups — the long ones — are
@@ -1237,6 +1265,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
   const int* cc = cellCount + (uint64_t)f * g->totalCells + L.cellBase;
   int* co = cellOff + (uint64_t)f * g->totalCells + L.cellBase;
 
+  QT_STAMP(0);
   // ---- gather: candidate order = cells row-major, pixels row-major inside a cell -------------
   {
     // cell offsets also live in LDS while they fit (the child-count array is dead until the roots exist): the gather below then has
@@ -1295,9 +1324,11 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     }
     __syncthreads();
   }
+  QT_STAMP(1);
   const int n = s_n;
   const int N = L.N;
   int cur = 0;
+  int Scur = 0;   // length of the node list: uniform, kept in a register (every count below is a scan total all threads hold)
 
   // ---- roots (:559-601) ------------------------------------------------------------------------
   {
@@ -1344,7 +1375,7 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       }
       carry += tot;
     }
-    if (tid == 0) s_S = carry;
+    Scur = carry;   // (uniform: every thread holds the scan's total)
     __syncthreads();
     for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
       int r[4], pos[4], cnt[4];
@@ -1366,64 +1397,60 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     __syncthreads();
   }
   // ---- main loop ---------------------------------------------------------------------------------
+  // A sweep is a chain of short passes separated by workgroup barriers — ~14 of them in round 3's form, which were most of its time (the
+  // level-0 tree: ~180 barriers in 56 us).  Now 6: the scans take one barrier instead of two (block_excl_scan_db), one scan carries the
+  // children count AND the number of children to expand (packed 16 + 16 bits: both < 4 x 4096), the number of unsplit nodes is the total of
+  // the scan qt_rebuild runs anyway, list length and totals live in registers (they are scan totals: uniform), and a thread reads flag /
+  // posArr / ecum only of the nodes it wrote them for (k = tid, tid + OCT_T, ... in every loop).
+  QT_STAMP(2);
+  int qtp = 3;   // next stamp
   bool finish = (n == 0);
   while (!finish) {
-    const int S = s_S;
+    const int S = Scur;
     // full sweep: split every multi-point node (:622-681)
     qt_count_children(sh.nodes_(cur), S, sh.childCnt, (uint32_t*)sh.posArr, pts, nodeOf, n);
-    int nExpandLocal = 0;
+    QT_STAMP(qtp); qtp++;
+    int T, nToExpand;
     {
       // children block: node k's children sit in front of the children of all earlier nodes
-      int carry = 0;
+      int carry = 0;   // packed: children | children with more than one point << 16
       for (int b = 0; b < S; b += OCT_T) {
         const int k = b + tid;
-        int e = 0;
+        int e = 0, ne = 0;
         if (k < S) {
           const bool split = sh.nodes_(cur)[k].cnt > 1;
           sh.flag[k] = split ? 1 : 0;
           if (split) {
             e = __popc(qt_mask(sh.childCnt, k));
 #pragma unroll
-            for (int q = 0; q < 4; q++) nExpandLocal += sh.childCnt[4 * k + q] > 1 ? 1 : 0;
+            for (int q = 0; q < 4; q++) ne += sh.childCnt[4 * k + q] > 1 ? 1 : 0;
           }
         }
         int tot;
-        const int ex = block_excl_scan_rt(e, wsum, tot);
-        if (k < S) sh.ecum[k] = carry + ex + e;  // inclusive
+        const int ex = block_excl_scan_db(e | (ne << 16), wsum2, par, tot);
+        if (k < S) sh.ecum[k] = ((carry + ex) & 0xFFFF) + e;  // inclusive
         carry += tot;
       }
-      if (tid == 0) { s_T = carry; s_nexp = 0; }
-      __syncthreads();
-      const int T = s_T;
+      T = carry & 0xFFFF; nToExpand = carry >> 16;
       for (int k = tid; k < S; k += OCT_T)
         if (sh.flag[k]) sh.posArr[k] = T - sh.ecum[k];
-      if (nExpandLocal) atomicAdd(&s_nexp, nExpandLocal);
-      __syncthreads();
     }
-    const int T = s_T;
-    const int nToExpand = s_nexp;
-    int nUnsplit = 0;
-    {  // count unsplit nodes = S - (#split); derive from flags
-      int loc = 0;
-      for (int k = tid; k < S; k += OCT_T) loc += sh.flag[k] ? 0 : 1;
-      if (tid == 0) s_c = 0;
-      __syncthreads();
-      if (loc) atomicAdd(&s_c, loc);
-      __syncthreads();
-      nUnsplit = s_c;
-    }
-    qt_rebuild(sh, cur, S, T, pts, nodeOf, n, wsum);
+    QT_STAMP(qtp); qtp++;
+    const int nUnsplit = qt_rebuild(sh, cur, S, T, pts, nodeOf, n, wsum2, par);
+    QT_STAMP(qtp); qtp++;
     cur ^= 1;
-    int Snew = T + nUnsplit;
-    if (tid == 0) s_S = Snew;
-    __syncthreads();
+    const int Snew = T + nUnsplit;
+    Scur = Snew;
     if (Snew >= N || Snew == S) { finish = true; break; }
     if (Snew + nToExpand * 3 <= N) continue;
 
     // ordered phase (:692-753)
+    qtp = 40;
+    QT_STAMP(qtp); qtp++;
     int m = qt_build_expand_list(sh, cur, T, wsum);
     while (!finish) {
-      const int Sb = s_S;
+      QT_STAMP(qtp); qtp++;
+      const int Sb = Scur;
       if (m == 0) { finish = true; break; }  // nothing to split: size stays == prevSize
       qt_count_children(sh.nodes_(cur), Sb, sh.childCnt, (uint32_t*)sh.posArr, pts, nodeOf, n);
       for (int r = tid; r < m; r += OCT_T) {
@@ -1433,7 +1460,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
       }
       for (int k = tid; k < Sb; k += OCT_T) sh.flag[k] = 0;
       __syncthreads();
+      QT_STAMP(qtp); qtp++;
       qt_sort_block(sh.sortbuf, m, sh.ecum, sh.posArr, s_sort);  // ecum / posArr are dead until the sweep below
+      QT_STAMP(qtp); qtp++;
       // processing order r' = 0..m-1 walks the sorted vector from the back (:701)
       int carry = 0;
       if (tid == 0) s_c = 0;
@@ -1465,17 +1494,19 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
         sh.posArr[k] = Tm - sh.ecum[r];
       }
       __syncthreads();
-      qt_rebuild(sh, cur, Sb, Tm, pts, nodeOf, n, wsum);
+      QT_STAMP(qtp); qtp++;
+      (void)qt_rebuild(sh, cur, Sb, Tm, pts, nodeOf, n, wsum2, par);
+      QT_STAMP(qtp); qtp++;
       cur ^= 1;
       const int Sn = Tm + (Sb - M);
-      if (tid == 0) s_S = Sn;
-      __syncthreads();
+      Scur = Sn;
       if (Sn >= N || Sn == Sb) { finish = true; break; }
       m = qt_build_expand_list(sh, cur, Tm, wsum);
     }
   }
   // ---- best point per node (:757-776), list order = output order ----------------------------------
-  const int S = (n == 0) ? 0 : s_S;
+  QT_STAMP(90);
+  const int S = (n == 0) ? 0 : Scur;
   QNode* nodes = sh.nodes_(cur);
   int* best = sh.childCnt;
   for (int k = tid; k < S; k += OCT_T) best[k] = 0;
@@ -1497,6 +1528,10 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
     if (k < N + 4) outp[k] = pts[i];
   }
   if (tid == 0) lvlKpCount[f * g->nlevels + level] = min(S, N + 4);
+  QT_STAMP(91);
+#ifdef DVS_QT_PROF
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { g_qt_prof[92] = (unsigned long long)n; g_qt_prof[93] = (unsigned long long)S; g_qt_prof[94] = (unsigned long long)qtp; }
+#endif
 }
 
 #undef OCT_T
