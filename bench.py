@@ -335,6 +335,7 @@ def main():
     ap.add_argument("--quadtree-async", type=int, default=0, choices=(-1, 0, 1),
                     help="dvs_pipeline_params::quadtree_async: the four-stream form of the two-stream pipeline on (1) / off (-1) / by batch size (0)")
     ap.add_argument("--lanes", type=int, default=0, help="dvs_pipeline_params::lanes: 0 = by batch size, 1 = two-stream software pipeline, 2..4 = lane schedule")
+    ap.add_argument("--nsets", type=int, default=0, help="output sets of the pipeline in rotation (0 = the library's choice: 4, or two per lane)")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--serial-match", dest="pipelined", action="store_false",
                     help="match batch i in step i behind its own extraction on one stream.  Default: software-pipelined (dvslam_amd/pipeline.py) "
@@ -386,7 +387,7 @@ def main():
 
     # One pipeline per GPU (dvslam_amd/pipeline.py: the step that tests/test_gpu_pipeline.py checks against the oracle).  All its streams
     # are created by the library, back to back, BEFORE RCCL comes up.
-    pipe = StreamingPipeline(B, rows, cols, args.nfeatures, device=local, nsets=4 if args.lanes == 1 or B > 4 else 0, pipelined=args.pipelined,
+    pipe = StreamingPipeline(B, rows, cols, args.nfeatures, device=local, nsets=args.nsets, pipelined=args.pipelined,
                              lanes=args.lanes, quadtree_async=args.quadtree_async)
     orb, cap = pipe.orb, pipe.cap
     torch.cuda.synchronize()

@@ -1038,11 +1038,14 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
 
 extern "C" {
 
-static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, dvs_orb** out);
-dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, false, out); }
-dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, true, out); }
+static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, bool on_stream, hipStream_t ext, dvs_orb** out);
+dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, false, false, nullptr, out); }
+dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, true, false, nullptr, out); }
+dvs_status dvs_orb_create_on_stream(const dvs_orb_params* params, int32_t device, void* hip_stream, dvs_orb** out) {
+  return orb_create(params, device, true, true, (hipStream_t)hip_stream, out);
+}
 
-static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, dvs_orb** out) {
+static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, bool on_stream, hipStream_t ext, dvs_orb** out) {
   DVS_ARG(params && out);
   *out = nullptr;
   DVS_ARG(params->nlevels >= 1 && params->nlevels <= DVS_MAX_LEVELS);
@@ -1062,9 +1065,13 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   if (ksum > 257) { delete h; set_error("gauss_kernel sum %d would overflow the Q8.8 row buffer", ksum); return DVS_ERR_ARG; }
   h->device = device;
   h->max_batch = params->max_batch > 0 ? params->max_batch : 1;
-  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
-  h->stream = h->own_stream;
+  if (on_stream) {   // the caller's stream for good: no stream of its own is ever created
+    h->stream = ext;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
+    h->stream = h->own_stream;
+  }
   // The switches of this handle, read once (see the struct).  DVS_NO_OVERLAP=1 = dvs_orb_set_overlap(h, 0) from the start: every
   // stage alone on the main stream.
   h->single_stream = single_stream;
@@ -1176,6 +1183,7 @@ dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
 }
 dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
   DVS_ARG(h);
+  if (!h->own_stream) { set_error("dvs_orb_use_own_stream: this extractor was created on a caller's stream and has none of its own"); return DVS_ERR_UNSUPPORTED; }
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
   h->stream = h->own_stream;

@@ -143,6 +143,7 @@ def lib():
     L.dvs_pipeline_nsets.argtypes = [vp]
     L.dvs_pipeline_quadtree_async.argtypes = [vp]
     L.dvs_orb_create_single_stream.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
+    L.dvs_orb_create_on_stream.argtypes = [C.POINTER(OrbParams), i32, vp, C.POINTER(vp)]
     L.dvs_pipeline_extractor.argtypes = [vp]; L.dvs_pipeline_extractor.restype = vp
     L.dvs_pipeline_matcher.argtypes = [vp]; L.dvs_pipeline_matcher.restype = vp
     L.dvs_pipeline_match_stream.argtypes = [vp]; L.dvs_pipeline_match_stream.restype = vp

@@ -8,7 +8,7 @@ rotate (>= 3 when pipelined — refused by dvs_pipeline_create otherwise).  With
 ranks) the frame before this rank's first frame comes from `dvs_exchange_boundary`.  `pipelined=False` is the
 plain schedule: every batch's match behind its own extraction on one stream.  `lanes`: 0 = by batch size, 1 = the two-stream software
 pipeline, 2..4 = the small-batch lane schedule (whole steps in flight on independent extractor / matcher pairs).  `quadtree_async`:
-1 / -1 / 0 = the four-stream form of the two-stream pipeline on / off / by batch size (5..24 frames per step).
+1 / -1 / 0 = the four-stream form of the two-stream pipeline on / off / by batch size (7..24 frames per step).
 
 Pure ctypes: no torch in here."""
 import ctypes as C

@@ -97,6 +97,9 @@ dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb*
  * created (every HIP stream is a hardware queue, and a process has four) and dvs_orb_set_overlap(h, 1) is refused.  What the lanes of
  * dvs_pipeline are made of; results are identical. */
 dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out);
+/* ... and a single-stream extractor on a stream the CALLER owns (NULL: HIP's legacy default stream) — it never creates one of its own;
+ * dvs_orb_use_own_stream is refused.  dvs_pipeline's fourth lane lives on a stream of another dispatch priority this way. */
+dvs_status dvs_orb_create_on_stream(const dvs_orb_params* params, int32_t device, void* hip_stream, dvs_orb** out);
 void dvs_orb_destroy(dvs_orb* h);
 /* capacity a caller must provide per frame: nfeatures + 3 * nlevels (a level may return quota + 2, ORBextractor.cpp:746-747) */
 int32_t dvs_orb_max_keypoints(const dvs_orb* h);
@@ -286,16 +289,17 @@ typedef struct dvs_pipeline_params {
   int32_t rows, cols;
   int32_t nsets;        /* output sets in rotation; 0 = 4 (lane schedule: two per lane); lanes are reduced to a divisor of nsets */
   int32_t pipelined;    /* 1: the software pipeline described above; 0: serial match */
-  int32_t lanes;        /* pipelined only.  0 = by batch size (3 up to DVS_PIPELINE_LANE_BATCH frames, else 1); 1 = the two-stream
-                           software pipeline; 2..DVS_PIPELINE_MAX_LANES = lanes */
+  int32_t lanes;        /* pipelined only.  0 = by batch size (DVS_PIPELINE_MAX_LANES up to DVS_PIPELINE_LANE_BATCH frames, else 1); 1 = the
+                           two-stream software pipeline; 2..DVS_PIPELINE_MAX_LANES = lanes.  The fourth lane's stream has the highest dispatch
+                           priority: streams of one priority share four hardware queues with the process's default stream */
   int32_t quadtree_async; /* two-stream pipeline only.  1: the four-stream form — quad-tree on the extractor's auxiliary stream beside the next
                            step's FAST (dvs_orb_set_async_quadtree), descriptor stage on the match stream (dvs_orb_set_tail_stream), blur on the
                            main stream ahead of FAST; -1: off; 0 = by batch size (on for DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH:
                            measured +21 % at 8 frames per step, +13 % at 16, +3.5 % at 24, a tie at 28..32, -4 % at 64: profiles/r04_batch_sweep.json) */
 } dvs_pipeline_params;
 #define DVS_PIPELINE_ASYNC_BATCH 24
-#define DVS_PIPELINE_MAX_LANES 4     /* HIP streams beyond four share hardware queues on this part */
-#define DVS_PIPELINE_LANE_BATCH 4    /* lanes = 0: batches up to this size run on lanes (measured: 8 frames and more tie or lose) */
+#define DVS_PIPELINE_MAX_LANES 4     /* four hardware queues run at a time on this part: a fifth lane collapses all of them (EXPERIMENTS.md) */
+#define DVS_PIPELINE_LANE_BATCH 6    /* lanes = 0: batches up to this size run on lanes (four lanes against the four-stream form: +16 % at 5 frames, +14 % at 6, a tie at 7, -5 % at 8) */
 /* results of one step's batch (device pointers into the handle's output set; valid until step + nsets is enqueued) */
 typedef struct dvs_pipeline_set {
   const dvs_keypoint* d_kps;  /* [B][capacity] */

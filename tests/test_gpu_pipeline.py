@@ -96,7 +96,7 @@ def test_lane_schedule_for_small_batches(gpu, oracle, B, lanes, nsets, steps):
     order by events only — every resident frame and match job against the oracle, at 1280x720 / 2000 like the timed configuration;
     (8, 1): the two-stream software pipeline forced at a lane-sized batch"""
     p = _run_shape(oracle, B, 720, 1280, 2000, nsets, steps, lanes=lanes)
-    assert p == (lanes or 3)                                              # lanes = 0: three lanes (and six sets) up to 4 frames per step
+    assert p == (lanes or 4)                                              # lanes = 0: four lanes (and eight sets) up to 4 frames per step
 
 
 @pytest.mark.parametrize("B,rows,cols,nf,nsets,steps", [(8, 720, 1280, 2000, 4, 7), (12, 480, 640, 800, 3, 7), (40, 360, 1000, 700, 4, 6), (7, 250, 332, 200, 3, 6)])
@@ -126,11 +126,11 @@ def test_level_chain_as_graph_launch(gpu, oracle, monkeypatch, B, rows, cols, nf
     assert graphs == [0]
 
 
-def test_four_stream_is_the_default_from_5_to_24_frames(gpu, oracle):
-    """DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH (4, 24): lanes below, the two-stream pipeline above; one default shape
+def test_four_stream_is_the_default_from_7_to_24_frames(gpu, oracle):
+    """DVS_PIPELINE_LANE_BATCH < batch <= DVS_PIPELINE_ASYNC_BATCH (6, 24): lanes below, the two-stream pipeline above; one default shape
     in the upper half of the range against the oracle (rings of four sets: 9 steps go round twice)"""
     from dvslam_amd.pipeline import StreamingPipeline
-    for B, want_lanes, want_async in [(4, 3, False), (5, 1, True), (24, 1, True), (25, 1, False)]:
+    for B, want_lanes, want_async in [(4, 4, False), (6, 4, False), (7, 1, True), (24, 1, True), (25, 1, False)]:
         pipe = StreamingPipeline(B, 240, 320, 300, nsets=0)
         assert (pipe.lanes, pipe.quadtree_async) == (want_lanes, want_async), B
         pipe.close()
