@@ -769,7 +769,10 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
       DVS_HIP(hipGraphLaunch(cg->exec, h->pf_stream));
       h->chain_graph_launches++;
     } else {           // first time: plain launches, remember the argument set
-      if (h->chain_graphs.size() >= 48) drop_chain_graphs(h);   // a caller whose buffers never come back: stay bounded
+      if (h->chain_graphs.size() >= 48) {   // a caller whose buffers never come back: stay bounded (rare: let launched graphs finish first)
+        DVS_HIP(hipStreamSynchronize(h->pf_stream));
+        drop_chain_graphs(h);
+      }
       h->chain_graphs.push_back({next_img0, src.step0, src.fstride0, nimg, h->d_pyr_alt, nullptr, nullptr});
       DVS_TRY(launch_pyramid_chain(h, nsrc, nimg, h->d_pyr_alt, h->pf_stream, false));
     }

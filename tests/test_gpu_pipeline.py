@@ -137,6 +137,31 @@ def test_four_stream_is_the_default_from_7_to_24_frames(gpu, oracle):
     _run_shape(oracle, 18, 480, 640, 700, 4, 9)
 
 
+def test_level_chain_graph_cache_stays_bounded(gpu, oracle):
+    """a caller streaming from more buffers than the graph cache holds (17 blocks x 4 pyramids > 48 argument sets): the cache is dropped
+    and refilled on the way, the results stay the oracle's"""
+    from dvslam_amd import _lib
+    from dvslam_amd.pipeline import StreamingPipeline
+    B, rows, cols, nf, NB, steps = 7, 240, 320, 300, 17, 150
+    frames = [np.stack([synth.make_frame(3 * g + i, cols, rows, seed=5 + g) for i in range(B)]) for g in range(NB)]
+    d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=4, pipelined=True)
+    assert pipe.quadtree_async
+    # 45 steps over 5 blocks (20 argument sets: graphs from the second round on), then all 17 (the 49th set drops the cache; with 68 sets
+    # in rotation none comes back before the next drop: plain launches from there on)
+    order = [i % 5 for i in range(45)] + [i % NB for i in range(steps - 45)]
+    for i in range(steps):
+        pipe.step(d_img[order[i]].ptr, d_img[order[i + 1]].ptr if i + 1 < steps else 0)
+    pipe.flush(); pipe.synchronize()
+    assert 15 <= _lib.lib().dvs_orb_chain_graph_launches(pipe.orb._h) <= 45
+    o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
+    for i in range(steps - 3, steps):
+        n, k, d = pipe.outputs(i)
+        for f in (0, B - 1):
+            _assert_frame((n[f], k[f], d[f]), o.extract(frames[order[i]][f]), f"step {i} frame {f}")
+    pipe.close()
+
+
 def _lib_mod():
     from dvslam_amd import _lib
     return _lib
