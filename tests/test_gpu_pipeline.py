@@ -236,7 +236,7 @@ def test_frame_sharded_loopback_equals_single_rank(gpu, oracle):
     want = [(one.outputs(i), one.matches(i)) for i in range(STEPS)]
     one.close()
     d_rank = [[_lib.DeviceBuffer(gb[g][r * B:(r + 1) * B].nbytes).upload(gb[g][r * B:(r + 1) * B]) for g in range(NG)] for r in range(WORLD)]
-    for lanes in (1, 2):    # the two-stream software pipeline per rank; the lane schedule (strong-scaling form: 8 frames per rank), whose
+    for lanes in (1, 2, 4):    # the two-stream software pipeline per rank; the lane schedule (4: with the priority-stream lane) (strong-scaling form: 8 frames per rank), whose
         _loopback_ranks(oracle, want, d_rank, WORLD, B, NG, STEPS, lanes)    # successive exchanges run on different streams
 
 
