@@ -123,6 +123,99 @@ __global__ __launch_bounds__(64 * kSplit) void k_match(const u64* __restrict__ q
   }
 }
 
+// The FEW-jobs match with the train set staged in LDS and 16 queries per workgroup.  k_match<16, 1> gives one 2000 x 2000 job 32
+// workgroups of 16 wavefronts — 32 of 256 CUs, each wavefront walking 125 train rows through scalar loads one trip ahead: 18.5 us per
+// launch whatever the job count up to 8 (tools/time_match_few.py).  Here a workgroup takes 16 queries: its 1024 threads copy the job's
+// train set (<= ldsRows x 32 bytes: one coalesced round trip) into LDS, lane = (query, quarter): the 64 (wavefront, quarter) pairs each
+// scan 1/64 of the rows for their query, the four quarters fold by two shuffles, the sixteen wavefronts through LDS.  The running best
+// is ONE word — distance << 23 | train index — so every fold is an unsigned minimum: smallest distance, lowest index on ties, in any order.
+// 125 workgroups per job.  A job whose train set does not fit (nt > ldsRows: the trusted predecessor block of a sequence) reads global memory.
+constexpr int kLdsQ = 16;   // queries per workgroup
+__global__ __launch_bounds__(1024) void k_match_lds(const u64* __restrict__ q, const int* __restrict__ nqArr, int nqConst, int qStrideRows,
+                                                    const u64* __restrict__ t, const int* __restrict__ ntArr, int ntConst, int tStrideRows,
+                                                    int* __restrict__ outIdx, int* __restrict__ outDist, int ldsRows,
+                                                    const u64* __restrict__ t0 = nullptr, const int* __restrict__ nt0 = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) u64 trows[];
+  __shared__ unsigned sp[16][kLdsQ];
+  const int pair = blockIdx.y;
+  const int nq = nqArr ? min(nqArr[pair], qStrideRows) : nqConst;
+  const bool first = pair == 0 && t0 != nullptr;
+  const int nt = first ? *nt0 : (ntArr ? min(ntArr[pair], tStrideRows > 0 ? tStrideRows : ntArr[pair]) : ntConst);
+  const int q0 = blockIdx.x * kLdsQ;
+  if (q0 >= nq) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ql = lane & (kLdsQ - 1), quarter = lane >> 4;
+  const u64* tp = first ? t0 : t + (ptrdiff_t)pair * tStrideRows * 4;
+  const bool staged = nt <= ldsRows;
+  if (staged) {   // 16 bytes per thread and trip (descriptor rows are 32-byte aligned)
+    const uint4* src = reinterpret_cast<const uint4*>(tp);
+    uint4* dst = reinterpret_cast<uint4*>(trows);
+    for (int i = threadIdx.x; i < 2 * nt; i += 1024) dst[i] = src[i];
+  }
+  const int qi = q0 + ql;
+  const u64* qp = q + ((size_t)pair * qStrideRows + (qi < nq ? qi : q0)) * 4;
+  const u64 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  __syncthreads();
+  const int slice = w * 4 + quarter;            // 64 slices of the train set
+  const int chunk = (nt + 63) / 64;
+  const int jb = min(nt, slice * chunk), je = min(nt, jb + chunk);
+  unsigned bestp = 0xFFFFFFFFu;
+  auto dist = [&](u64 r0, u64 r1, u64 r2, u64 r3) -> unsigned {
+    return (unsigned)(__popcll(a0 ^ r0) + __popcll(a1 ^ r1) + __popcll(a2 ^ r2) + __popcll(a3 ^ r3));
+  };
+  const u64* rows = staged ? trows : tp;
+  if (staged) {
+    int j = jb;
+    for (; j + 4 <= je; j += 4) {   // four rows' reads in flight
+      const ulonglong2* r = reinterpret_cast<const ulonglong2*>(trows + (size_t)j * 4);
+      ulonglong2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = r[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) bestp = min(bestp, (dist(v[2 * k].x, v[2 * k].y, v[2 * k + 1].x, v[2 * k + 1].y) << 23) | (unsigned)(j + k));
+    }
+    for (; j < je; j++) {
+      const u64* r = trows + (size_t)j * 4;
+      bestp = min(bestp, (dist(r[0], r[1], r[2], r[3]) << 23) | (unsigned)j);
+    }
+  } else {
+    for (int j = jb; j < je; j++) {
+      const u64* r = rows + (size_t)j * 4;
+      bestp = min(bestp, (dist(r[0], r[1], r[2], r[3]) << 23) | (unsigned)j);
+    }
+  }
+  bestp = min(bestp, (unsigned)__shfl_xor((int)bestp, 16));
+  bestp = min(bestp, (unsigned)__shfl_xor((int)bestp, 32));
+  if (quarter == 0) sp[w][ql] = bestp;
+  __syncthreads();
+  if (w == 0 && quarter == 0 && qi < nq) {
+    unsigned b = sp[0][ql];
+#pragma unroll
+    for (int k = 1; k < 16; k++) b = min(b, sp[k][ql]);
+    outIdx[(size_t)pair * qStrideRows + qi] = b == 0xFFFFFFFFu ? -1 : (int)(b & 0x7FFFFFu);
+    outDist[(size_t)pair * qStrideRows + qi] = b == 0xFFFFFFFFu ? INT_MAX : (int)(b >> 23);
+  }
+}
+
+// enqueue the few-jobs match: train sets of up to 4096 rows are staged in LDS (k_match_lds), larger strides take k_match<16, 1>
+static inline void launch_match_few(hipStream_t st, dim3 grid, const u64* q, const int* nqArr, int nqConst, int qStrideRows, const u64* t,
+                                    const int* ntArr, int ntConst, int tStrideRows, int* outIdx, int* outDist, int trainRows,
+                                    const u64* t0 = nullptr, const int* nt0 = nullptr) {
+  static const bool lds_on = !(getenv("DVS_MATCH_LDS") && getenv("DVS_MATCH_LDS")[0] == '0');
+  // up to 6 jobs (what a lane of dvs_pipeline enqueues, and the single-call entry point): one 2000 x 2000 job 18.3 -> 7.7 us per launch, two
+  // 18.5 -> 8.1, four 18.8 -> 13.1, six 18.7 -> 19.5 alone but +8 % in the six-frame lane step (no scalar-load chain beside the other lanes'
+  // kernels); 7 and 8 jobs (the four-stream form's match stream) lose 3-7 %: k_match<16, 1> there.  DVS_MATCH_LDS=0: never.
+  if (lds_on && grid.y <= 6 && trainRows > 0 && trainRows <= 4096 && (((uintptr_t)t | (uintptr_t)t0) & 15) == 0) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_match_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32); attr = true; }
+    const dim3 g16((grid.x * 64 + kLdsQ - 1) / kLdsQ, grid.y);   // (the callers' grids count 64 queries per workgroup)
+    hipLaunchKernelGGL(k_match_lds, g16, dim3(1024), (size_t)trainRows * 32, st, q, nqArr, nqConst, qStrideRows, t, ntArr, ntConst, tStrideRows, outIdx,
+                       outDist, trainRows, t0, nt0);
+  } else {
+    hipLaunchKernelGGL((k_match<16, 1>), grid, dim3(1024), 0, st, q, nqArr, nqConst, qStrideRows, t, ntArr, ntConst, tStrideRows, outIdx, outDist, t0, nt0);
+  }
+}
+
 // =============================================================================================================================
 // Matrix-core variant for batches of large jobs.  Hamming distance as an exact integer contraction:
 // with every descriptor bit b encoded as the byte e(b) = +8 / -8,   sum_k e(q_k) e(t_k) = 64 (256 - 2 dist(q, t)),
@@ -538,8 +631,8 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   DVS_HIP(hipSetDevice(m->device));
   const bool few = (long long)npairs * q_stride_rows <= 16384;  // a few jobs: favour wavefront count over per-wave efficiency
   if (few) {
-    hipLaunchKernelGGL((k_match<16, 1>), dim3((q_stride_rows + 63) / 64, npairs), dim3(1024), 0, m->stream, (const u64*)d_q, d_nq, 0, q_stride_rows,
-                       (const u64*)d_t, d_nt, 0, t_stride_rows, d_idx, d_dist);
+    launch_match_few(m->stream, dim3((q_stride_rows + 63) / 64, npairs), (const u64*)d_q, d_nq, 0, q_stride_rows, (const u64*)d_t, d_nt, 0, t_stride_rows,
+                     d_idx, d_dist, t_stride_rows);
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }
@@ -585,8 +678,8 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
   // one 2000 x 2000 job on <8, 2> occupies 16 workgroups for 39 us
   // train of job p >= 1 = frame p - 1: the base pointers are shifted back by one frame and never dereferenced for job 0
   if ((long long)nframes * stride_rows <= 16384)
-    hipLaunchKernelGGL((k_match<16, 1>), dim3((stride_rows + 63) / 64, nframes), dim3(1024), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
-                       (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
+    launch_match_few(m->stream, dim3((stride_rows + 63) / 64, nframes), (const u64*)d_desc, d_n, 0, stride_rows,
+                     (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, stride_rows, (const u64*)d_prev_desc, d_prev_n);
   else   // DVS_MATCH_MFMA=0 with many jobs: the throughput shape
     hipLaunchKernelGGL((k_match<8, 2>), dim3((stride_rows + 127) / 128, nframes), dim3(512), 0, m->stream, (const u64*)d_desc, d_n, 0, stride_rows,
                        (const u64*)(d_desc - (size_t)stride_rows * 32), d_n - 1, 0, stride_rows, d_idx, d_dist, (const u64*)d_prev_desc, d_prev_n);
@@ -620,8 +713,8 @@ dvs_status dvs_match_hamming(dvs_matcher* m, const uint8_t* q, int32_t nq, const
     if (nt) DVS_HIP(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
   }
   if (nq <= 16384)
-    hipLaunchKernelGGL((k_match<16, 1>), dim3((nq + 63) / 64, 1), dim3(1024), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
-                     (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);
+    launch_match_few(m->stream, dim3((nq + 63) / 64, 1), (const u64*)m->d_q, (const int*)nullptr, nq, nq, (const u64*)m->d_t, (const int*)nullptr, nt, nt,
+                     d_idx, d_dist, nt);
   else
     hipLaunchKernelGGL((k_match<8, 2>), dim3((nq + 127) / 128, 1), dim3(512), 0, m->stream, (const u64*)m->d_q, (const int*)nullptr, nq, nq,
                      (const u64*)m->d_t, (const int*)nullptr, nt, nt, d_idx, d_dist);

@@ -106,6 +106,28 @@ def test_sequence_device(gpu, oracle):
             assert (idx[p, :n[p]] == i2).all() and (d[p, :n[p]] == d2).all(), (with_prev, p)
 
 
+def test_sequence_device_predecessor_larger_than_the_stride(gpu, oracle):
+    """k_match_lds stages a job's train set in LDS sized by the declared row stride; the predecessor block of a sequence has no declared
+    size — one with more rows than the stride is read from global memory instead (job 0 only), tie-heavy sets throughout"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    F, S, NP = 3, 256, 450
+    n = np.array([256, 200, 255], np.int32)
+    D = np.stack([_tie_heavy(S, 170 + p) for p in range(F)])
+    prev = _tie_heavy(NP, 199); nprev = np.array([NP], np.int32)
+    dd = DeviceBuffer(D.nbytes).upload(D); dn = DeviceBuffer(F * 4).upload(n)
+    dp = DeviceBuffer(prev.nbytes).upload(prev); dnp = DeviceBuffer(4).upload(nprev)
+    di = DeviceBuffer(F * S * 4); dx = DeviceBuffer(F * S * 4)
+    m.match_sequence_device(dd.ptr, dn.ptr, S, F, dp.ptr, dnp.ptr, di.ptr, dx.ptr)
+    m.synchronize()
+    idx = di.download(np.int32, F * S).reshape(F, S); d = dx.download(np.int32, F * S).reshape(F, S)
+    for p in range(F):
+        t = prev if p == 0 else D[p - 1, :n[p - 1]]
+        i2, d2 = oracle.match(D[p, :n[p]], t)
+        assert (idx[p, :n[p]] == i2).all() and (d[p, :n[p]] == d2).all(), p
+
+
 def _tie_heavy(n, seed, distinct=37):
     """descriptors drawn from a small pool (+ a few flipped bits): many exact ties between train rows, so the lowest-index rule
     decides most matches"""
