@@ -75,6 +75,7 @@ struct dvs_orb {
   // cannot be shorter than that chain of stages: at 8 frames 264 us / 3 = 88 us per step with three buffers, 66 with four (EXPERIMENTS.md).
   int ring = 3;
   int async_run = 0;               // consecutive asynchronous (prefetched + deferred) calls so far
+  int env_fuse_blur = 1;           // DVS_FUSE_BLUR=0: a single-stream handle launches quad-trees and blur one after the other
   int env_ring = 4;                // DVS_RING=3: keep three in the four-stream form
   // deferred descriptor stage (dvs_orb_set_output_event + dvs_orb_set_defer_outputs): ordered on the auxiliary stream only
   hipEvent_t ev_outs[3] = {nullptr, nullptr, nullptr};   // completion of the last ring - 1 deferred stages (ev_out = the latest)
@@ -629,6 +630,7 @@ dvs_status ensure_workspace(dvs_orb* h, int rows, int cols) {
   }
   h->octree_smem = (size_t)h->octree_nmax * (2 * sizeof(QNode) + 8 + 16 + 4 * 4) + (size_t)h->octree_ptscap * 8;
   DVS_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
+  DVS_HIP(hipFuncSetAttribute((const void*)k_octree_blur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octree_smem));
   h->d_cand2[0] = h->d_cand; h->d_cellcount2[0] = h->d_cellcount; h->cset = 0;
   h->d_blur3[0] = h->d_blur; h->bset = 0;
   {
@@ -786,12 +788,18 @@ dvs_status launch_prefetch(dvs_orb* h, const ImgSrc& src, int nimg, const u8* ne
 }
 
 // 7x7 fixed-point Gaussian of every level (ORBextractor.cpp:1132-1133)
-void launch_blur(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t bst, bool cascade) {
+// streaming blur kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
+// k_resize4 / k_pyr_cascade (which also write the reflected border columns); anything else takes the generic tile kernel
+bool blur_stream_ok(const dvs_orb* h, const ImgSrc& src, bool cascade) {
   const Geom& G = h->geom;
-  // streaming kernel: dword-aligned level-0 rows of width % 4 == 0 (border by byte permutes) and levels >= 1 written by
-  // k_resize4 (which also writes the reflected border columns); anything else takes the generic tile kernel
   bool stream_ok = (((uintptr_t)src.img0) | src.step0 | src.fstride0) % 4 == 0 && G.lv[0].w % 4 == 0;
   for (int l = 1; l < G.nlevels; l++) stream_ok = stream_ok && (cascade || G.lv[l].gtab >= 0);
+  return stream_ok;
+}
+
+void launch_blur(dvs_orb* h, const ImgSrc& src, int nimg, hipStream_t bst, bool cascade) {
+  const Geom& G = h->geom;
+  const bool stream_ok = blur_stream_ok(h, src, cascade);
   // matrix-core blur: 16-byte aligned rows (the pyramid block always is; a caller's level 0 when its pointer and strides are)
   const bool mfma_ok = h->env_blur_mfma && h->blur_mfma_ok && stream_ok &&
                        (((uintptr_t)src.img0 | src.step0 | src.fstride0) % 16 == 0) && src.step0 >= 16;
@@ -975,8 +983,20 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   //    stream needs it, so the next call's FAST follows this one's immediately and the tree runs beside it.
   hipStream_t qs = async ? bst : st;
   if (async) DVS_HIP(hipStreamWaitEvent(bst, ev_fastdone, 0));
+  // a lane (one stream, a few frames): quad-trees and streaming blur in one launch (k_octree_blur) — the blur then runs beside the trees
+  // instead of behind them (the lane's chain: -13 us of ~140 at one frame)
+  const int blurRows = (G.blurStrips + kOctTMax / 64 - 1) / (kOctTMax / 64);
+  const bool fuse_blur = h->single_stream && h->env_fuse_blur && !async && !sharded && !(h->env_blur_mfma && h->blur_mfma_ok) &&
+                         blur_stream_ok(h, src, cascade) && (long)nimg * (G.nlevels + blurRows) <= 256;
   h->timer.begin(DVS_STAGE_OCTREE, qs);
-  launch_octree(h, nimg, qs, src.levelMask, async && G.nlevels * nimg > 256);
+  if (fuse_blur) {
+    if (h->guard_event) { DVS_HIP(hipStreamWaitEvent(qs, h->guard_event, 0)); h->guard_event = nullptr; }   // (the blur's place below takes it otherwise)
+    hipLaunchKernelGGL(k_octree_blur, dim3(nimg, G.nlevels + blurRows), dim3(kOctTMax), h->octree_smem, qs, h->d_geom, h->d_cand, h->d_cellcount,
+                       h->d_celloff, h->d_pts, h->d_nodeof, h->d_candtotal, h->d_lvlkp, h->d_lvlcount, h->octree_nmax, h->octree_ptscap, src.levelMask,
+                       G.nlevels, h->d_strips, G.blurStrips, src, h->d_blur);
+  } else {
+    launch_octree(h, nimg, qs, src.levelMask, async && G.nlevels * nimg > 256);
+  }
   h->timer.end(qs);
   if (async) { DVS_HIP(hipEventRecord(h->ev_octdone[h->cset], qs)); h->octdone_valid[h->cset] = true; }
 
@@ -986,7 +1006,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   else if (h->guard_event) DVS_HIP(hipStreamWaitEvent(st, h->guard_event, 0));
   hipEvent_t late_guard = bst != st ? h->guard_event : nullptr;   // still set only for a deferring call (see above)
   h->guard_event = nullptr;   // one-shot
-  if (!tail) {
+  if (!tail && !fuse_blur) {
     h->timer.begin(DVS_STAGE_BLUR, bst);
     launch_blur(h, src, nimg, bst, cascade);
     h->timer.end(bst);
@@ -1082,6 +1102,7 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->env_cascade = env_int("DVS_CASCADE", -1);
   h->env_chain_graph = env_int("DVS_CHAIN_GRAPH", -1);
   h->env_ring = env_int("DVS_RING", 4);
+  h->env_fuse_blur = env_int("DVS_FUSE_BLUR", 1);
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
   h->env_oct_threads = env_int("DVS_OCT_T", 0);

@@ -1217,11 +1217,11 @@ __global__ __launch_bounds__(kOctTMax) void k_test_sort(unsigned long long* __re
 }
 #endif
 
-__global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
-                                                const int* __restrict__ cellCount, int* __restrict__ cellOff,
-                                                uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
-                                                int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
-                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int level0) {
+__device__ __forceinline__ void octree_body(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
+                                            const int* __restrict__ cellCount, int* __restrict__ cellOff,
+                                            uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
+                                            int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
+                                            int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int level0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   DVS_CHAIN_PRIO();
   __shared__ int wsum[kOctTMax / 64 + 1];
@@ -1534,6 +1534,14 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
 #endif
 }
 
+__global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
+                                                const int* __restrict__ cellCount, int* __restrict__ cellOff,
+                                                uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
+                                                int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
+                                                int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int level0) {
+  octree_body(g, cand, cellCount, cellOff, ptsAll, nodeOfAll, candTotal, lvlKp, lvlKpCount, nmax, ptsLdsCap, levelMask, level0);
+}
+
 #undef OCT_T
 // =============================================================================================
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101 on the level itself — OpenCV's 8-bit fixed-point path:
@@ -1598,14 +1606,13 @@ __device__ __forceinline__ uint32_t blur_word_reflect(const u8* row, int xw, int
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g, const BlurStrip* __restrict__ strips, int nstrips,
-                                                     ImgSrc src, u8* __restrict__ blur) {
-  const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: strip geometry in SGPRs
+// one wavefront = one strip `wi` of frame `f` (no LDS, no workgroup barrier: k_octree_blur runs it in workgroups beside the quad-trees')
+__device__ __forceinline__ void blur_stream_wave(const Geom* __restrict__ g, const BlurStrip* __restrict__ strips, int nstrips,
+                                                 const ImgSrc& src, u8* __restrict__ blur, int wi, int f) {
   if (wi >= nstrips) return;
   const BlurStrip s = strips[wi];
   if (!((src.levelMask >> s.level) & 1u)) return;
   const int lane = lane_id();
-  const int f = blockIdx.y;
   const LevelGeom& L = g->lv[s.level];
   int pitch;
   const u8* img = level_ptr(g, src, f, s.level, pitch);
@@ -1713,6 +1720,29 @@ __global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g,
 #pragma unroll
     for (int kk = 0; kk < 7; kk++) cur[kk] = nxt[kk];
   }
+}
+
+__global__ __launch_bounds__(256) void k_blur_stream(const Geom* __restrict__ g, const BlurStrip* __restrict__ strips, int nstrips,
+                                                     ImgSrc src, u8* __restrict__ blur) {
+  // wave-uniform strip index: strip geometry in SGPRs
+  blur_stream_wave(g, strips, nstrips, src, blur, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), blockIdx.y);
+}
+
+// Quad-trees and the streaming blur in ONE launch, for a lane of dvs_pipeline (one stream, a few frames): there the blur (9 us for one
+// frame) waits behind the latency-bound trees (54 us) although neither needs the other.  Grid (frames, levels + blur rows): rows
+// [0, treeLevels) are the trees' workgroups, the others run eight blur strips each — one per wavefront, no LDS, no barrier.
+__global__ __launch_bounds__(kOctTMax) void k_octree_blur(const Geom* __restrict__ g, const uint32_t* __restrict__ cand,
+                                                     const int* __restrict__ cellCount, int* __restrict__ cellOff,
+                                                     uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
+                                                     int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
+                                                     int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int treeLevels,
+                                                     const BlurStrip* __restrict__ strips, int nstrips, ImgSrc src, u8* __restrict__ blur) {
+  if ((int)blockIdx.y >= treeLevels) {
+    const int wpb = (int)blockDim.x >> 6;
+    blur_stream_wave(g, strips, nstrips, src, blur, ((int)blockIdx.y - treeLevels) * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), blockIdx.x);
+    return;
+  }
+  octree_body(g, cand, cellCount, cellOff, ptsAll, nodeOfAll, candTotal, lvlKp, lvlKpCount, nmax, ptsLdsCap, levelMask, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
