@@ -409,9 +409,14 @@ def main():
         print(f"[bench] rank {rank}: RCCL communicator of {world} ranks (version {comm.rccl_version})", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
 
+    diag_no_match = os.environ.get("BENCH_DIAG_NO_MATCH") == "1"   # diagnostics only: the step without its match (the line says so)
+
     def step():
         i = pipe.i
-        pipe.step(img[i % NB], img[(i + 1) % NB])
+        if diag_no_match:
+            pipe.step(img[i % NB], img[(i + 1) % NB], match=False)
+        else:
+            pipe.step(img[i % NB], img[(i + 1) % NB])
 
     def barrier():
         pipe.synchronize()
@@ -566,6 +571,9 @@ def main():
             "rccl": rccl, "match_check": match_check,
             "oracle_check": ocheck,
         }
+        if diag_no_match:
+            out["diagnostic"] = "BENCH_DIAG_NO_MATCH=1: the match was NOT enqueued in the timed region — not a result, a diagnostic"
+            out["metric"] = "DIAGNOSTIC (extraction only) " + out["metric"]
         if world == 1 and not args.no_cpu_baseline:
             cb_frames = [synth.make_frame(t, cols, rows) for t in range(min(48, 64))]
             out["cpu_baseline"] = cpu_baseline(cb_frames, args.nfeatures)

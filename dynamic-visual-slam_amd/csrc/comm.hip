@@ -7,6 +7,7 @@
 // RCCL is resolved with dlopen at first use: single-GPU callers never need librccl, and a process that already
 // carries an RCCL (PyTorch bundles one under the same SONAME librccl.so.1) shares that copy instead of loading a second.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <chrono>
@@ -108,6 +109,12 @@ struct dvs_comm {
   int device = 0, rank = 0, world = 1;
   NcclComm comm = nullptr;
   LoopGroup* loop = nullptr;   // loopback communicator: no RCCL
+  // host-transport communicator (dvs_comm_create_host): blocks and gather buffers live in HOST memory, the all-gather is the caller's
+  // callback (MPI_Allgather, a torch.distributed group, sockets).  No device is touched: the rank logic of dvs_exchange_boundary —
+  // buffer rotation, slot of this rank, predecessor selection with the wrap-around to the previous call — is the same code for every
+  // transport, and this one lets two OS processes without a GPU run it (tests/test_adapters_and_dist.py)
+  dvs_host_all_gather_fn host_gather = nullptr;
+  void* host_user = nullptr;
   uint8_t* gather[3] = {nullptr, nullptr, nullptr};  // [world][block] x 3: a call's result points into this call's and the previous
                                                      // call's buffer, and stays valid while the next call gathers into the third
   long calls = 0;
@@ -154,6 +161,11 @@ dvs_status loop_all_gather(dvs_comm* c, const void* send, void* recv, size_t byt
 }
 
 dvs_status comm_all_gather(dvs_comm* c, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  if (c->host_gather) {
+    const int r = c->host_gather(c->host_user, send, recv, bytes);
+    if (r != 0) { set_error("host all-gather callback failed with %d (rank %d of %d)", r, c->rank, c->world); return DVS_ERR_HIP; }
+    return DVS_OK;
+  }
   if (c->loop) return loop_all_gather(c, send, recv, bytes, st);
   DVS_NCCL(g_rccl.AllGather(send, recv, bytes, kNcclUint8, c->comm, st));
   return DVS_OK;
@@ -194,6 +206,27 @@ dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const ui
   return DVS_OK;
 }
 
+dvs_status dvs_comm_create_host(int32_t rank, int32_t world, dvs_host_all_gather_fn all_gather, void* user, dvs_comm** out) {
+  DVS_ARG(out && all_gather && world >= 1 && rank >= 0 && rank < world);
+  *out = nullptr;
+  dvs_comm* c = new (std::nothrow) dvs_comm();
+  if (!c) { set_error("out of host memory"); return DVS_ERR_HIP; }
+  c->device = -1; c->rank = rank; c->world = world; c->host_gather = all_gather; c->host_user = user;
+  *out = c;
+  return DVS_OK;
+}
+
+int32_t dvs_comm_is_host(const dvs_comm* c) { return c && c->host_gather ? 1 : 0; }
+
+dvs_status dvs_comm_reset_sequence(dvs_comm* c) {
+  DVS_ARG(c);
+  // the next dvs_exchange_boundary is a FIRST call again: rank 0 gets no predecessor.  The caller has drained its streams (a reader of
+  // the previous gathers may not be pending); the buffers and their rotation stay.
+  c->calls = 0;
+  c->has_last = false;
+  return DVS_OK;
+}
+
 dvs_status dvs_comm_create_loopback(int32_t device, int32_t world, dvs_comm** out) {
   DVS_ARG(out && world >= 1 && world <= DVS_COMM_MAX_LOOPBACK);
   for (int r = 0; r < world; r++) out[r] = nullptr;
@@ -224,6 +257,11 @@ dvs_status dvs_comm_create_loopback(int32_t device, int32_t world, dvs_comm** ou
 
 void dvs_comm_destroy(dvs_comm* c) {
   if (!c) return;
+  if (c->host_gather) {
+    for (uint8_t* p : c->gather) free(p);
+    delete c;
+    return;
+  }
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   if (c->loop) {
@@ -252,8 +290,9 @@ int32_t dvs_comm_rccl_version(void) {
 
 dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, void* d_recv, size_t bytes_per_rank) {
   DVS_ARG(c && d_send && d_recv);
-  DVS_HIP(hipSetDevice(c->device));
   if (bytes_per_rank == 0) return DVS_OK;
+  if (c->host_gather) return comm_all_gather(c, d_send, d_recv, bytes_per_rank, nullptr);
+  DVS_HIP(hipSetDevice(c->device));
   if (c->loop) DVS_TRY(loop_before_send(c, (hipStream_t)stream));   // (the caller's send block was written before this call: see the header)
   return comm_all_gather(c, d_send, d_recv, bytes_per_rank, (hipStream_t)stream);
 }
@@ -261,13 +300,20 @@ dvs_status dvs_comm_all_gather(dvs_comm* c, void* stream, const void* d_send, vo
 dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_desc_last, const int32_t* d_n_last, int32_t cap,
                                  const uint8_t** d_prev_desc, const int32_t** d_prev_n) {
   DVS_ARG(c && d_desc_last && d_n_last && cap > 0 && d_prev_desc && d_prev_n);
-  DVS_ARG(((uintptr_t)d_desc_last) % 16 == 0);
-  DVS_HIP(hipSetDevice(c->device));
+  const bool host = c->host_gather != nullptr;
+  DVS_ARG(host || ((uintptr_t)d_desc_last) % 16 == 0);
+  if (!host) DVS_HIP(hipSetDevice(c->device));
   const size_t blk = dvs_boundary_block_bytes(cap);
   if (c->block != blk) {  // (re)allocate the three gather buffers once per capacity: nothing is allocated per step
-    DVS_HIP(hipDeviceSynchronize());
-    for (uint8_t*& p : c->gather) { if (p) DVS_HIP(hipFree(p)); p = nullptr; }
-    for (uint8_t*& p : c->gather) DVS_HIP(hipMalloc((void**)&p, blk * (size_t)c->world));
+    if (host) {
+      for (uint8_t*& p : c->gather) { free(p); p = nullptr; }
+      for (uint8_t*& p : c->gather)
+        if (!(p = (uint8_t*)calloc(blk, (size_t)c->world))) { set_error("out of host memory (%zu bytes of gather buffer)", blk * (size_t)c->world); return DVS_ERR_HIP; }
+    } else {
+      DVS_HIP(hipDeviceSynchronize());
+      for (uint8_t*& p : c->gather) { if (p) DVS_HIP(hipFree(p)); p = nullptr; }
+      for (uint8_t*& p : c->gather) DVS_HIP(hipMalloc((void**)&p, blk * (size_t)c->world));
+    }
     c->block = blk; c->calls = 0; c->turn = 0;
   }
   uint8_t* g = c->gather[c->turn];
@@ -275,7 +321,7 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   c->turn = (c->turn + 1) % 3;
   c->calls++;
   hipStream_t st = (hipStream_t)stream;
-  if (c->has_last && c->last_stream != st) {
+  if (!host && c->has_last && c->last_stream != st) {
     if (c->multi_stream) DVS_HIP(hipStreamWaitEvent(st, c->ev_last, 0));
     else {
       DVS_HIP(hipStreamSynchronize(c->last_stream));
@@ -286,11 +332,17 @@ dvs_status dvs_exchange_boundary(dvs_comm* c, void* stream, const uint8_t* d_des
   if (c->loop) DVS_TRY(loop_before_send(c, st));
   uint8_t* mine = g + (size_t)c->rank * blk;
   const int rows16 = cap * 2, blk16 = (int)(blk / 16);
-  hipLaunchKernelGGL(k_pack_boundary, dim3((blk16 + 255) / 256), dim3(256), 0, st, (const uint4*)d_desc_last, d_n_last, (uint4*)mine, rows16, blk16);
-  DVS_HIP(hipGetLastError());
+  if (host) {   // the block k_pack_boundary writes: descriptor rows, the count, zero padding
+    memcpy(mine, d_desc_last, (size_t)cap * 32);
+    memset(mine + (size_t)cap * 32, 0, blk - (size_t)cap * 32);
+    memcpy(mine + (size_t)cap * 32, d_n_last, 4);
+  } else {
+    hipLaunchKernelGGL(k_pack_boundary, dim3((blk16 + 255) / 256), dim3(256), 0, st, (const uint4*)d_desc_last, d_n_last, (uint4*)mine, rows16, blk16);
+    DVS_HIP(hipGetLastError());
+  }
   // in place: this rank's block already sits at its slot of the receive buffer
   DVS_TRY(comm_all_gather(c, mine, g, blk, st));
-  if (c->multi_stream) DVS_HIP(hipEventRecord(c->ev_last, st));
+  if (!host && c->multi_stream) DVS_HIP(hipEventRecord(c->ev_last, st));
   c->last_stream = st; c->has_last = true;
   // predecessor of this rank's FIRST frame of the batch: the previous rank's last frame of the SAME batch — or, for rank 0, the
   // last rank's last frame of the PREVIOUS batch (the previous call's gather; nothing on the first call)

@@ -14,6 +14,8 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <atomic>
+#include <algorithm>
 #include "common.h"
 #include "io_pinned.h"
 
@@ -205,9 +207,20 @@ static inline void launch_match_few(hipStream_t st, dim3 grid, const u64* q, con
   // up to 6 jobs (what a lane of dvs_pipeline enqueues, and the single-call entry point): one 2000 x 2000 job 18.3 -> 7.7 us per launch, two
   // 18.5 -> 8.1, four 18.8 -> 13.1, six 18.7 -> 19.5 alone but +8 % in the six-frame lane step (no scalar-load chain beside the other lanes'
   // kernels); 7 and 8 jobs (the four-stream form's match stream) lose 3-7 %: k_match<16, 1> there.  DVS_MATCH_LDS=0: never.
-  if (lds_on && grid.y <= 6 && trainRows > 0 && trainRows <= 4096 && (((uintptr_t)t | (uintptr_t)t0) & 15) == 0) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_match_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32); attr = true; }
+  // the train set + the kernel's own 1 KB must fit the device's LDS per workgroup; the limit and the kernel's attribute are per DEVICE
+  // (a function attribute set on one device says nothing about the next): looked up once for each
+  static std::atomic<int> ldsLimit[64];   // 0 = not asked yet, -1 = k_match_lds unusable there
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int lim = dev >= 0 && dev < 64 ? ldsLimit[dev].load(std::memory_order_acquire) : -1;
+  if (lim == 0) {
+    int v = 0;
+    lim = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 1024 ? v : -1;
+    if (lim > 0 && hipFuncSetAttribute((const void*)k_match_lds, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(lim - 1024, 4096 * 32)) != hipSuccess) lim = -1;
+    (void)hipGetLastError();
+    ldsLimit[dev].store(lim, std::memory_order_release);
+  }
+  if (lds_on && grid.y <= 6 && trainRows > 0 && trainRows <= 4096 && (long long)trainRows * 32 + 1024 <= lim && (((uintptr_t)t | (uintptr_t)t0) & 15) == 0) {
     const dim3 g16((grid.x * 64 + kLdsQ - 1) / kLdsQ, grid.y);   // (the callers' grids count 64 queries per workgroup)
     hipLaunchKernelGGL(k_match_lds, g16, dim3(1024), (size_t)trainRows * 32, st, q, nqArr, nqConst, qStrideRows, t, ntArr, ntConst, tStrideRows, outIdx,
                        outDist, trainRows, t0, nt0);
@@ -217,157 +230,148 @@ static inline void launch_match_few(hipStream_t st, dim3 grid, const u64* q, con
 }
 
 // =============================================================================================================================
-// Matrix-core variant for batches of large jobs.  Hamming distance as an exact integer contraction:
-// with every descriptor bit b encoded as the byte e(b) = +8 / -8,   sum_k e(q_k) e(t_k) = 64 (256 - 2 dist(q, t)),
-// so a 2000 x 256 . 256 x 2000 int8 product on the MFMA pipe (v_mfma_i32_32x32x32_i8, exact int32 accumulation) replaces
-// 16 M (v_xor, v_bcnt) pairs per job on the VALU pipe — which every other kernel of the path saturates while the matrix
-// cores sit idle.  The arg-min with cv::BFMatcher's lowest-index tie-break also comes out of the product: one extra
-// k-step carries, for the train row r, the constant 63 - code(r), code = the position of r among the 64 rows a lane's
-// accumulators hold, times a 1 on the query side; so   acc = 64 (256 - 2 dist) + 63 - code   and ONE signed max over a lane's
-// accumulator registers picks the smallest distance and, among equals, the lowest row.  Rows past the set's count carry
-// -32512 from four more slots of that k-step and can never win.  north_star says "no MFMA: none of this is a dense
-// contraction" — the match is one once the bits are bytes; measured effect in DESIGN.md §4.
-//
-// Expanded set layout (k_expand_desc, per set of strideRows descriptors): tiles of 32 rows x 10 KB =
-//   [8 data k-steps | query-role extra step | train-role extra step] x [half h = 0, 1] x [row & 31] x 16 bytes,
-// i.e. every 1-KB piece is exactly one operand fragment of the 32x32x32 MFMA in lane order (lane = 32 h + (row & 31) holds 16
-// consecutive k) — the layout both operands share, so a piece moves HBM -> LDS by one LDS-DMA wave-instruction and LDS -> VGPR
-// by one ds_read_b128 per lane, with no shuffle on either side.
+// Matrix-core match for batches of large jobs (rebuilt in round 5).  north_star says "no MFMA: none of this is a dense
+// contraction" — the match is one once the bits are bytes: Hamming distance as an exact integer contraction on
+// v_mfma_i32_32x32x32_i8 (int32 accumulation) replaces 16 M (v_xor, v_bcnt) pairs per 2000 x 2000 job on the vector pipe, which every
+// other kernel of the path saturates while the matrix cores sit idle.
+//   dist(q, t) = |q| + |t| - 2 |q AND t|.   Train bit -> byte 0 / 2, query bit -> byte 0 / 64: the eight data k-steps give
+//   128 |q AND t|; a ninth step adds, per train row, -64 |t| (each wavefront the count of the bits it expanded, in a slot of its own),
+//   63 - code(row) — code = the row's place among the 64 rows a lane's accumulators hold per 128-row chunk, so that ONE signed max over
+//   the accumulator registers picks the smallest distance and, among equals, the lowest row (cv::BFMatcher's tie-break) — and -8192 for
+//   rows past the set's count:   key = 64 (2 |q AND t| - |t|) + 63 - code,   dist = |q| - (key >> 6).
+// Both operands are built IN the kernel straight from the 32-byte descriptor rows (rounds 2-4 wrote +8 / -8 byte images of every set to
+// HBM with a second kernel — 41.6 MB written + 76 MB read per 64 jobs for 9.2 MB of descriptors — and streamed them through 72 KB of
+// LDS per workgroup, which beside FAST cost the 64-frame step 57 us: EXPERIMENTS.md, round 5):
+//   * contraction order: lane (h, r) of an operand fragment supplies 16 k-values of row r; which of the 256 bits they are is free as
+//     long as both operands agree, so half h takes bytes [16 h, 16 h + 16) of the row and k-step j the bits [16 (j & 1), +16) of its
+//     word j >> 1
+//   * the nibble-to-bytes spread is one multiply and one mask per four bytes: nibble x (1 + 2^7 + 2^14 + 2^21) V puts bit i at byte i
+//     (the terms never overlap)
+//   * the train fragments are SHARED by the four wavefronts of a workgroup through 18 KB of LDS: wavefront w expands k-steps 2 w and
+//     2 w + 1 of a tile of 32 rows (word w of every row half: together they read each descriptor byte once) — 24 vector instructions
+//     per wavefront and tile; two 9-KB tile buffers, one barrier per tile; every wavefront holds the 9 query fragments of NQ tiles
+//     in registers.  Rows past the count repeat row nt - 1 (clamped loads): a repeat can never beat its original.
 // =============================================================================================================================
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int kMtBytes = 10 * 1024;            // one 32-row tile of an expanded set
-constexpr int kChunkTiles = 4;                 // 128 train rows per chunk = the 64 accumulator registers of one lane
-constexpr int kPieces = kChunkTiles * 9;       // 1-KB pieces staged per chunk (8 data steps + the train-role extra step per tile)
-constexpr int kChunkLds = kPieces * 1024;      // 36 KB; two buffers -> 72 KB per workgroup, two workgroups per CU
 
-// position of row r (within its 128-row chunk) in the register order of the lane that holds it: C/D layout of the 32x32 MFMA,
-// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) within a tile; tiles in order
-__host__ __device__ __forceinline__ int mfma_row_code(int r128) {
-  const int r = r128 & 31;
-  return (r128 >> 5) * 16 + (r >> 3) * 4 + (r & 3);
-}
-
-__global__ __launch_bounds__(256) void k_expand_desc(const uint8_t* __restrict__ desc, const int* __restrict__ nArr, int strideRows,
-                                                     const uint8_t* __restrict__ desc0, const int* __restrict__ n0, int8_t* __restrict__ E,
-                                                     size_t setBytes, int mtPad) {
-  const int set = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int piece = t >> 5, r32 = t & 31;
-  const int mt = piece / 20, sh = piece - mt * 20;
-  if (mt >= mtPad) return;
-  const int s = sh >> 1, h = sh & 1;
-  const bool first = set == 0 && desc0 != nullptr;   // set 0 may live elsewhere (a frame sequence's predecessor)
-  const uint8_t* d = first ? desc0 : desc + (ptrdiff_t)set * strideRows * 32;
-  const int n = min(max(first ? *n0 : nArr[set], 0), strideRows);
-  const int row = mt * 32 + r32;
-  const bool valid = row < n;
-  uint4 o = make_uint4(0u, 0u, 0u, 0u);
-  if (s < 8) {
-    if (valid) {
-      const unsigned bits = *reinterpret_cast<const unsigned short*>(d + (size_t)row * 32 + s * 4 + h * 2);
-      auto ex = [](unsigned x4) -> unsigned {  // 4 bits -> 4 bytes of +8 / -8 (0x08 / 0xF8): spread by multiply, no carries
-        return ((((x4 & 15u) * 0x00204081u) & 0x01010101u) * 0xF0u) | 0x08080808u;
-      };
-      o = make_uint4(ex(bits), ex(bits >> 4), ex(bits >> 8), ex(bits >> 12));
-    }
-  } else if (h == 0) {
-    if (s == 8) o = make_uint4(0x40404001u, 0x00000040u, 0u, 0u);                       // query role: 1, then 64 x 4
-    else o = make_uint4((unsigned)(63 - mfma_row_code(row & 127)) | (valid ? 0u : 0x81818100u), valid ? 0u : 0x00000081u, 0u, 0u);
-  }
-  *reinterpret_cast<uint4*>(E + (size_t)set * setBytes + (size_t)mt * kMtBytes + (size_t)sh * 512 + r32 * 16) = o;
-}
-
-// workgroup = 128 NQ queries (NQ 32-query tiles per wavefront, their 9 B fragments each resident in registers) x all train rows,
-// streamed in chunks of 128 rows through two LDS buffers by LDS-DMA; job = blockIdx.y.  Query set of job p = set p + qSetOff of
-// Eq, train set = set p of Et (a frame sequence expands [predecessor, frame 0, ...] once and uses it in both roles).
-// NQ = 2: every A fragment read from LDS feeds two MFMAs and a chunk carries twice the matrix work per workgroup barrier.
-template <int NQ>
-__global__ __launch_bounds__(256, 2) void k_match_mfma(const int8_t* __restrict__ Eq, size_t qSetBytes, int qSetOff, const int8_t* __restrict__ Et,
-                                                       size_t tSetBytes, const int* __restrict__ nqArr, int qStrideRows,
-                                                       const int* __restrict__ ntArr, int tStrideRows, const int* __restrict__ nt0,
-                                                       int* __restrict__ outIdx, int* __restrict__ outDist) {
-  extern __shared__ __attribute__((aligned(16))) int8_t mlds[];
-#if defined(DVS_CHAIN_PRIO_LEVEL) && DVS_CHAIN_PRIO_LEVEL
-  __builtin_amdgcn_s_setprio(DVS_CHAIN_PRIO_LEVEL);
-#endif
-  // XCD-aware job mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, and with (x = query tile, y = pair) the
-  // tiles of one pair — which all stream the SAME train set — landed on 8 different L2s: 335 MB fetched per 64 pairs of 40 MB of
-  // distinct expanded descriptors (profiles/r02_pmc_summary.csv).  Re-deal the linear id so that pair p runs entirely on XCD p % 8.
+template <int NQ, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_match_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nqArr, int qStrideRows,
+                                                        const uint8_t* __restrict__ t, const int* __restrict__ ntArr, int tStrideRows,
+                                                        const uint8_t* __restrict__ t0, const int* __restrict__ nt0,
+                                                        int* __restrict__ outIdx, int* __restrict__ outDist) {
+  __shared__ __attribute__((aligned(16))) uint8_t tl[2][9 * 1024];
   int pair = blockIdx.y, qt = blockIdx.x;
   if ((gridDim.y & 7) == 0) {
     const int lid = blockIdx.x + gridDim.x * blockIdx.y, xcd = lid & 7, k = lid >> 3;
     pair = xcd + 8 * (k / (int)gridDim.x);
     qt = k % (int)gridDim.x;
   }
+  const bool first = pair == 0 && t0 != nullptr;
   const int nq = min(max(nqArr[pair], 0), qStrideRows);
-  const int nt = min(max(pair == 0 && nt0 ? *nt0 : ntArr[pair], 0), tStrideRows);
-  if (qt * 128 * NQ >= nq) return;
-  const int lane = threadIdx.x & 63;
+  const int nt = min(max(first ? *nt0 : ntArr[pair], 0), tStrideRows);
+  if (qt * 32 * NW * NQ >= nq) return;   // (uniform over the workgroup: no barrier is skipped by a part of it)
+  const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // this wave's query tiles: (qt * 4 + w) * NQ + u — consecutive, so the expanded image needs NQ * 4 tiles per workgroup
-  const int8_t* eq = Eq + (size_t)(pair + qSetOff) * qSetBytes + (size_t)((qt * 4 + w) * NQ) * kMtBytes + lane * 16;
+  const uint8_t* qb = q + (size_t)pair * qStrideRows * 32 + 16 * h;
+  constexpr int NS = 8 / NW;   // k-steps a wavefront expands per tile: 2 (a word of the row half) or 1 (16 bits of it)
+  const uint8_t* tb = (first ? t0 : t + (ptrdiff_t)pair * tStrideRows * 32) + 16 * h + 2 * NS * w;
+  auto word = [](const uint4& v, int i) -> uint32_t { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); };
   v4i bq[NQ][9];
+  int popq[NQ];
+  const int qtile0 = (qt * NW + w) * NQ;
 #pragma unroll
-  for (int u = 0; u < NQ; u++)
+  for (int u = 0; u < NQ; u++) {
+    const int row = min((qtile0 + u) * 32 + r, nq - 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(qb + (size_t)row * 32);
+    const int ph = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    popq[u] = ph + __shfl_xor(ph, 32);
 #pragma unroll
-    for (int s = 0; s < 9; s++) bq[u][s] = *reinterpret_cast<const v4i*>(eq + (size_t)u * kMtBytes + s * 1024);
-  const int8_t* et = Et + (size_t)pair * tSetBytes + lane * 16;
-  const int nchunks = (nt + 127) >> 7;
-  auto stage = [&](int c, int buf) {
-    for (int p = w; p < kPieces; p += 4) {
-      const int mt = p / 9, s = p - mt * 9;
-      const int8_t* src = et + (size_t)(c * kChunkTiles + mt) * kMtBytes + (s < 8 ? s : 9) * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(mlds + buf * kChunkLds + p * 1024), 16, 0, 0);
+    for (int j = 0; j < 8; j++) {
+      const uint32_t x = word(v, j >> 1) >> (16 * (j & 1));
+      bq[u][j] = v4i{(int)((((x >> 0) & 15u) * 0x08102040u) & 0x40404040u), (int)((((x >> 4) & 15u) * 0x08102040u) & 0x40404040u),
+                     (int)((((x >> 8) & 15u) * 0x08102040u) & 0x40404040u), (int)((((x >> 12) & 15u) * 0x08102040u) & 0x40404040u)};
     }
-  };
+    // slot 0: x 1 (code); slots 1..NW: x 64 (the wavefronts' counts); slot NW + 1: x 64 (past-the-count)
+    bq[u][8] = NW == 4 ? v4i{0x40404001, 0x00004040, 0, 0} : v4i{0x40404001, 0x40404040, 0x00004040, 0};
+  }
+  const int nchunks = (nt + 127) >> 7, ntiles = nchunks * 4;
   int bestc[NQ], besti[NQ];
 #pragma unroll
   for (int u = 0; u < NQ; u++) { bestc[u] = INT_MIN; besti[u] = -1; }
-  if (nchunks > 0) stage(0, 0);
+  const int lanePart = (r >> 3) * 4 + (r & 3);
+  // the ninth piece's bytes 6..15 stay zero; bytes 0..5 are rewritten for every tile
+  if (w < 2) *reinterpret_cast<uint4*>(&tl[w][8 * 1024 + lane * 16]) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  // expansion of this wavefront's two k-steps of a tile + its bytes of the ninth piece
+  auto expand = [&](int tile, uint32_t x, uint8_t* buf) {
+    constexpr uint32_t M = 0x00408102u, K = 0x02020202u;
+    const v4i a0 = v4i{(int)(__umul24(__builtin_amdgcn_ubfe(x, 0, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 4, 4), M) & K),
+                       (int)(__umul24(__builtin_amdgcn_ubfe(x, 8, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 12, 4), M) & K)};
+    *reinterpret_cast<v4i*>(buf + (NS * w) * 1024 + lane * 16) = a0;
+    if (NS == 2) {
+      const v4i a1 = v4i{(int)(__umul24(__builtin_amdgcn_ubfe(x, 16, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 20, 4), M) & K),
+                         (int)(__umul24(__builtin_amdgcn_ubfe(x, 24, 4), M) & K), (int)(__umul24(x >> 28, M) & K)};
+      *reinterpret_cast<v4i*>(buf + (2 * w + 1) * 1024 + lane * 16) = a1;
+    }
+    const uint32_t np = (uint32_t)(-__popc(x)) & 0xFFu;
+    uint8_t* e = buf + 8 * 1024 + lane * 16;
+    if (w == 0) *reinterpret_cast<uint16_t*>(e) = (uint16_t)((h == 0 ? (uint32_t)(63 - ((tile & 3) * 16 + lanePart)) : 0u) | np << 8);
+    else if (w == NW - 1) *reinterpret_cast<uint16_t*>(e + NW) = (uint16_t)(np | (tile * 32 + r < nt ? 0u : 0x8000u));
+    else e[1 + w] = (uint8_t)np;
+  };
+  auto load = [&](int tile) -> uint32_t {
+    const uint8_t* a = tb + (size_t)min(tile * 32 + r, nt - 1) * 32;
+    return NS == 2 ? *reinterpret_cast<const uint32_t*>(a) : (uint32_t)*reinterpret_cast<const uint16_t*>(a);
+  };
+  uint32_t wnext = 0;
+  if (ntiles > 0) {
+    expand(0, load(0), tl[0]);
+    wnext = load(1);
+  }
+  __syncthreads();
   for (int c = 0; c < nchunks; c++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c have landed ...
-    __syncthreads();                                   // ... and everyone's; everyone has also finished reading the other buffer
-    if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-    const int8_t* buf = mlds + (c & 1) * kChunkLds + lane * 16;
     int key[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; u++) key[u] = INT_MIN;
 #pragma unroll
-    for (int m = 0; m < kChunkTiles; m++) {
+    for (int m = 0; m < 4; m++) {
+      const int tile = c * 4 + m;
+      const uint32_t wcur = wnext;
+      wnext = load(tile + 2);                                     // two tiles ahead (clamped: always a valid address)
+      if (tile + 1 < ntiles) expand(tile + 1, wcur, tl[(tile + 1) & 1]);
+      const uint8_t* buf = tl[tile & 1] + lane * 16;
       v16i acc[NQ];
 #pragma unroll
       for (int u = 0; u < NQ; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < 9; s++) {
-        const v4i a = *reinterpret_cast<const v4i*>(buf + (m * 9 + s) * 1024);
+      for (int s9 = 0; s9 < 9; s9++) {
+        const v4i a = *reinterpret_cast<const v4i*>(buf + s9 * 1024);
 #pragma unroll
-        for (int u = 0; u < NQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], acc[u], 0, 0, 0);
+        for (int u = 0; u < NQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s9], acc[u], 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < NQ; u++)
 #pragma unroll
         for (int i = 0; i < 16; i++) key[u] = max(key[u], acc[u][i]);
+      __syncthreads();   // tile + 1 is complete for everyone; everyone has read tile's buffer, which tile + 2 overwrites
     }
 #pragma unroll
     for (int u = 0; u < NQ; u++) {
-      // key = 64 (256 - 2 dist) + 63 - code: the lane's best row of this chunk (lowest row among equal distances)
       const int cval = key[u] >> 6, code = 63 - (key[u] & 63);
-      const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + (lane >> 5) * 4 + (code & 3);
-      if (cval > bestc[u]) { bestc[u] = cval; besti[u] = row; }   // later chunks hold higher rows: strict '>' keeps the lowest on ties
+      const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + h * 4 + (code & 3);
+      if (cval > bestc[u]) { bestc[u] = cval; besti[u] = row; }
     }
   }
 #pragma unroll
   for (int u = 0; u < NQ; u++) {
-    // the two lane halves hold interleaved rows of the same query column
     const int oc = __shfl_xor(bestc[u], 32), oi = __shfl_xor(besti[u], 32);
     int bc = bestc[u], bi = besti[u];
     if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-    const int qi = ((qt * 4 + w) * NQ + u) * 32 + (lane & 31);
+    const int qi = (qtile0 + u) * 32 + r;
     if (lane < 32 && qi < nq) {
       outIdx[(size_t)pair * qStrideRows + qi] = nt > 0 ? bi : -1;
-      outDist[(size_t)pair * qStrideRows + qi] = nt > 0 ? (256 - bc) >> 1 : INT_MAX;
+      outDist[(size_t)pair * qStrideRows + qi] = nt > 0 ? popq[u] - bc : INT_MAX;
     }
   }
 }
@@ -453,8 +457,6 @@ struct dvs_matcher {
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only buffers of the glue entry points (frontend.hip)
   size_t cscratch[4] = {0, 0, 0, 0};
   void* d_zero = nullptr;  // 64 zero bytes: the empty predecessor of dvs_match_hamming_sequence_device
-  void* d_expand[2] = {nullptr, nullptr};  // +8 / -8 byte images of the descriptor sets for the matrix-core kernel (grow-only)
-  size_t cexpand[2] = {0, 0};
   int use_mfma = 1;        // DVS_MATCH_MFMA=0 keeps every job on the popcount kernel
   // pinned in / out block of the small host entry points (RANSAC stages): inputs are placed here and imported by a kernel, results
   // are exported by a kernel that publishes a sequence number the host polls — no copy commands, no stream wait
@@ -469,40 +471,6 @@ dvs_status grow(void** p, size_t* cap, size_t need) {
   *p = nullptr; *cap = 0;
   DVS_HIP(hipMalloc(p, need ? need : 1));
   *cap = need;
-  return DVS_OK;
-}
-}  // namespace
-
-namespace {
-// expanded image of `nsets` descriptor sets (set s at desc + s * strideRows * 32 with count nArr[s]; set 0 from desc0 / n0 if given)
-dvs_status expand_sets(dvs_matcher* m, int slot, const uint8_t* desc, const int* nArr, int strideRows, const uint8_t* desc0, const int* n0,
-                       int nsets, size_t* setBytes) {
-  const int mtPad = (strideRows + 127) / 128 * kChunkTiles;
-  *setBytes = (size_t)mtPad * kMtBytes;
-  DVS_TRY(grow(&m->d_expand[slot], &m->cexpand[slot], *setBytes * (size_t)nsets));
-  hipLaunchKernelGGL(k_expand_desc, dim3((mtPad * 640 + 255) / 256, nsets), dim3(256), 0, m->stream, desc, nArr, strideRows, desc0, n0,
-                     (int8_t*)m->d_expand[slot], *setBytes, mtPad);
-  DVS_HIP(hipGetLastError());
-  return DVS_OK;
-}
-dvs_status launch_match_mfma(dvs_matcher* m, const int8_t* Eq, size_t qSetBytes, int qSetOff, const int8_t* Et, size_t tSetBytes, const int* nq,
-                             int qStrideRows, const int* nt, int tStrideRows, const int* nt0, int npairs, int* d_idx, int* d_dist) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
-    DVS_HIP(hipFuncSetAttribute((const void*)k_match_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkLds));
-    attr_set = true;
-  }
-  // the expanded query image is padded to a multiple of 4 tiles (128 rows): a 256-query workgroup whose second half lies past
-  // it must not read there -> NQ = 2 only when the padded tile count is a multiple of 8
-  const int mtPadQ = (qStrideRows + 127) / 128 * kChunkTiles;
-  if (qStrideRows > 128 && mtPadQ % 8 == 0)
-    hipLaunchKernelGGL(k_match_mfma<2>, dim3((qStrideRows + 255) / 256, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et,
-                       tSetBytes, nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
-  else
-    hipLaunchKernelGGL(k_match_mfma<1>, dim3((qStrideRows + 127) / 128, npairs), dim3(256), 2 * kChunkLds, m->stream, Eq, qSetBytes, qSetOff, Et,
-                       tSetBytes, nq, qStrideRows, nt, tStrideRows, nt0, d_idx, d_dist);
-  DVS_HIP(hipGetLastError());
   return DVS_OK;
 }
 }  // namespace
@@ -592,7 +560,7 @@ void dvs_matcher_destroy(dvs_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
-  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero, m->d_expand[0], m->d_expand[1]};
+  void* ptrs[] = {m->d_q, m->d_t, m->d_idx, m->d_dist, m->d_counts, m->d_offs, m->d_pairs, m->scratch[0], m->scratch[1], m->scratch[2], m->scratch[3], m->d_zero};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_io) (void)hipHostFree(m->h_io);
   if (m->h_seq) (void)hipHostFree(m->h_seq);
@@ -636,12 +604,12 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }
-  if (m->use_mfma && t_stride_rows > 0) {  // many large jobs: the contraction runs on the matrix cores (k_match_mfma)
-    size_t qb = 0, tb = 0;
-    DVS_TRY(expand_sets(m, 0, d_q, d_nq, q_stride_rows, nullptr, nullptr, npairs, &qb));
-    DVS_TRY(expand_sets(m, 1, d_t, d_nt, t_stride_rows, nullptr, nullptr, npairs, &tb));
-    return launch_match_mfma(m, (const int8_t*)m->d_expand[0], qb, 0, (const int8_t*)m->d_expand[1], tb, d_nq, q_stride_rows, d_nt, t_stride_rows,
-                             nullptr, npairs, d_idx, d_dist);
+  // many large jobs: the contraction runs on the matrix cores, operands built in the kernel (16-byte row loads: other bases take k_match)
+  if (m->use_mfma && t_stride_rows > 0 && (((uintptr_t)d_q | (uintptr_t)d_t) & 15) == 0) {
+    hipLaunchKernelGGL(k_match_mfma<2>, dim3((q_stride_rows + 255) / 256, npairs), dim3(256), 0, m->stream, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows,
+                       (const uint8_t*)nullptr, (const int*)nullptr, d_idx, d_dist);
+    DVS_HIP(hipGetLastError());
+    return DVS_OK;
   }
   constexpr int kSplit = 8, kQPL = 2;
   dim3 grid((q_stride_rows + 64 * kQPL - 1) / (64 * kQPL), npairs);
@@ -667,12 +635,12 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
     }
     d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
   }
-  if (m->use_mfma && (long long)nframes * stride_rows > 16384) {
-    // sets [predecessor, frame 0 .. nframes - 1] are expanded ONCE and used in both roles: job p = set p + 1 against set p
-    size_t sb = 0;
-    DVS_TRY(expand_sets(m, 0, d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, nframes + 1, &sb));
-    return launch_match_mfma(m, (const int8_t*)m->d_expand[0], sb, 1, (const int8_t*)m->d_expand[0], sb, d_n, stride_rows, d_n - 1, stride_rows, d_prev_n,
-                             nframes, d_idx, d_dist);
+  if (m->use_mfma && (long long)nframes * stride_rows > 16384 && (((uintptr_t)d_desc | (uintptr_t)d_prev_desc) & 15) == 0) {
+    // job p = frame p against frame p - 1 (job 0: the predecessor block): train base shifted back by one frame, never dereferenced for job 0
+    hipLaunchKernelGGL(k_match_mfma<2>, dim3((stride_rows + 255) / 256, nframes), dim3(256), 0, m->stream, d_desc, d_n, stride_rows,
+                       d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, d_idx, d_dist);
+    DVS_HIP(hipGetLastError());
+    return DVS_OK;
   }
   // a few jobs (everything below the matrix-core threshold): favour wavefront count over per-wave efficiency, as the batch entry point does —
   // one 2000 x 2000 job on <8, 2> occupies 16 workgroups for 39 us

@@ -562,7 +562,9 @@ __global__ __launch_bounds__(256) void k_fast_cell(const Geom* __restrict__ g, c
     for (int p = tid; p < ch * P / 4; p += 256) s32[p] = 0;
   }
   __syncthreads();
-  const int tmin = g->minTh, tini = g->iniTh;
+  // one score map serves both of the reference's calls when minTh <= iniTh; with minTh > iniTh the second call finds a subset of the
+  // first's (empty) result, so the lower of the two thresholds is the one to test and score at
+  const int tini = g->iniTh, tmin = min(g->minTh, tini);
   const int npx = iw * ih;
   const float invw = 1.0f / (float)iw;
   // 2. rejection test + compaction
@@ -811,15 +813,31 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
   if (gi == 0) cmLane &= 0x80808080u << (8 * (cx0 & 3));
   if (gi == ng - 1) cmLane &= 0x80808080u >> (8 * (3 - ((cx1 - 1) & 3)));
   const uint32_t cmTail = rsub < tailRows ? cmLane : 0u;   // the last trip's mask: only the rows that exist
-  int nwork = 0;
-  const uint32_t* rp = reinterpret_cast<const uint32_t*>(tile) + mad_i24(rsub + 3, P / 4, g0 + gi);   // centre word of the lane's first row
+  const uint32_t* const rpFirst = reinterpret_cast<const uint32_t*>(tile) + mad_i24(rsub + 3, P / 4, g0 + gi);   // centre word of the lane's first row
   // survivors are listed by the offset of the pixel 3 rows and 3 columns up-left; the lane's four candidates entries ride in the
   // halves of two registers (ds_write_b16 / ds_write_b16_d16_hi store either half), advanced by one packed add each per trip
   const int cbase0 = mad_i24(rsub, P, (g0 + gi) * 4 - 3);
-  u16x2 c01 = {(uint16_t)cbase0, (uint16_t)(cbase0 + 1)}, c23 = {(uint16_t)(cbase0 + 2), (uint16_t)(cbase0 + 3)};
+  const u16x2 c01First = {(uint16_t)cbase0, (uint16_t)(cbase0 + 1)}, c23First = {(uint16_t)(cbase0 + 2), (uint16_t)(cbase0 + 3)};
   const uint16_t cstep = (uint16_t)(rpt * P);
   const u16x2 cstep2 = {cstep, cstep};
   const uint32_t workLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)work;
+  const uint32_t* work32 = reinterpret_cast<const uint32_t*>(work);
+  const uint32_t tileLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u8*)tile;
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  // The reference's two literal calls (ORBextractor.cpp:826-846): cv::FAST at iniThFAST, and ONLY for a cell that ends with no corner
+  // again at minThFAST.  Every phase below runs at the pass's threshold tcur: survivors of the rejection test, exact scores, the corner
+  // list (score >= tcur) and the strict 3x3 maximum among exactly those corners — the score tile holds nothing else: pass 0 leaves the
+  // scores of corners >= iniTh there, which the second pass, whose corners are a superset, writes again with the same values.
+  // (Round 1-4 ran ONE pass at minTh and picked the >= iniTh maxima afterwards: the same corners for iniTh >= minTh, but every cell
+  // scored its minTh survivors — 2.5 trips of the score stage per cell against 1.5 at iniTh on the benchmark's frames, where 6 % of the
+  // cells are empty at iniTh and pay a second rejection loop.)
+  int ncorner = 0;
+  int tcur = tini;
+  for (int pass = 0;; pass++) {
+  int nwork = 0;
+  const uint32_t* rp = rpFirst;
+  u16x2 c01 = c01First, c23 = c23First;
+  const s16x2 T2 = {(short)tcur, (short)tcur};
   for (int row0 = 0; row0 < ih; row0 += rpt, rp += rpt * (P / 4), c01 += cstep2, c23 += cstep2) {
     const uint32_t Om3 = rp[-3 * (P / 4)], Op3 = rp[3 * (P / 4)];
     const uint32_t Lm2 = rp[-2 * (P / 4) - 1], Om2 = rp[-2 * (P / 4)], Rm2 = rp[-2 * (P / 4) + 1];
@@ -830,8 +848,6 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     //   all four opposite pairs hold a brighter sample <=>  min_pairs(max(r_k, r_k+8)) > v + t
     // A ring sample of the pixel pair (2 hh, 2 hh + 1) is two bytes of the eight bytes (hi : lo) of two neighbouring words: ONE byte
     // permute moves them into the 16-bit halves (round 2a shifted the words first — six v_alignbyte per trip — and unpacked then)
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    const s16x2 T2 = {(short)tmin, (short)tmin};
     uint32_t sgn[2];
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
@@ -895,20 +911,18 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     nwork += __builtin_amdgcn_readlane(incl, 63);
   }
   wave_lds_fence();
-  // 3. exact score for the survivors, two per lane (2 lane, 2 lane + 1); corners (score >= minTh) are re-compacted in place, row-major
-  int ncorner = 0;
-  const uint32_t* work32 = reinterpret_cast<const uint32_t*>(work);
-  const uint32_t tileLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u8*)tile;
+  // 3. exact score for the survivors, two per lane (2 lane, 2 lane + 1); corners (score >= tcur) are re-compacted in place, row-major
+  ncorner = 0;
   for (int e0 = 0; e0 < nwork; e0 += 128) {
     const int ea = e0 + 2 * lane;
     // idle halves read ONE harmless pixel (offset 0: a broadcast; stale entries would scatter over the banks)
     const uint32_t cc = ea < nwork ? work32[(e0 >> 1) + lane] : 0u;
     const uint32_t ca = cc & 0xFFFFu, cb = ea < nwork - 1 ? cc >> 16 : 0u;
     const i16x2 sc2 = fast_corner_score2<P>(tile + ca, tile + cb);
-    // corners: list entry in range and score >= minTh.  The compare builtins ARE the ballots (a ballot of a combined predicate is
+    // corners: list entry in range and score >= tcur.  The compare builtins ARE the ballots (a ballot of a combined predicate is
     // re-made by two more vector instructions), combined on the scalar unit
-    const unsigned long long ba = __builtin_amdgcn_sicmp(ea, nwork, 40 /* < */) & __builtin_amdgcn_sicmp((int)sc2.x, tmin, 39 /* >= */);
-    const unsigned long long bb = __builtin_amdgcn_sicmp(ea, nwork - 1, 40) & __builtin_amdgcn_sicmp((int)sc2.y, tmin, 39);
+    const unsigned long long ba = __builtin_amdgcn_sicmp(ea, nwork, 40 /* < */) & __builtin_amdgcn_sicmp((int)sc2.x, tcur, 39 /* >= */);
+    const unsigned long long bb = __builtin_amdgcn_sicmp(ea, nwork - 1, 40) & __builtin_amdgcn_sicmp((int)sc2.y, tcur, 39);
     // corners before this lane's: four v_mbcnt; the list keeps the survivors' form of the offset (3 rows and 3 columns up-left)
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba,
                           __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u))));
@@ -934,28 +948,31 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     ncorner += __popcll(ba) + __popcll(bb);
   }
   wave_lds_fence();
-  // 4. NMS on the corner list: bit 14 = strict 3x3 maximum, bit 15 = ... and score >= iniTh
-  bool any20 = false;
+  // 4. NMS on the corner list: bit 14 = strict 3x3 maximum among the pass's corners
+  bool anyMax = false;
   for (int e0 = 0; e0 < ncorner; e0 += 64) {
     const int e = e0 + lane;
-    bool hi = false;
+    bool ismax = false;
     if (e < ncorner) {
       const int c = work[e];
       const u8* sp = score + c + (3 * P + 3);   // the corner's own byte
       const int sc = sp[0];
       // all eight neighbours read at once (a short-circuit chain is eight dependent LDS round trips), folded by four 3-operand maxima
       const int n0 = sp[-1], n1 = sp[1], n2 = sp[-P - 1], n3 = sp[-P], n4 = sp[-P + 1], n5 = sp[P - 1], n6 = sp[P], n7 = sp[P + 1];
-      const bool ismax = sc > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-      hi = ismax && sc >= tini;
-      work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0) | (hi ? 0x8000 : 0));
+      ismax = sc > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+      work[e] = (uint16_t)(c | (ismax ? 0x4000 : 0));
     }
-    any20 = any20 || (__ballot(hi) != 0ull);
+    anyMax = anyMax || (__ballot(ismax) != 0ull);
   }
   wave_lds_fence();
+  // a second call at a threshold that is not lower finds a subset of nothing
+  if (anyMax || pass == 1 || tmin >= tini) break;
+  tcur = tmin;
+  }
   // 5. ordered emission
   uint32_t* out = cand + (uint64_t)f * g->candPerFrame + L.candOff + (uint64_t)cell.slot * L.cellCap;
   const int cap = L.cellCap;
-  const int selbit = any20 ? 0x8000 : 0x4000;
+  const int selbit = 0x4000;
   int nout = 0;
   for (int e0 = 0; e0 < ncorner; e0 += 64) {
     const int e = e0 + lane;
@@ -1539,6 +1556,9 @@ __global__ __launch_bounds__(kOctTMax) void k_octree(const Geom* __restrict__ g,
                                                 uint32_t* __restrict__ ptsAll, int* __restrict__ nodeOfAll,
                                                 int* __restrict__ candTotal, uint32_t* __restrict__ lvlKp,
                                                 int* __restrict__ lvlKpCount, int nmax, int ptsLdsCap, uint32_t levelMask, int level0) {
+#ifdef DVS_EXP_OCT_PRIO   /* EXPERIMENT (round 5): issue priority of the latency-bound trees over what runs beside them */
+  __builtin_amdgcn_s_setprio(DVS_EXP_OCT_PRIO);
+#endif
   octree_body(g, cand, cellCount, cellOff, ptsAll, nodeOfAll, candTotal, lvlKp, lvlKpCount, nmax, ptsLdsCap, levelMask, level0);
 }
 

@@ -44,6 +44,7 @@ struct dvs_pipeline {
   std::vector<hipEvent_t> ev_ext, ev_match;
   hipEvent_t ev_fast = nullptr;
   int64_t i = 0;
+  int64_t matched = -1;                   // pipelined schedule: the last batch whose match has been enqueued (a flush enqueues it early)
 };
 
 namespace {
@@ -113,6 +114,11 @@ dvs_status dvs_pipeline_create(const dvs_pipeline_params* prm, int32_t device, d
   // a set always belongs to the same lane (nsets a multiple of lanes): whatever was enqueued earlier for a set — its extraction, its match,
   // their events — precedes on that lane's stream
   while (lanes > 1 && nsets % lanes) lanes--;
+  if (!prm->pipelined && nsets < 2) {
+    set_error("the serial schedule rotates at least 2 output sets (frame 0 of batch i is matched against the last frame of batch "
+              "i - 1, which one set would have overwritten); nsets = %d", nsets);
+    return DVS_ERR_ARG;
+  }
   if (prm->pipelined && nsets < 3) {
     set_error("the pipelined schedule rotates at least 3 output sets (the match of batch i + 1 reads batch i's last frame and is "
               "enqueued in step i + 2); nsets = %d", nsets);
@@ -218,6 +224,10 @@ void dvs_pipeline_destroy(dvs_pipeline* p) {
 
 dvs_status dvs_pipeline_attach_comm(dvs_pipeline* p, dvs_comm* comm) {
   DVS_ARG(p);
+  if (comm && dvs_comm_is_host(comm)) {
+    set_error("dvs_pipeline_attach_comm: a host-transport communicator exchanges host blocks; the pipeline's are device memory");
+    return DVS_ERR_ARG;
+  }
   p->comm = comm;
   return DVS_OK;
 }
@@ -249,7 +259,8 @@ dvs_status dvs_pipeline_step(dvs_pipeline* p, const uint8_t* d_imgs, const uint8
                                        p->cap, p->n[s]));
   if (flags & DVS_PIPELINE_NO_MATCH) return DVS_OK;
   if (p->pipelined) {
-    if (i >= 1) DVS_TRY(enqueue_match(p, i - 1, true));
+    // (a flush may have enqueued it already: a second exchange for the same batch would hand rank 0 that batch as its predecessor)
+    if (i >= 1 && p->matched < i - 1) { DVS_TRY(enqueue_match(p, i - 1, true)); p->matched = i - 1; }
   } else {
     DVS_TRY(enqueue_match(p, i, false));
   }
@@ -258,7 +269,10 @@ dvs_status dvs_pipeline_step(dvs_pipeline* p, const uint8_t* d_imgs, const uint8
 
 dvs_status dvs_pipeline_flush(dvs_pipeline* p) {
   DVS_ARG(p);
-  if (p->pipelined && p->lanes == 1 && p->i >= 1) DVS_TRY(enqueue_match(p, p->i - 1, false));
+  if (p->pipelined && p->lanes == 1 && p->i >= 1 && p->matched < p->i - 1) {
+    DVS_TRY(enqueue_match(p, p->i - 1, false));
+    p->matched = p->i - 1;
+  }
   return DVS_OK;
 }
 
@@ -273,6 +287,8 @@ dvs_status dvs_pipeline_reset(dvs_pipeline* p) {
   DVS_ARG(p);
   DVS_TRY(dvs_pipeline_synchronize(p));
   p->i = 0;
+  p->matched = -1;
+  if (p->comm) DVS_TRY(dvs_comm_reset_sequence(p->comm));   // batch 0 of the next run has no predecessor on rank 0 either
   return DVS_OK;
 }
 

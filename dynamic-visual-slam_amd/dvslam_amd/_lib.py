@@ -124,6 +124,9 @@ def lib():
     L.dvs_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
     L.dvs_comm_create_loopback.argtypes = [i32, i32, C.POINTER(vp)]
     L.dvs_comm_destroy.argtypes = [vp]; L.dvs_comm_destroy.restype = None
+    L.dvs_comm_create_host.argtypes = [i32, i32, vp, vp, C.POINTER(vp)]
+    L.dvs_comm_is_host.argtypes = [vp]
+    L.dvs_comm_reset_sequence.argtypes = [vp]
     L.dvs_comm_rank.argtypes = [vp]
     L.dvs_comm_world.argtypes = [vp]
     L.dvs_comm_rccl_version.restype = i32

@@ -5,12 +5,11 @@ the descriptors of frame r*B - 1, which the previous rank produced as the last f
 the last rank's last frame of the batch before).  One all-gather of the fixed-size block {descriptors[cap x 32], n}
 per global batch; the result for rank 0 comes from the previous call's gather.
 
-Two implementations of the same block layout:
-* `Comm` — the product path: dvs_comm_* / dvs_exchange_boundary of the C-ABI (RCCL ncclAllGather over xGMI on the
-  caller's HIP stream, gather buffers owned by the communicator, nothing allocated per step).  This is what a C++ host
-  calls and what bench.py runs on GPUs.
-* `BoundaryExchanger` / `exchange_boundary` — the torch.distributed test double (gloo in the CPU tests), with the block
-  and the gather buffer preallocated once."""
+ONE implementation — dvs_exchange_boundary of the C-ABI (csrc/comm.hip) — behind two thin ctypes wrappers:
+* `Comm` — RCCL ncclAllGather over xGMI on the caller's HIP stream (or the loopback group), gather buffers owned by the
+  communicator, nothing allocated per step.  This is what a C++ host calls and what bench.py runs on GPUs.
+* `HostComm` — the same C function over a host-transport communicator (dvs_comm_create_host): blocks in host memory, the
+  all-gather is the caller's callback.  The CPU tests drive it from two OS processes with gloo as the transport."""
 import ctypes as C
 import os
 import numpy as np
@@ -39,70 +38,64 @@ def level_shards(level_pixels, world: int):
     return masks
 
 
-def _block_bytes(cap: int) -> int:
-    """descriptors first (so every rank's descriptor rows start 64-byte aligned inside the gathered buffer), then n, padded;
-    = dvs_boundary_block_bytes(cap)"""
-    return (cap * 32 + 4 + 63) // 64 * 64
+class HostComm:
+    """dvs_comm_create_host of the C-ABI: the SAME exchange step (csrc/comm.hip: buffer rotation, this rank's slot, the predecessor with
+    its wrap-around to the previous call) with the blocks in host memory and the caller's all-gather as the transport.  No device is
+    touched, so two OS processes without a GPU run the product's rank logic (tests/test_adapters_and_dist.py: gloo as the transport).
+    `all_gather(buf, rank, nbytes)`: buf is a uint8 numpy view of the whole receive buffer [world * nbytes]; this rank's block already
+    sits at buf[rank * nbytes:(rank + 1) * nbytes]; fill in the others (in place)."""
 
+    def __init__(self, rank: int, world: int, all_gather):
+        from ._lib import lib, check
+        self._L, self._check, self.rank, self.world = lib(), check, rank, world
+        self.error = None
 
-def pack_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """desc_last: [cap, 32] uint8, n_last: int32 scalar / 1-element tensor -> one flat uint8 block (into `out` if given)"""
-    cap = desc_last.shape[0]
-    block = out if out is not None else torch.zeros(_block_bytes(cap), dtype=torch.uint8, device=desc_last.device)
-    block[:cap * 32].copy_(desc_last.reshape(-1))
-    block[cap * 32:cap * 32 + 4].copy_(n_last.reshape(1).to(torch.int32).view(torch.uint8))
-    return block
+        def _cb(user, send, recv, nbytes):
+            try:
+                buf = np.ctypeslib.as_array((C.c_uint8 * (nbytes * world)).from_address(recv))
+                assert send == recv + rank * nbytes, "in-place contract"
+                all_gather(buf, rank, nbytes)
+                return 0
+            except Exception as e:   # noqa: BLE001 — reported through the C-ABI's status, kept for the caller
+                self.error = e
+                return 1
+        self._cb = HOST_ALL_GATHER(_cb)   # (kept alive with the object)
+        h = C.c_void_p()
+        check(self._L.dvs_comm_create_host(rank, world, self._cb, None, C.byref(h)))
+        self.h = h
 
-
-def unpack_boundary(block: torch.Tensor, cap: int):
-    """views into the block: (desc [cap, 32] uint8, n int32 0-dim) — usable in place by the matcher (data_ptr)"""
-    n = block[cap * 32:cap * 32 + 4].view(torch.int32)[0]
-    return block[:cap * 32].view(cap, 32), n
-
-
-class BoundaryExchanger:
-    """torch.distributed form of the exchange step with everything preallocated: the gather buffer [world][block] three times (a
-    call's result points into this call's and the previous call's buffer and stays valid while the next call gathers into the
-    third); this rank packs straight into its slot.  Same contract as dvs_exchange_boundary: called once per global batch with
-    this rank's last frame, returns the predecessor of this rank's FIRST frame — rank r >= 1: rank r - 1's block of this call;
-    rank 0: the last rank's block of the previous call, (None, None) on the first call."""
-
-    def __init__(self, cap: int, device, group=None):
-        self.cap, self.group = cap, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.blk = _block_bytes(cap)
-        self.bufs = [torch.zeros(self.world * self.blk, dtype=torch.uint8, device=device) for _ in range(3)]
-        self.turn = 0
-        self.calls = 0
-
-    def __call__(self, desc_last: torch.Tensor, n_last: torch.Tensor):
-        out = self.bufs[self.turn]
-        prev_out = self.bufs[(self.turn + 2) % 3] if self.calls > 0 else None
-        self.turn = (self.turn + 1) % 3
-        self.calls += 1
-        mine = out[self.rank * self.blk:(self.rank + 1) * self.blk]
-        pack_boundary(desc_last, n_last, mine)
-        if self.world > 1:
-            dist.all_gather_into_tensor(out, mine, group=self.group)
-        if self.rank > 0:
-            return unpack_boundary(out[(self.rank - 1) * self.blk:self.rank * self.blk], self.cap)
-        if prev_out is None:
+    def exchange_boundary(self, desc_last: np.ndarray, n_last: int):
+        """one call per global batch with this rank's LAST frame ([cap, 32] uint8, count) -> (descriptors [cap, 32], count) of the frame
+        before this rank's FIRST frame in the global order — views into the communicator's buffers, valid until the call after next —
+        or (None, None) where the sequence starts"""
+        desc_last = np.ascontiguousarray(desc_last, np.uint8)
+        cap = desc_last.shape[0]
+        n = np.array([n_last], np.int32)
+        pd, pn = C.c_void_p(), C.c_void_p()
+        self._check(self._L.dvs_exchange_boundary(self.h, None, desc_last.ctypes.data, n.ctypes.data, cap, C.byref(pd), C.byref(pn)))
+        if not pd.value:
             return None, None
-        return unpack_boundary(prev_out[(self.world - 1) * self.blk:self.world * self.blk], self.cap)
+        d = np.ctypeslib.as_array((C.c_uint8 * (cap * 32)).from_address(pd.value)).reshape(cap, 32)
+        return d, int(C.c_int32.from_address(pn.value).value)
+
+    def reset_sequence(self):
+        self._check(self._L.dvs_comm_reset_sequence(self.h))
+
+    def close(self):
+        if self.h:
+            self._L.dvs_comm_destroy(self.h)
+            self.h = None
 
 
-_exchangers = {}
+HOST_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
-def exchange_boundary(desc_last: torch.Tensor, n_last: torch.Tensor, cap: int, group=None):
-    """one call per global batch with this rank's last frame; returns (desc, n) of the frame BEFORE this rank's first frame of the
-    batch in the global order (see BoundaryExchanger), (None, None) where the sequence starts"""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    key = (cap, str(desc_last.device), id(group), world)
-    if key not in _exchangers:
-        _exchangers[key] = BoundaryExchanger(cap, desc_last.device, group)
-    return _exchangers[key](desc_last, n_last)
+def gloo_all_gather(group=None):
+    """transport of HostComm over a torch.distributed group (gloo in the CPU tests)"""
+    def fn(buf, rank, nbytes):
+        t = torch.from_numpy(buf)
+        dist.all_gather_into_tensor(t, t[rank * nbytes:(rank + 1) * nbytes].clone(), group=group)
+    return fn
 
 
 class Comm:

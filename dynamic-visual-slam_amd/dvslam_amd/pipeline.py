@@ -35,7 +35,7 @@ class _Ptr:
 
 
 class StreamingPipeline:
-    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=4, pipelined=True, params=(1.2, 8, 20, 7), lanes=0, quadtree_async=0):
+    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=0, pipelined=True, params=(1.2, 8, 20, 7), lanes=0, quadtree_async=0):
         self.L = L = _lib.lib()
         self.B, self.rows, self.cols, self.device, self.nsets, self.pipelined = B, rows, cols, device, nsets, pipelined
         prm = _lib.PipelineParams(_lib.OrbParams(nfeatures, params[0], params[1], params[2], params[3], (C.c_int32 * 7)(*([0] * 7)), B),

@@ -24,7 +24,7 @@ namespace dvslam {
 class StreamingPipeline {
  public:
   StreamingPipeline(int batch, int rows, int cols, int nfeatures = 2000, float scaleFactor = 1.2f, int nlevels = 8, int iniThFAST = 20,
-                    int minThFAST = 7, int device = 0, int nsets = 4, bool pipelined = true, int lanes = 0, int quadtree_async = 0)
+                    int minThFAST = 7, int device = 0, int nsets = 0 /* the library's choice: 4, or two per lane */, bool pipelined = true, int lanes = 0, int quadtree_async = 0)
       : device_(device), batch_(batch) {
     dvs_pipeline_params p;
     std::memset(&p, 0, sizeof(p));

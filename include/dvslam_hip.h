@@ -249,6 +249,17 @@ dvs_status dvs_comm_create(int32_t device, int32_t rank, int32_t world, const ui
  * then pulls the peers' blocks with device-to-device copies behind their events.  Same results as the RCCL communicator. */
 #define DVS_COMM_MAX_LOOPBACK 16
 dvs_status dvs_comm_create_loopback(int32_t device, int32_t world, dvs_comm** out /* [world] */);
+/* Host-transport communicator: the same exchange step for a host that moves the blocks itself (MPI_Allgather, sockets, a
+ * torch.distributed group).  `all_gather(user, send, recv, bytes)` gathers `bytes` from every rank into recv[rank * bytes] on HOST memory
+ * and returns 0 on success; it is called in place (send == recv + this rank's slot).  With such a communicator dvs_exchange_boundary /
+ * dvs_comm_all_gather take and return HOST pointers, ignore `stream`, run synchronously and touch no device: the rank logic — buffer
+ * rotation, this rank's slot, the predecessor with its wrap-around to the previous call — is the code the RCCL communicator runs.
+ * Not accepted by dvs_pipeline_attach_comm (its blocks are device memory). */
+typedef int (*dvs_host_all_gather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+dvs_status dvs_comm_create_host(int32_t rank, int32_t world, dvs_host_all_gather_fn all_gather, void* user, dvs_comm** out);
+int32_t dvs_comm_is_host(const dvs_comm* c);
+/* the next dvs_exchange_boundary starts a new sequence (rank 0: no predecessor).  Call with the streams of earlier calls drained. */
+dvs_status dvs_comm_reset_sequence(dvs_comm* c);
 void dvs_comm_destroy(dvs_comm* c);
 int32_t dvs_comm_rank(const dvs_comm* c);
 int32_t dvs_comm_world(const dvs_comm* c);

@@ -137,6 +137,24 @@ int main() {
     const double er = std::fabs(rvec.at<double>(0, 0)) + std::fabs(rvec.at<double>(1, 0)) + std::fabs(rvec.at<double>(2, 0));
     if (!success || inliers.size() < 120 || inliers.size() > 130 || et > 1e-3 || er > 1e-3) { std::printf("solvePnPRansac: %d, %zu inliers, |dt| %.2e |r| %.2e\n", (int)success, inliers.size(), et, er); return 1; }
     std::printf("dvslam::solvePnPRansac: %zu of 150 inliers\n", inliers.size());
+    // the same scene through a camera that reports plumb_bob coefficients (camera_info's D, frontend.cpp:911-921), here as CV_32F: the
+    // adapter moves the points to distortion-free pixels first and finds the same motion
+    const double Dd[5] = {-0.28, 0.07, 0.0012, -0.0008, 0.004};
+    cv::Mat distf(1, 5, CV_32F);
+    for (int k = 0; k < 5; k++) distf.at<float>(0, k) = (float)Dd[k];
+    std::vector<cv::Point2f> distorted;
+    for (size_t i = 0; i < points2d.size(); i++) {
+      const double x = (points2d[i].x - 320.0) / 600.0, y = (points2d[i].y - 240.0) / 600.0, r2 = x * x + y * y;
+      const double cd = 1 + ((Dd[4] * r2 + Dd[1]) * r2 + Dd[0]) * r2;
+      const double xd = x * cd + 2 * Dd[2] * x * y + Dd[3] * (r2 + 2 * x * x), yd = y * cd + Dd[2] * (r2 + 2 * y * y) + 2 * Dd[3] * x * y;
+      distorted.push_back(cv::Point2f((float)(xd * 600.0 + 320.0), (float)(yd * 600.0 + 240.0)));
+    }
+    cv::Mat rvec2, tvec2;
+    std::vector<int> inliers2;
+    const bool success2 = dvslam::solvePnPRansac(matcher_, points3d, distorted, K, distf, rvec2, tvec2, false, 100, 4.0, 0.99, &inliers2);
+    const double et2 = std::fabs(tvec2.at<double>(0, 0) - 0.04) + std::fabs(tvec2.at<double>(1, 0) + 0.02) + std::fabs(tvec2.at<double>(2, 0) + 0.03);
+    if (!success2 || inliers2.size() < 118 || inliers2.size() > 130 || et2 > 2e-3) { std::printf("solvePnPRansac (distorted): %d, %zu inliers, |dt| %.2e\n", (int)success2, inliers2.size(), et2); return 1; }
+    std::printf("dvslam::solvePnPRansac with D != 0: %zu of 150 inliers\n", inliers2.size());
   }
   std::printf("opencv-typed adapters ok: %d keypoints, BA cost %.3e in %d steps\n", n, result.final_cost, result.iterations_completed);
   return 0;

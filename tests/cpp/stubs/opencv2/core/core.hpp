@@ -12,6 +12,7 @@
 
 typedef unsigned char uchar;   // as opencv2/core/hal/interface.h declares it, in the global namespace
 #define CV_8U 0
+#define CV_32F 5
 #define CV_64F 6
 #define CV_8UC1 0
 #define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
@@ -53,7 +54,7 @@ class Mat {
   template <class T> const T& at(int i) const { return cols == 1 ? at<T>(i, 0) : at<T>(0, i); }
 
  private:
-  size_t esz() const { return type_ == CV_64F ? 8 : 1; }
+  size_t esz() const { return type_ == CV_64F ? 8 : (type_ == CV_32F ? 4 : 1); }
   int type_ = CV_8U;
   std::shared_ptr<std::vector<uint8_t>> buf_;
 };

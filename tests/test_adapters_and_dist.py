@@ -1,6 +1,6 @@
 """C++ adapter headers (include/dvslam/*.hpp) and the multi-rank exchange step.
-CPU: the adapters compile against the C-ABI with plain g++, and the boundary-descriptor exchange of
-dvslam_amd/dist.py is exercised with 2 gloo ranks.  GPU: the compiled adapter program runs end to end."""
+CPU: the adapters compile against the C-ABI with plain g++, and the PRODUCT's boundary-descriptor exchange
+(dvs_exchange_boundary over a host-transport communicator, csrc/comm.hip) runs in 2 and 3 OS processes with gloo as the transport.  GPU: the compiled adapter program runs end to end."""
 import os
 import subprocess
 import sys
@@ -53,6 +53,13 @@ def _build_cpp(tmpdir, src, name):
     return exe
 
 
+def test_undistortion_ahead_of_the_pnp_stage(tmp_path, hiplib):
+    """dvslam::undistortImagePoints (the solvePnPRansac adapter's handling of camera_info's D, frontend.cpp:911-921): pixels distorted with
+    plumb_bob / rational coefficients return to the distortion-free ones to < 0.02 px; host code, no GPU"""
+    out = subprocess.run([_build_cpp(tmp_path, "undistort_roundtrip.cpp", "undistort_roundtrip")], capture_output=True, text=True)
+    assert out.returncode == 0 and "undistort round trip ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_sequential_association_adapter_compiles(tmp_path, hiplib):
     from dvslam_amd import device_count
     assert subprocess.call([_build_cpp(tmp_path, "association_seq.cpp", "association_seq")]) == (0 if device_count() > 0 else 3)
@@ -86,35 +93,53 @@ def test_adapters_run_on_gpu(tmp_path, gpu, hiplib):
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, os.path.join(sys.argv[1], "dynamic-visual-slam_amd"))
+import numpy as np
 import torch, torch.distributed as dist
 from dvslam_amd import dist as dvdist
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 cap = 2024
 assert list(dvdist.shard_range(world, rank, 8)) == list(range(rank * 8, rank * 8 + 8))
-desc = torch.full((cap, 32), 10 + rank, dtype=torch.uint8)
+# the PRODUCT's exchange step (dvs_exchange_boundary in csrc/comm.hip, host-transport communicator): gloo only moves the bytes
+comm = dvdist.HostComm(rank, world, dvdist.gloo_all_gather())
+desc = np.full((cap, 32), 10 + rank, np.uint8)
 desc[5, 7] = 200 + rank
-n = torch.tensor(1900 + rank, dtype=torch.int32)
+n = 1900 + rank
 # one call per global batch with this rank's LAST frame; the result is the frame before this rank's FIRST frame in the global order
-d, m = dvdist.exchange_boundary(desc, n, cap)
+d, m = comm.exchange_boundary(desc, n)
 if rank == 0:
     assert d is None and m is None                     # the sequence starts here
 else:
-    assert int(m) == 1900 + rank - 1 and int(d[0, 0]) == 10 + rank - 1 and int(d[5, 7]) == 200 + rank - 1 and d.shape == (cap, 32)
+    assert m == 1900 + rank - 1 and int(d[0, 0]) == 10 + rank - 1 and int(d[5, 7]) == 200 + rank - 1 and d.shape == (cap, 32)
 # second batch with different payloads: rank r >= 1 sees rank r - 1's block of THIS batch, rank 0 the last rank's of the FIRST batch
-d2, m2 = dvdist.exchange_boundary(desc + 1, n + 7, cap)
+d2, m2 = comm.exchange_boundary(desc + 1, n + 7)
 if rank == 0:
-    assert int(m2) == 1900 + world - 1 and int(d2[0, 0]) == 10 + world - 1 and int(d2[5, 7]) == 200 + world - 1
+    assert m2 == 1900 + world - 1 and int(d2[0, 0]) == 10 + world - 1 and int(d2[5, 7]) == 200 + world - 1
 else:
-    assert int(m2) == 1907 + rank - 1 and int(d2[0, 0]) == 11 + rank - 1
-# third batch: rank 0 now sees the second batch's last block; the first batch's result is still intact (three buffers)
-d3, m3 = dvdist.exchange_boundary(desc + 2, n + 9, cap)
+    assert m2 == 1907 + rank - 1 and int(d2[0, 0]) == 11 + rank - 1
+# third batch: rank 0 now sees the second batch's last block; the second call's result is still intact (three buffers in rotation)
+d3, m3 = comm.exchange_boundary(desc + 2, n + 9)
 if rank == 0:
-    assert int(m3) == 1907 + world - 1 and int(d3[0, 0]) == 11 + world - 1
-    assert int(m2) == 1900 + world - 1 and int(d2[0, 0]) == 10 + world - 1
+    assert m3 == 1907 + world - 1 and int(d3[0, 0]) == 11 + world - 1
+    assert int(d2[0, 0]) == 10 + world - 1 and int(d2[5, 7]) == 200 + world - 1
 else:
-    assert int(m3) == 1909 + rank - 1 and int(d3[0, 0]) == 12 + rank - 1
-    assert int(m2) == 1907 + rank - 1 and int(d2[0, 0]) == 11 + rank - 1
+    assert m3 == 1909 + rank - 1 and int(d3[0, 0]) == 12 + rank - 1
+    assert int(d2[0, 0]) == 11 + rank - 1
+# a fourth call overwrites the buffer of the first: the rotation has three
+d4, m4 = comm.exchange_boundary(desc + 3, n + 11)
+assert (m4 == 1909 + world - 1) if rank == 0 else (m4 == 1911 + rank - 1)
+# a new sequence (dvs_pipeline_reset's path): rank 0 has no predecessor again, the others see THIS call's blocks
+comm.reset_sequence()
+d5, m5 = comm.exchange_boundary(desc + 4, n + 13)
+if rank == 0:
+    assert d5 is None and m5 is None
+else:
+    assert m5 == 1913 + rank - 1 and int(d5[0, 0]) == 14 + rank - 1
+# another capacity: the buffers are re-made and the sequence restarts
+small = np.full((64, 32), 50 + rank, np.uint8)
+d6, m6 = comm.exchange_boundary(small, 60 + rank)
+assert (d6 is None) if rank == 0 else (m6 == 60 + rank - 1 and d6.shape == (64, 32) and int(d6[63, 31]) == 50 + rank - 1)
+comm.close()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -135,14 +160,40 @@ def test_boundary_exchange_two_gloo_ranks(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
-def test_single_rank_exchange_returns_the_previous_batch():
-    import torch
-    from dvslam_amd import dist as dvdist
-    desc = torch.arange(64 * 32, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(64, 32)
-    d, n = dvdist.exchange_boundary(desc, torch.tensor(17, dtype=torch.int32), 64)
+def test_boundary_exchange_three_gloo_ranks(tmp_path):
+    """an odd world: rank 1 and rank 2 both read a neighbour's block of the same call, rank 0 wraps to rank 2's of the call before"""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 3
+
+
+def test_single_rank_host_exchange_returns_the_previous_batch():
+    """one rank, host transport (the callback has nothing to move): its own last frame of the batch before; a failing transport surfaces
+    as an error of the C-ABI call, and the pipeline refuses a host-transport communicator"""
+    from dvslam_amd import dist as dvdist, DvsError
+    comm = dvdist.HostComm(0, 1, lambda buf, rank, nbytes: None)
+    desc = (np.arange(64 * 32) % 251).astype(np.uint8).reshape(64, 32)
+    d, n = comm.exchange_boundary(desc, 17)
     assert d is None and n is None                                     # first batch: no predecessor
-    d, n = dvdist.exchange_boundary(desc + 1, torch.tensor(18, dtype=torch.int32), 64)
-    assert int(n) == 17 and torch.equal(d, desc)                       # one rank: its own last frame of the batch before
+    d, n = comm.exchange_boundary(desc + 1, 18)
+    assert n == 17 and (d == desc).all()                               # one rank: its own last frame of the batch before
+    comm.close()
+
+    def broken(buf, rank, nbytes):
+        raise RuntimeError("link down")
+    bad = dvdist.HostComm(0, 1, broken)
+    with pytest.raises(DvsError):
+        bad.exchange_boundary(desc, 1)
+    assert isinstance(bad.error, RuntimeError)
+    bad.close()
 
 
 def test_level_shards_cover_every_level_once():
@@ -181,13 +232,12 @@ def test_bench_self_launch_spawns_the_ranks():
 
 
 def test_comm_c_abi_refuses_without_gpu(hiplib):
-    """the RCCL exchange behind the C-ABI: symbols exist, the block layout equals dist.py's, and without a device
-    dvs_comm_create says DVS_ERR_NO_DEVICE instead of falling back to anything"""
+    """the RCCL exchange behind the C-ABI: symbols exist, the block is {cap x 32 descriptor bytes, int32 count} padded to 64 bytes, and
+    without a device dvs_comm_create says DVS_ERR_NO_DEVICE instead of falling back to anything"""
     import ctypes as C
     from dvslam_amd import device_count
-    from dvslam_amd import dist as dvdist
     for cap in (1, 500, 2024, 3024):
-        assert hiplib.dvs_boundary_block_bytes(cap) == dvdist._block_bytes(cap)
+        assert hiplib.dvs_boundary_block_bytes(cap) == (cap * 32 + 4 + 63) // 64 * 64
     if device_count() == 0:
         h = C.c_void_p()
         ident = (C.c_uint8 * 128)()

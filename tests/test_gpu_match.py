@@ -155,7 +155,7 @@ def test_batch_device_matrix_core(gpu, oracle):
     dq = DeviceBuffer(Q.nbytes).upload(Q); dt = DeviceBuffer(T.nbytes).upload(T)
     dnq = DeviceBuffer(P * 4).upload(nq); dnt = DeviceBuffer(P * 4).upload(nt)
     di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
-    for rep in range(2):   # second call: the expanded images are rebuilt in the same buffers
+    for rep in range(2):   # second call: same buffers, same results
         m.match_batch_device(dq.ptr, dnq.ptr, S, dt.ptr, dnt.ptr, S, P, di.ptr, dd.ptr)
         m.synchronize()
         idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
@@ -164,8 +164,38 @@ def test_batch_device_matrix_core(gpu, oracle):
             assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (rep, p)
 
 
+def test_matrix_core_extreme_popcounts_and_unaligned_bases(gpu, oracle):
+    """rows of 0 and 256 set bits (the ninth k-step carries -64 |t| per train row: both ends of its range), rows that differ in one bit,
+    and descriptor bases that are not 16-byte aligned (those jobs take the popcount kernel): all against the oracle"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    P, S = 9, 2024
+    rng = np.random.Generator(np.random.PCG64(77))
+    Q = rng.integers(0, 256, size=(P, S, 32), dtype=np.uint8); T = rng.integers(0, 256, size=(P, S, 32), dtype=np.uint8)
+    Q[0, ::3] = 0; Q[0, 1::3] = 255; T[0, ::5] = 0; T[0, 2::5] = 255
+    T[1, :] = 255; T[1, 1000, 31] = 0x7F                      # all ones but one bit in one row
+    T[2, :] = 0; T[2, 77, 0] = 1; Q[2, :] = 0
+    Q[3, :] = 255; T[3, :] = 255                               # every distance 0: index 0 must win everywhere
+    T[4] = Q[4][::-1]                                          # a permutation: every query has an exact twin
+    nq = np.full(P, S, np.int32); nt = np.full(P, S, np.int32); nt[5] = 1; nq[6] = 31
+    pad = 8
+    dq = DeviceBuffer(Q.nbytes + pad); dt = DeviceBuffer(T.nbytes + pad)
+    dnq = DeviceBuffer(P * 4).upload(nq); dnt = DeviceBuffer(P * 4).upload(nt)
+    di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
+    for off in (0, pad):
+        dq.upload(np.concatenate([np.zeros(off, np.uint8), Q.reshape(-1)])); dt.upload(np.concatenate([np.zeros(off, np.uint8), T.reshape(-1)]))
+        m.match_batch_device(dq.ptr + off, dnq.ptr, S, dt.ptr + off, dnt.ptr, S, P, di.ptr, dd.ptr)
+        m.synchronize()
+        idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
+        for p in range(P):
+            i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
+            assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (off, p)
+    assert (idx[3] == 0).all() and (d[3] == 0).all() and (d[4] == 0).all()
+
+
 def test_sequence_device_matrix_core(gpu, oracle):
-    """the bench's shape on the MFMA kernel: frames of up to 2024 descriptors, frame p against p - 1 (expanded once, used in
+    """the bench's shape on the MFMA kernel: frames of up to 2024 descriptors, frame p against p - 1 (every set used in
     both roles), frame 0 against a predecessor elsewhere or against nothing"""
     from dvslam_amd import BFMatcher
     from dvslam_amd._lib import DeviceBuffer

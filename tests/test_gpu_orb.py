@@ -89,6 +89,23 @@ def test_threshold_fallback_cells(gpu, oracle):
     assert (r[1]["response"] < 20).any() and r[0] > 100
 
 
+@pytest.mark.parametrize("ini,mn", [(5, 12), (20, 20), (40, 3), (7, 20)])
+@pytest.mark.parametrize("cols", [640, 643])   # aligned rows: k_fast_wave; odd width: k_fast_cell
+def test_threshold_orders_follow_the_two_literal_calls(gpu, oracle, ini, mn, cols):
+    """cv::FAST at iniThFAST, then — only for a cell left empty — at minThFAST, whatever the order of the two numbers
+    (ORBextractor.cpp:826-846): with minTh > iniTh the second call can only find a subset of nothing"""
+    from dvslam_amd import ORBextractor
+    img = synth.make_frame(3, cols=cols, rows=480)
+    low = (100 + (img.astype(np.int32) - 128) // 3).astype(np.uint8)
+    for im in (img, low):
+        g = ORBextractor(600, 1.2, 6, ini, mn); o = oracle.OracleORB(600, 1.2, 6, ini, mn)
+        r = g(im); r2 = o.extract(im)
+        for l in range(6):
+            assert len(g.candidates(l)) == len(o.candidates(l)) and (g.candidates(l) == o.candidates(l)).all(), f"candidates level {l}"
+        _assert_same_result(*r, *r2)
+        g.close()
+
+
 def test_noncontiguous_step_and_repeat_determinism(gpu, oracle):
     big = np.zeros((480, 700), np.uint8)
     img = synth.make_frame(2, cols=640, rows=480)
