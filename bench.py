@@ -322,6 +322,140 @@ def oracle_check(synth, pipe, batch_of_step, rows, cols, nfeatures, sample=(0, 1
     return {"frames": len(frames), "match_jobs": jobs, "result": "identical to the oracle" if not bad else "MISMATCH: " + ", ".join(bad)}
 
 
+def frame_seed(batch_index, NB, rank):
+    """seed of the scene that rank `rank` extracts in step `batch_index` (make_batches: one scene per (rank, resident batch))"""
+    return 1234 + 101 * (batch_index % NB) + 7 * rank
+
+
+def boundary_predecessor(rank, world, j):
+    """(rank, batch) whose LAST frame precedes this rank's frame 0 of batch j in the global frame order — what dvs_exchange_boundary must
+    have delivered: the previous rank's block of the same call, or for rank 0 the last rank's block of the call before (None: the
+    sequence starts there).  The reference's analogue is prev_descriptors_ of frontend.cpp:1096-1132."""
+    if rank > 0:
+        return rank - 1, j
+    return (world - 1, j - 1) if j >= 1 else None
+
+
+def boundary_verdict(synth, pipe, rank, world, NB, rows, cols, nfeatures, j):
+    """N > 1 self-check, run on EVERY rank after the timed region: match job 0 of batch j — the only job that depends on the all-gather —
+    against the oracle's match of this rank's own frame-0 descriptors with the ORACLE's extraction of the predecessor frame, which every
+    rank can synthesise from the seeds.  Never raises: a failure is a verdict."""
+    try:
+        import oracle_bindings as ob
+        nj, _, dj = pipe.outputs(j)
+        idx, dst = pipe.matches(j)
+        nq = int(nj[0])
+        pred = boundary_predecessor(rank, world, j)
+        if pred is None:
+            ok = bool((idx[0, :nq] == -1).all())
+            return {"rank": rank, "ok": ok, "batch": j, "queries": nq, "train": 0, "predecessor": None}
+        pr, pb = pred
+        frame = synth.make_frame(pipe.B - 1, cols, rows, seed=frame_seed(pb, NB, pr))
+        n2, _, d2 = ob.OracleORB(nfeatures, 1.2, 8, 20, 7).extract(frame)
+        i2, dd2 = ob.match(dj[0, :nq], d2)
+        ok = bool((idx[0, :nq] == i2).all() and (dst[0, :nq] == dd2).all())
+        return {"rank": rank, "ok": ok, "batch": j, "queries": nq, "train": int(n2), "predecessor": {"rank": pr, "batch": pb}}
+    except Exception as e:   # noqa: BLE001
+        return {"rank": rank, "ok": False, "error": repr(e)}
+
+
+def rccl_report(world, version, transport, verdicts, block_bytes, allgather_us):
+    """the `rccl` object of the result line: every rank's boundary verdict, gathered on rank 0"""
+    bad = [v for v in verdicts if not v.get("ok")]
+    return {"nranks": world, "version": version, "transport": transport,
+            "exchange": "dvs_exchange_boundary: one in-place all-gather of the ranks' last-frame blocks per global batch, behind the C-ABI",
+            "boundary_check": {"ranks_checked": len(verdicts), "job": "frame 0 of the last matched batch against the predecessor the exchange delivered, "
+                                                                      "vs the oracle on the oracle's extraction of that predecessor frame",
+                               "result": "identical to the oracle on every rank" if not bad else
+                                         "MISMATCH on rank(s) " + ", ".join(str(v.get("rank")) for v in bad),
+                               "per_rank": verdicts},
+            "allgather_bytes": int(world * block_bytes), "allgather_us": allgather_us}
+
+
+def time_exchange(pipe, comm, stream_sync, reps=20):
+    """wall time of one dvs_exchange_boundary (pack + all-gather, nothing else on the GPU), after the timed region; collective: every rank
+    makes the same calls"""
+    s = (pipe.i - 1) % pipe.nsets
+    pd, pn = pipe._last(s)
+    for _ in range(3):
+        comm.exchange_boundary(pipe.M or pipe.T, pd, pn, pipe.cap)
+    stream_sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        comm.exchange_boundary(pipe.M or pipe.T, pd, pn, pipe.cap)
+    stream_sync()
+    return round((time.perf_counter() - t0) / reps * 1e6, 1)
+
+
+def loopback_bench(args):
+    """`--loopback N`: the frame-sharded step of N ranks on ONE GPU — N pipelines, each driven by its own host thread, joined by the loopback
+    communicator (same dvs_exchange_boundary, a host rendezvous + device-to-device pulls in RCCL's place).  A rehearsal of the N > 1
+    code path (sharding, exchange, the boundary self-check and its report), not a measurement: the line says DIAGNOSTIC."""
+    import threading
+    _stdout_to_stderr()
+    import torch
+    from dvslam_amd import synth
+    from dvslam_amd import dist as dvdist
+    from dvslam_amd.pipeline import StreamingPipeline
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    N, rows, cols = args.loopback, 720, 1280
+    assert args.global_batch % N == 0
+    B = args.global_batch // N
+    NB = min(2, max(1, args.resident_batches))
+    dev = torch.device("cuda", 0)
+    imgs = []
+    for r in range(N):
+        d, _ = make_batches(synth, torch, dev, B, NB, r, rows, cols, True)
+        imgs.append(d)
+    pipes = [StreamingPipeline(B, rows, cols, args.nfeatures, device=0, nsets=args.nsets, pipelined=args.pipelined, lanes=args.lanes,
+                               quadtree_async=args.quadtree_async) for _ in range(N)]
+    comms = dvdist.Comm.loopback(0, N)
+    for p_, c_ in zip(pipes, comms):
+        p_.attach_comm(c_)
+    torch.cuda.synchronize()
+    gate = threading.Barrier(N)
+    elapsed, ag_us, verdicts, errors = [0.0] * N, [None] * N, [None] * N, []
+
+    def run(r):
+        try:
+            pipe, img = pipes[r], [imgs[r][k].data_ptr() for k in range(NB)]
+            for _ in range(args.warmup):
+                pipe.step(img[pipe.i % NB], img[(pipe.i + 1) % NB])
+            pipe.synchronize(); gate.wait()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.step(img[pipe.i % NB], img[(pipe.i + 1) % NB])
+            pipe.synchronize(); gate.wait()
+            elapsed[r] = time.perf_counter() - t0
+            ag_us[r] = time_exchange(pipe, comms[r], pipe.synchronize, reps=5)
+            jb = pipe.i - 2 if args.pipelined else pipe.i - 1
+            verdicts[r] = boundary_verdict(synth, pipe, r, N, NB, rows, cols, args.nfeatures, jb)
+        except Exception as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+            gate.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(N)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    el = max(elapsed)
+    cap = pipes[0].cap
+    rep_ = rccl_report(N, 0, "loopback group (dvs_comm_create_loopback): host rendezvous + device-to-device pulls in RCCL's place",
+                       [v if v is not None else {"rank": r, "ok": False, "error": "rank did not finish"} for r, v in enumerate(verdicts)],
+                       pipes[0].L.dvs_boundary_block_bytes(cap), max([u for u in ag_us if u is not None], default=None))
+    out = {"metric": "DIAGNOSTIC (loopback rehearsal: N logical ranks on ONE GPU) frames/sec ORB+match @1280x720x2000kp",
+           "diagnostic": "not a scaling result: the ranks share one GPU; what it rehearses is the N > 1 code path and its self-check",
+           "value": round(N * B * args.steps / el, 2) if el > 0 else 0.0, "unit": "frames/s", "n_gpus": 1, "logical_ranks": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * el / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+           "data": "synthetic", "config": {"workload": f"{args.global_batch} frame pairs per step over {N} logical ranks ({B} each), 1280x720, 2000 kp",
+                                           "frames_per_rank_per_step": B}, "rccl": rep_, "errors": errors}
+    for c_ in comms:
+        c_.close()
+    _emit(out)
+    if "MISMATCH" in rep_["boundary_check"]["result"] or errors:
+        print(f"[bench] WARNING: loopback rehearsal: {rep_['boundary_check']['result']} {errors}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,6 +484,8 @@ def main():
                     help="levels: SURVEY.md section 8e's small-batch mode (use with --batch < 8): every rank holds the same frames, extracts its "
                          "own pyramid levels, one all-gather of level-slotted blocks, on-device merge; total work fixed (strong scaling)")
     ap.add_argument("--trace-steps", action="store_true", help="diagnostics: also print the time between consecutive steps of the timed region (stderr)")
+    ap.add_argument("--loopback", type=int, default=0, help="rehearsal of the N > 1 path on ONE GPU: N logical ranks of this process "
+                    "(dvs_comm_create_loopback, a host thread each), --global-batch frames split over them; prints a DIAGNOSTIC line with the same `rccl` object")
     ap.add_argument("--dry-launch", action="store_true", help="only start the ranks and report them (no GPU work): launcher self-test")
     args = ap.parse_args()
 
@@ -360,8 +496,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.dry_launch:
-        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local, "pid": os.getpid()}), flush=True)
+        # (also what the N > 1 self-check would look at on this rank, and the keys of the `rccl` object it fills: no GPU work)
+        _emit({"dry_launch": True, "rank": rank, "world": world, "local_rank": local, "pid": os.getpid(),   # (one write: the ranks share a pipe)
+               "boundary_predecessor": {"batch5": boundary_predecessor(rank, world, 5), "batch0": boundary_predecessor(rank, world, 0)},
+               "rccl_keys": sorted(rccl_report(world, 0, "dry launch", [{"rank": rank, "ok": True}], 64, None))})
         return
+    if args.loopback >= 2:
+        return loopback_bench(args)
 
     _stdout_to_stderr()
     import torch
@@ -405,7 +546,7 @@ def main():
             return box[0]
         comm = dvdist.Comm(local, rank, world, bcast_id)
         pipe.attach_comm(comm)
-        rccl = {"nranks": world, "version": comm.rccl_version, "exchange": "dvs_exchange_boundary: ncclAllGather behind the C-ABI"}
+        rccl = {"nranks": world, "version": comm.rccl_version, "exchange": "dvs_exchange_boundary: ncclAllGather behind the C-ABI"}   # (completed after the run)
         print(f"[bench] rank {rank}: RCCL communicator of {world} ranks (version {comm.rccl_version})", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
 
@@ -479,6 +620,28 @@ def main():
 
     # checks of what was just timed (outside the timed region)
     match_check = ocheck = None
+    if comm is not None:
+        # N > 1 — and one rank under the launcher, a real 1-rank RCCL: EVERY rank checks the one match job that depends on the all-gather
+        # (frame 0 of a batch against the predecessor dvs_exchange_boundary delivered) against the oracle, rank 0 gathers the verdicts.
+        # A mismatch prints loudly and never loses the result line.
+        ag_us = None
+        try:
+            ag_us = time_exchange(pipe, comm, lambda: (pipe.synchronize(), torch.cuda.synchronize()))
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] rank {rank}: timing the exchange failed: {e!r}", file=sys.stderr, flush=True)
+        jb = pipe.i - 2 if args.pipelined else pipe.i - 1
+        verdict = (boundary_verdict(synth, pipe, rank, world, NB, rows, cols, args.nfeatures, jb) if jb >= 0 else
+                   {"rank": rank, "ok": False, "error": "no matched batch to check"})
+        verdicts = [verdict]
+        try:
+            box = [None] * world
+            dist.all_gather_object(box, verdict)
+            verdicts = box
+        except Exception as e:   # noqa: BLE001
+            verdicts = [dict(verdict, gather_error=repr(e))]
+        rccl = rccl_report(world, comm.rccl_version, "RCCL ncclAllGather (dlopen'ed librccl.so.1)", verdicts, pipe.L.dvs_boundary_block_bytes(cap), ag_us)
+        if rank == 0 and "MISMATCH" in rccl["boundary_check"]["result"]:
+            print(f"[bench] WARNING: boundary check: {rccl['boundary_check']['result']}: {verdicts}", file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_bindings as ob
         ob.use_native()   # the CPU baseline below times a -O2 -march=native build made here; it must be selected before the first oracle call

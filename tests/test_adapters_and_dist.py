@@ -1,6 +1,7 @@
 """C++ adapter headers (include/dvslam/*.hpp) and the multi-rank exchange step.
 CPU: the adapters compile against the C-ABI with plain g++, and the PRODUCT's boundary-descriptor exchange
 (dvs_exchange_boundary over a host-transport communicator, csrc/comm.hip) runs in 2 and 3 OS processes with gloo as the transport.  GPU: the compiled adapter program runs end to end."""
+import json
 import os
 import subprocess
 import sys
@@ -224,11 +225,32 @@ def test_bench_self_launch_spawns_the_ranks():
     ranks = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert sorted(r["rank"] for r in ranks) == [0, 1] and all(r["world"] == 2 and r["dry_launch"] for r in ranks)
     assert len({r["pid"] for r in ranks}) == 2
+    # what the N > 1 self-check looks at: rank 1 reads rank 0's block of the same call, rank 0 wraps to the LAST rank's of the call before
+    # (nothing at the start of a sequence); and the keys of the `rccl` object of the result line
+    by = {r["rank"]: r for r in ranks}
+    assert by[1]["boundary_predecessor"] == {"batch5": [0, 5], "batch0": [0, 0]}
+    assert by[0]["boundary_predecessor"] == {"batch5": [1, 4], "batch0": None}
+    assert {"nranks", "version", "transport", "exchange", "boundary_check", "allgather_bytes", "allgather_us"} <= set(by[0]["rccl_keys"])
     # under a launcher (the driver's form) the same file must NOT spawn again: it reads RANK / WORLD_SIZE from the environment
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-launch"], capture_output=True, text=True,
                          env=env2, timeout=120)
     assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_bench_rccl_report_shape():
+    """bench.py's `rccl` object: one verdict per rank, a mismatch named by rank, never an exception"""
+    sys.path.insert(0, ROOT)
+    import bench
+    ok = [{"rank": r, "ok": True, "batch": 23, "queries": 2000, "train": 1990, "predecessor": {"rank": (r - 1) % 8, "batch": 23 - (r == 0)}} for r in range(8)]
+    rep = bench.rccl_report(8, 22304, "RCCL", ok, 64832, 41.5)
+    assert rep["nranks"] == 8 and rep["allgather_bytes"] == 8 * 64832 and rep["allgather_us"] == 41.5
+    assert rep["boundary_check"]["ranks_checked"] == 8 and rep["boundary_check"]["result"] == "identical to the oracle on every rank"
+    bad = [dict(v) for v in ok]; bad[3]["ok"] = False; bad[0] = {"rank": 0, "ok": False, "error": "boom"}
+    assert bench.rccl_report(8, 22304, "RCCL", bad, 64832, None)["boundary_check"]["result"] == "MISMATCH on rank(s) 0, 3"
+    assert [bench.boundary_predecessor(r, 8, 0) for r in (0, 1, 7)] == [None, (0, 0), (6, 0)]
+    assert bench.boundary_predecessor(0, 8, 9) == (7, 8) and bench.frame_seed(9, 6, 7) == 1234 + 101 * 3 + 49
+    json.dumps(rep)
 
 
 def test_comm_c_abi_refuses_without_gpu(hiplib):
