@@ -874,6 +874,11 @@ __global__ __launch_bounds__(256) void k_fast_wave(const Geom* __restrict__ g, c
     // the four sign bytes (bytes 1 and 3 of either half) side by side: bit 8 j + 7 = pixel j passes; gated by the lane's column
     // mask (the cell's last trip: cut down to the rows that exist)
     const uint32_t m4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (row0 + rpt >= ih ? cmTail : cmLane);
+#ifndef DVS_EXP_NO_EMPTY_TRIP_SKIP
+    // a trip without a survivor (23 % of them at iniTh = 20 on the benchmark's frames: flat regions under sensor noise) skips the
+    // count, the prefix sum and the four conditional stores
+    if (__builtin_amdgcn_ballot_w64(m4 != 0u) == 0ull) continue;
+#endif
     const int cnt = __popc(m4);
     const int incl = wave_incl_scan_dpp(cnt);
     // the four conditional stores, by hand: per pixel ONE compare (SDWA picks the pixel's byte) and ONE add — the running address,

@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B/... of (library, environment) pairs on one box, alternating: tools/ab_mixed.sh <repeats> "<so or -> [NAME=V ...]" ...
+# A/B/... of (library, environment) pairs on one box, alternating: tools/ab_mixed.sh <repeats> "<so or -> [NAME=V ...]" ...   (BENCH_ARGS: extra bench.py flags)
 n=$1; shift
 for i in $(seq $n); do
   for spec in "$@"; do
-    set -- $spec_dummy
     so=$(echo $spec | cut -d' ' -f1); envs=$(echo $spec | cut -s -d' ' -f2-)
     p=$so; [ "$so" = "-" ] && p=""
     env DVSLAM_HIP_SO=$p $envs python3 bench.py --no-cpu-baseline ${BENCH_ARGS} 2>/dev/null | python3 -c "
