@@ -635,8 +635,11 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
     }
     d_prev_desc = (const uint8_t*)m->d_zero; d_prev_n = (const int32_t*)m->d_zero;
   }
-  static const long long exp_min_rows = getenv("DVS_EXP_MFMA_MIN_ROWS") ? atoll(getenv("DVS_EXP_MFMA_MIN_ROWS")) : 16384;   // EXPERIMENT (round 5)
-  if (m->use_mfma && (long long)nframes * stride_rows > exp_min_rows && (((uintptr_t)d_desc | (uintptr_t)d_prev_desc) & 15) == 0) {
+  // from 7 frames of 2 000 descriptors on (the four-stream schedule's match stream; up to 6 frames a lane matches from LDS, k_match_lds):
+  // with the operands built in the kernel the matrix-core match needs no second launch and wins earlier than rounds 2-4's 16 384 rows
+  // (8 frames per step 82.2 -> 90 k frames/s, 7: 77.2 -> 81.5 k; 6 frames on a lane: no gain)
+  constexpr long long kMfmaMinRows = 14000;
+  if (m->use_mfma && (long long)nframes * stride_rows > kMfmaMinRows && (((uintptr_t)d_desc | (uintptr_t)d_prev_desc) & 15) == 0) {
     // job p = frame p against frame p - 1 (job 0: the predecessor block): train base shifted back by one frame, never dereferenced for job 0
     hipLaunchKernelGGL(k_match_mfma<2>, dim3((stride_rows + 255) / 256, nframes), dim3(256), 0, m->stream, d_desc, d_n, stride_rows,
                        d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, d_idx, d_dist);
