@@ -1362,6 +1362,7 @@ dvs_status dvs_ba_solve(dvs_ba* h, int32_t max_iterations, double ftol, double g
   DVS_ARG(h && summary && max_iterations >= 0);
   memset(summary, 0, sizeof(*summary));
   summary->termination = 2;
+  summary->linear_solver = 2;   // reduced camera system + Cholesky on the HOST (this entry point)
   DVS_HIP(hipSetDevice(h->device));
   const int K = h->K, L = h->L, R = h->R, NT = 6 * K + 3 * L;
   if (R == 0) { set_error("no observations"); return DVS_ERR_ARG; }
@@ -1555,6 +1556,7 @@ dvs_status dvs_ba_solve_device(dvs_ba* h, int32_t max_iterations, double ftol, d
   DVS_ARG(h && summary && max_iterations >= 0);
   memset(summary, 0, sizeof(*summary));
   summary->termination = 2;
+  summary->linear_solver = 1;   // linear algebra on the DEVICE
   DVS_HIP(hipSetDevice(h->device));
   const int K = h->K, L = h->L, R = h->R, NT = 6 * K + 3 * L;
   if (R == 0) { set_error("no observations"); return DVS_ERR_ARG; }

@@ -41,7 +41,7 @@ class KeyframeHeader(C.Structure):
 
 class BaSummary(C.Structure):
     _fields_ = [("termination", C.c_int32), ("num_successful_steps", C.c_int32), ("num_iterations", C.c_int32),
-                ("reserved", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+                ("linear_solver", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double)]
 
 
 def build_library():

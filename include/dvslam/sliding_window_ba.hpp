@@ -16,6 +16,7 @@
 #pragma once
 #include <array>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -71,6 +72,8 @@ class BaEngine {
   ~BaEngine() { dvs_ba_destroy(h_); }
   BaEngine(const BaEngine&) = delete;
   BaEngine& operator=(const BaEngine&) = delete;
+  bool warned_host_solver = false;   // the fall-back to host linear algebra announces itself once per object
+  int last_linear_solver = 0;        // dvs_ba_summary::linear_solver of the last optimize(): 1 = device, 2 = host, 0 = none ran
   dvs_ba* get() {
     if (!h_ && dvs_ba_create(device_, &h_) != DVS_OK) h_ = nullptr;
     return h_;
@@ -148,9 +151,19 @@ typename Traits::Result optimize_impl(BaEngine& eng, const Intrinsics& K_, const
                                lm_fixed.data(), K_.fx, K_.fy, K_.cx, K_.cy, K_.sigma, 1.345) == DVS_OK;
   if (ok) {  // linear algebra on the device for sliding-window shapes, GPU evaluation + host Schur complement otherwise
     dvs_status st = dvs_ba_solve_device(h, max_iterations, 1e-6, 1e-10, 1e-8, &s);
-    if (st == DVS_ERR_UNSUPPORTED) st = dvs_ba_solve(h, max_iterations, 1e-6, 1e-10, 1e-8, &s);
+    if (st == DVS_ERR_UNSUPPORTED) {
+      // NOT silent: the device solver takes windows of up to 16 free keyframes (the reference's live window is 5-10,
+      // backend.cpp:895); a larger one still optimises — GPU evaluation, normal equations on the host, ~40x slower per solve — and says so
+      // once per object on stderr, in last_linear_solver() and in dvs_ba_summary::linear_solver
+      if (!eng.warned_host_solver) {
+        std::fprintf(stderr, "dvslam::SlidingWindowBA: %s — solving the normal equations on the host for this window\n", dvs_last_error());
+        eng.warned_host_solver = true;
+      }
+      st = dvs_ba_solve(h, max_iterations, 1e-6, 1e-10, 1e-8, &s);
+    }
     ok = st == DVS_OK;
   }
+  eng.last_linear_solver = ok ? s.linear_solver : 0;
   if (!ok) {  // the reference never throws: exceptions become success=false + message (:890-895)
     res.message = std::string("Bundle adjustment exception: ") + dvs_last_error();
     res.optimization_time = elapsed();
@@ -196,6 +209,8 @@ class SlidingWindowBA {
                               const std::vector<Observation>& observations, int max_iterations = 10) {
     return detail::optimize_impl<detail::PlainTraits>(eng_, k_, keyframes, landmarks, observations, max_iterations);
   }
+  // (not in the reference) who solved the normal equations of the last optimize(): 1 = the device, 2 = the host (> 16 free keyframes), 0 = nobody
+  int last_linear_solver() const { return eng_.last_linear_solver; }
 
  private:
   detail::Intrinsics k_;

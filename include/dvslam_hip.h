@@ -509,7 +509,7 @@ typedef struct dvs_ba_summary {
   int32_t termination;          /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE (ceres::TerminationType order) */
   int32_t num_successful_steps; /* OptimizationResult::iterations_completed (bundle_adjustment.hpp:862) */
   int32_t num_iterations;
-  int32_t reserved;
+  int32_t linear_solver;        /* who solved the normal equations: 1 = the device (dvs_ba_solve_device), 2 = the host (dvs_ba_solve) */
   double initial_cost, final_cost;
 } dvs_ba_summary;
 

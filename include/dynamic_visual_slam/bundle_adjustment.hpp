@@ -75,6 +75,8 @@ class SlidingWindowBA {  // (:652-904)
                               const std::vector<Observation>& observations, int max_iterations = 10) {
     return dvslam::detail::optimize_impl<CvTraits>(eng_, k_, keyframes, landmarks, observations, max_iterations);
   }
+  // (not in the reference) who solved the normal equations of the last optimize(): 1 = the device, 2 = the host (> 16 free keyframes), 0 = nobody
+  int last_linear_solver() const { return eng_.last_linear_solver; }
 
  private:
   struct CvTraits {

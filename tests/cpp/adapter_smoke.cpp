@@ -43,5 +43,21 @@ int main() {
   dvslam::OptimizationResult r = ba.optimize(kf, lms, obs, 10);
   std::printf("orb %d keypoints; BA success=%d cost=%.3e msg=%s\n", n, (int)r.success, r.final_cost, r.message.c_str());
   if (!r.success || r.final_cost > 1e-12 || r.optimized_poses.size() != 2 || r.optimized_landmarks.size() != 30) return 1;
+  if (ba.last_linear_solver() != 1) { std::printf("a 2-keyframe window must run on the device solver, got %d\n", ba.last_linear_solver()); return 1; }
+  // a window beyond the device solver's 16 free keyframes (the reference accepts any window, bundle_adjustment.hpp:737-898): it still
+  // optimises — normal equations on the host — and says so: once on stderr and in last_linear_solver()
+  std::vector<dvslam::KeyframeData> kf20;
+  std::vector<dvslam::Observation> obs20;
+  for (int c = 0; c < 20; c++) {
+    const double tc[3] = {-0.05 * c, 0, 0};   // world -> camera translation of a camera at x = 0.05 c (the smoke test's convention: I, t)
+    kf20.emplace_back(100 + c, I, tc);
+    for (int i = 0; i < 30; i++) {
+      const double X = -1.0 + 0.07 * i, Y = 0.5 * std::sin(0.7 * i), Z = 3.0 + 0.05 * i;
+      obs20.emplace_back(900 * (X - 0.05 * c) / Z + 640 + 0.3 * std::sin(1.3 * i + c), 900 * Y / Z + 360 + 0.3 * std::cos(0.9 * i + 2 * c), 100 + i, "unlabeled", 100 + c);
+    }
+  }
+  dvslam::OptimizationResult r20 = ba.optimize(kf20, lms, obs20, 10);
+  std::printf("BA 20 keyframes: success=%d cost=%.3e solver=%d msg=%s\n", (int)r20.success, r20.final_cost, ba.last_linear_solver(), r20.message.c_str());
+  if (r20.optimized_poses.size() != 20 || ba.last_linear_solver() != 2 || !(r20.final_cost < 30.0)) return 1;
   return 0;
 }

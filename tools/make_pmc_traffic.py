@@ -12,7 +12,7 @@ src = sys.argv[1]
 rows = [r for r in csv.reader(l for l in open(src) if not l.startswith("#"))]
 hdr = rows[0]
 fi, wi, vi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE"), hdr.index("SQ_INSTS_VALU")
-stage = {"k_resize4": "pyramid", "k_fast_wave": "fast", "k_octree": "octree", "k_blur_stream": "blur", "k_describe": "describe", "k_match": "match", "k_expand_desc": "match"}
+stage = {"k_resize4": "pyramid", "k_fast_wave": "fast", "k_octree": "octree", "k_blur_stream": "blur", "k_describe": "describe", "k_match": "match"}
 by, vl = {}, {}
 for r in rows[1:]:
     for k, v in stage.items():
