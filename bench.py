@@ -375,16 +375,23 @@ def rccl_report(world, version, transport, verdicts, block_bytes, allgather_us):
 def time_exchange(pipe, comm, stream_sync, reps=20):
     """wall time of one dvs_exchange_boundary (pack + all-gather, nothing else on the GPU), after the timed region; collective: every rank
     makes the same calls"""
+    from dvslam_amd import _lib
     s = (pipe.i - 1) % pipe.nsets
     pd, pn = pipe._last(s)
-    for _ in range(3):
-        comm.exchange_boundary(pipe.M or pipe.T, pd, pn, pipe.cap)
+    st = _lib.stream_create(pipe.device)   # (the pipeline is drained: any stream will do, and its own are the library's business)
     stream_sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        comm.exchange_boundary(pipe.M or pipe.T, pd, pn, pipe.cap)
-    stream_sync()
-    return round((time.perf_counter() - t0) / reps * 1e6, 1)
+    try:
+        for _ in range(3):
+            comm.exchange_boundary(st, pd, pn, pipe.cap)
+        _lib.stream_synchronize(st)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            comm.exchange_boundary(st, pd, pn, pipe.cap)
+        _lib.stream_synchronize(st)
+        return round((time.perf_counter() - t0) / reps * 1e6, 1)
+    finally:
+        _lib.stream_synchronize(st)
+        _lib.stream_destroy(st)
 
 
 def loopback_bench(args):
@@ -483,7 +490,6 @@ def main():
     ap.add_argument("--shard", choices=("frames", "levels"), default="frames",
                     help="levels: SURVEY.md section 8e's small-batch mode (use with --batch < 8): every rank holds the same frames, extracts its "
                          "own pyramid levels, one all-gather of level-slotted blocks, on-device merge; total work fixed (strong scaling)")
-    ap.add_argument("--trace-steps", action="store_true", help="diagnostics: also print the time between consecutive steps of the timed region (stderr)")
     ap.add_argument("--loopback", type=int, default=0, help="rehearsal of the N > 1 path on ONE GPU: N logical ranks of this process "
                     "(dvs_comm_create_loopback, a host thread each), --global-batch frames split over them; prints a DIAGNOSTIC line with the same `rccl` object")
     ap.add_argument("--dry-launch", action="store_true", help="only start the ranks and report them (no GPU work): launcher self-test")
@@ -530,7 +536,7 @@ def main():
     # are created by the library, back to back, BEFORE RCCL comes up.
     pipe = StreamingPipeline(B, rows, cols, args.nfeatures, device=local, nsets=args.nsets, pipelined=args.pipelined,
                              lanes=args.lanes, quadtree_async=args.quadtree_async)
-    orb, cap = pipe.orb, pipe.cap
+    cap = pipe.cap
     torch.cuda.synchronize()
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torchrun (also with one rank): exercise RCCL
     comm = None
@@ -575,44 +581,38 @@ def main():
     K = args.steps
     overlap_default = os.environ.get("DVS_NO_OVERLAP") != "1"   # tools/collect_profiles.sh serialises the WHOLE run for its per-kernel passes
     lanes = pipe.lanes                                          # >= 2: the small-batch lane schedule; its extractors have one stream each
-    orb.enable_stage_timing(True)                               # (lane 0's extractor: every lanes-th step is timed)
+    pipe.stage_timing(True)                                     # (lane 0's extractor: every lanes-th step is timed)
     if lanes >= 2:
         for k in range(K * lanes):
             pipe.step(img[k % NB], 0, match=False)
             pipe.synchronize()                                  # one step in flight: every kernel alone on the machine
     else:
-        orb.set_overlap(False)
+        pipe.set_serialized(True)
         for k in range(K):
             pipe.step(img[k % NB], 0, match=False)
     pipe.synchronize()
-    stage_ms, stage_calls = orb.stage_times()
+    stage_ms, stage_calls = pipe.stage_times()
     if lanes < 2:
-        orb.set_overlap(overlap_default)
+        pipe.set_serialized(not overlap_default)
     # (a) the pipelined schedule: what a kernel takes WHILE its neighbours share the machine (= rocprofv3's statistics of this command);
     #     last, so that the timed region follows work of its own intensity
     pipe.reset()
     for k in range(K * max(lanes, 1)):
         pipe.step(img[k % NB], img[(k + 1) % NB])
     pipe.synchronize()
-    ov_ms, ov_calls = orb.stage_times()
-    orb.enable_stage_timing(False)
+    ov_ms, ov_calls = pipe.stage_times()
+    pipe.stage_timing(False)
     pipe.reset()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    tev = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if args.trace_steps:
-            tev.append(_lib.timing_event_create(local)); pipe.L.dvs_event_record(tev[-1], pipe.T)
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no synchronisation inside)
     barrier()
     elapsed = time.perf_counter() - t0
-    if tev:
-        gaps = [round(_lib.event_elapsed_ms(a, b), 4) for a, b in zip(tev[:-1], tev[1:])]
-        print(f"[bench] rank {rank}: ms between consecutive steps (main stream): {gaps}", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -656,8 +656,9 @@ def main():
         if comm is None:
             i2 = _lib.DeviceBuffer(B * cap * 4, local); d2 = _lib.DeviceBuffer(B * cap * 4, local)
             pd, pn = pipe._last(sp)
-            pipe.mat.match_sequence_device(pipe.desc[sj].ptr, pipe.n[sj].ptr, cap, B, pd, pn, i2.ptr, d2.ptr)
-            pipe.synchronize()
+            chk = dvslam_amd.BFMatcher(device=local)   # a matcher of its own: the pipeline is drained, its handles are the library's business
+            chk.match_sequence_device(pipe.desc[sj].ptr, pipe.n[sj].ptr, cap, B, pd, pn, i2.ptr, d2.ptr)
+            chk.synchronize()
             ri = i2.download(np.int32, B * cap).reshape(B, cap); rd = d2.download(np.int32, B * cap).reshape(B, cap)
             same = all((ri[f, :nj[f]] == idx[f, :nj[f]]).all() and (rd[f, :nj[f]] == dst[f, :nj[f]]).all() for f in range(B))
             match_check = "identical to the serial match of the same batch" if same else "MISMATCH"

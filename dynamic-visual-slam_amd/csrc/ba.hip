@@ -1156,8 +1156,8 @@ dvs_status dvs_ba_create(int32_t device, dvs_ba** out) {
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   h->stream = h->own_stream;
-  if (const char* v = getenv("DVS_LM_POLL")) h->lm_poll = atoi(v) != 0;
-  if (const char* v = getenv("DVS_LM_SPECULATE")) h->lm_speculate = atoi(v) != 0;
+  h->lm_poll = dvs::env_switch("DVS_LM_POLL", 1) != 0;
+  h->lm_speculate = dvs::env_switch("DVS_LM_SPECULATE", 1) != 0;
   *out = h;
   return DVS_OK;
 }

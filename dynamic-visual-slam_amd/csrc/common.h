@@ -5,11 +5,21 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/dvslam_hip.h"
+#include "../../include/dvslam_hip_test.h"   // the extractor's scheduling hooks: used inside the library (pipeline.hip), exported by the test build only
+
+// scheduling / introspection hooks (declared in dvslam_hip_test.h): hidden in lib/libdvslam_hip.so, exported by lib/libdvslam_hip_test.so
+#ifdef DVS_TEST_HOOKS
+#define DVS_HOOK __attribute__((visibility("default")))
+#else
+#define DVS_HOOK __attribute__((visibility("hidden")))
+#endif
 
 namespace dvs {
 
 void set_error(const char* fmt, ...);  // util.hip
 dvs_status check_device(int device);   // selects the device; DVS_ERR_NO_DEVICE if none / not gfx950
+dvs_status env_check();                // util.hip: every DVS_* variable of the environment is a known switch with an allowed value
+int env_switch(const char* name, int dflt);   // value of a switch of util.hip's table (validated by env_check at handle creation)
 
 #define DVS_HIP(call)                                                                          \
   do {                                                                                         \

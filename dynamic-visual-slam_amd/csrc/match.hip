@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const u64* __restrict__ q, c
 static inline void launch_match_few(hipStream_t st, dim3 grid, const u64* q, const int* nqArr, int nqConst, int qStrideRows, const u64* t,
                                     const int* ntArr, int ntConst, int tStrideRows, int* outIdx, int* outDist, int trainRows,
                                     const u64* t0 = nullptr, const int* nt0 = nullptr) {
-  static const bool lds_on = !(getenv("DVS_MATCH_LDS") && getenv("DVS_MATCH_LDS")[0] == '0');
+  const bool lds_on = dvs::env_switch("DVS_MATCH_LDS", 1) != 0;
   // up to 6 jobs (what a lane of dvs_pipeline enqueues, and the single-call entry point): one 2000 x 2000 job 18.3 -> 7.7 us per launch, two
   // 18.5 -> 8.1, four 18.8 -> 13.1, six 18.7 -> 19.5 alone but +8 % in the six-frame lane step (no scalar-load chain beside the other lanes'
   // kernels); 7 and 8 jobs (the four-stream form's match stream) lose 3-7 %: k_match<16, 1> there.  DVS_MATCH_LDS=0: never.
@@ -538,7 +538,7 @@ dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out) {
   hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete m; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return DVS_ERR_HIP; }
   m->stream = m->own_stream;
-  if (const char* e2 = getenv("DVS_MATCH_MFMA")) m->use_mfma = e2[0] != '0';
+  m->use_mfma = dvs::env_switch("DVS_MATCH_MFMA", 1) != 0;
   *out = m;
   return DVS_OK;
 }
@@ -551,7 +551,7 @@ dvs_status dvs_matcher_create_on_stream(int32_t device, void* hip_stream, dvs_ma
   if (!m) { set_error("out of host memory"); return DVS_ERR_HIP; }
   m->device = device;
   m->stream = (hipStream_t)hip_stream;  // no stream of its own: every HIP stream is a hardware queue
-  if (const char* e2 = getenv("DVS_MATCH_MFMA")) m->use_mfma = e2[0] != '0';
+  m->use_mfma = dvs::env_switch("DVS_MATCH_MFMA", 1) != 0;
   *out = m;
   return DVS_OK;
 }
@@ -575,7 +575,7 @@ dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* s) {
   m->stream = (hipStream_t)s;  // NULL = HIP's legacy default stream
   return DVS_OK;
 }
-dvs_status dvs_matcher_use_own_stream(dvs_matcher* m) {
+DVS_HOOK dvs_status dvs_matcher_use_own_stream(dvs_matcher* m) {
   DVS_ARG(m);
   DVS_HIP(hipSetDevice(m->device));
   DVS_HIP(hipStreamSynchronize(m->stream));

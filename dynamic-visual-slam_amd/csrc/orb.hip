@@ -28,7 +28,7 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 using namespace dvs;
 
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int env_int(const char* name, int dflt) { return dvs::env_switch(name, dflt); }   // (util.hip: the one table of switches)
 
 struct dvs_orb {
   dvs_orb_params prm;
@@ -75,8 +75,6 @@ struct dvs_orb {
   // cannot be shorter than that chain of stages: at 8 frames 264 us / 3 = 88 us per step with three buffers, 66 with four (EXPERIMENTS.md).
   int ring = 3;
   int async_run = 0;               // consecutive asynchronous (prefetched + deferred) calls so far
-  int env_fuse_blur = 1;           // DVS_FUSE_BLUR=0: a single-stream handle launches quad-trees and blur one after the other
-  int env_ring = 4;                // DVS_RING=3: keep three in the four-stream form
   // deferred descriptor stage (dvs_orb_set_output_event + dvs_orb_set_defer_outputs): ordered on the auxiliary stream only
   hipEvent_t ev_outs[3] = {nullptr, nullptr, nullptr};   // completion of the last ring - 1 deferred stages (ev_out = the latest)
   hipEvent_t ev_out = nullptr, ev_oct = nullptr;  // ... / quad-tree finished (main stream): the deferred stage's join
@@ -395,7 +393,7 @@ dvs_status build_geometry(dvs_orb* h, int rows, int cols, Geom& G, std::vector<C
     // 512 / 1024 threads per workgroup with 256 x 64 tiles: +1 % at 4 and 8 frames, not kept).  DVS_CASC_TW / DVS_CASC_TH override
     // (tools/time_cascade_variants.py).  EXPERIMENTS.md, round 4.
     const int cascT = 256;   // threads per workgroup of k_pyr_cascade
-    const int tileW = env_int("DVS_CASC_TW", h->max_batch <= 1 ? 64 : kPyrTileW), tileH = env_int("DVS_CASC_TH", h->max_batch <= 1 ? 16 : kPyrTileH);
+    const int tileW = h->max_batch <= 1 ? 64 : kPyrTileW, tileH = h->max_batch <= 1 ? 16 : kPyrTileH;
     for (int ty = 0; ty < G.lv[1].h; ty += tileH)
       for (int tx = 0; tx < G.lv[1].w; tx += tileW) {
         PyrTile T{};
@@ -986,7 +984,7 @@ dvs_status enqueue_extract(dvs_orb* h, ImgSrc src, int nimg, dvs_keypoint* d_kps
   // a lane (one stream, a few frames): quad-trees and streaming blur in one launch (k_octree_blur) — the blur then runs beside the trees
   // instead of behind them (the lane's chain: -13 us of ~140 at one frame)
   const int blurRows = (G.blurStrips + kOctTMax / 64 - 1) / (kOctTMax / 64);
-  const bool fuse_blur = h->single_stream && h->env_fuse_blur && !async && !sharded && !(h->env_blur_mfma && h->blur_mfma_ok) &&
+  const bool fuse_blur = h->single_stream && !async && !sharded && !(h->env_blur_mfma && h->blur_mfma_ok) &&
                          blur_stream_ok(h, src, cascade) && (long)nimg * (G.nlevels + blurRows) <= 256;
   h->timer.begin(DVS_STAGE_OCTREE, qs);
   if (fuse_blur) {
@@ -1063,8 +1061,8 @@ extern "C" {
 
 static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool single_stream, bool on_stream, hipStream_t ext, dvs_orb** out);
 dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, false, false, nullptr, out); }
-dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, true, false, nullptr, out); }
-dvs_status dvs_orb_create_on_stream(const dvs_orb_params* params, int32_t device, void* hip_stream, dvs_orb** out) {
+DVS_HOOK dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out) { return orb_create(params, device, true, false, nullptr, out); }
+DVS_HOOK dvs_status dvs_orb_create_on_stream(const dvs_orb_params* params, int32_t device, void* hip_stream, dvs_orb** out) {
   return orb_create(params, device, true, true, (hipStream_t)hip_stream, out);
 }
 
@@ -1101,8 +1099,6 @@ static dvs_status orb_create(const dvs_orb_params* params, int32_t device, bool 
   h->overlap = env_int("DVS_NO_OVERLAP", 0) == 0 && !single_stream;
   h->env_cascade = env_int("DVS_CASCADE", -1);
   h->env_chain_graph = env_int("DVS_CHAIN_GRAPH", -1);
-  h->env_ring = env_int("DVS_RING", 4);
-  h->env_fuse_blur = env_int("DVS_FUSE_BLUR", 1);
   h->env_blur_mfma = env_int("DVS_BLUR_MFMA", 0);
   h->env_host_poll = env_int("DVS_HOST_POLL", 1);
   h->env_oct_threads = env_int("DVS_OCT_T", 0);
@@ -1161,7 +1157,7 @@ dvs_status dvs_orb_set_stream(dvs_orb* h, void* s) {
   h->stream = (hipStream_t)s;  // NULL is a real stream: HIP's legacy default stream
   return DVS_OK;
 }
-dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
+DVS_HOOK dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   if (on && h->single_stream) { set_error("dvs_orb_set_overlap: this extractor was created with one stream only"); return DVS_ERR_UNSUPPORTED; }
@@ -1174,7 +1170,7 @@ dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on) {
   h->overlap = on != 0;
   return DVS_OK;
 }
-dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on) {
+DVS_HOOK dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   if (on && h->single_stream) { set_error("dvs_orb_set_async_quadtree: this extractor was created with one stream only"); return DVS_ERR_UNSUPPORTED; }
   DVS_HIP(hipSetDevice(h->device));
@@ -1186,9 +1182,9 @@ dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on) {
   h->async_oct = on != 0;
   return DVS_OK;
 }
-int64_t dvs_orb_chain_graph_launches(const dvs_orb* h) { return h ? h->chain_graph_launches : 0; }
+DVS_HOOK int64_t dvs_orb_chain_graph_launches(const dvs_orb* h) { return h ? h->chain_graph_launches : 0; }
 
-dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
+DVS_HOOK dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
@@ -1197,7 +1193,7 @@ dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
   if (h->out_pending) { DVS_HIP(hipEventSynchronize(h->ev_out)); h->out_pending = false; }
   h->tail_stream = (hipStream_t)hip_stream;
   // the four-stream form rotates over rings of four (see `ring`); everything is idle here: restart every rotation at its first set
-  h->ring = hip_stream && h->env_ring == 4 ? 4 : 3;
+  h->ring = hip_stream ? 4 : 3;
   h->cset = h->bset = h->lset = 0; h->out_gen = 0; h->async_run = 0;
   for (bool& v : h->octdone_valid) v = false;
   h->d_cand = h->d_cand2[0]; h->d_cellcount = h->d_cellcount2[0]; h->d_blur = h->d_blur3[0];
@@ -1205,7 +1201,7 @@ dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream) {
   h->last_async = false;
   return DVS_OK;
 }
-dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
+DVS_HOOK dvs_status dvs_orb_use_own_stream(dvs_orb* h) {
   DVS_ARG(h);
   if (!h->own_stream) { set_error("dvs_orb_use_own_stream: this extractor was created on a caller's stream and has none of its own"); return DVS_ERR_UNSUPPORTED; }
   DVS_HIP(hipSetDevice(h->device));
@@ -1310,31 +1306,31 @@ dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int3
   return DVS_OK;
 }
 
-dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event) {
+DVS_HOOK dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event) {
   DVS_ARG(h);
   h->output_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 
-dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on) {
+DVS_HOOK dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   h->defer_outputs = on != 0;
   return DVS_OK;
 }
 
-dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event) {
+DVS_HOOK dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event) {
   DVS_ARG(h);
   h->guard_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 
-dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event) {
+DVS_HOOK dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event) {
   DVS_ARG(h);
   h->after_fast_event = (hipEvent_t)hip_event;
   return DVS_OK;
 }
 
-dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs) {
+DVS_HOOK dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs) {
   DVS_ARG(h);
   h->next_hint = d_next_imgs;
   return DVS_OK;
@@ -1422,7 +1418,7 @@ static dvs_status read_packed(dvs_orb* h, const uint32_t* dsrc, int n, int32_t* 
   return DVS_OK;
 }
 
-dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
+DVS_HOOK dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
   DVS_ARG(h && xys && n && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
@@ -1433,7 +1429,7 @@ dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int3
   return read_packed(h, h->d_pts + (uint64_t)frame * h->geom.ptsPerFrame + h->geom.lv[level].ptsOff, cnt, xys);
 }
 
-dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
+DVS_HOOK dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n) {
   DVS_ARG(h && xys && n && h->d_geom && frame >= 0 && frame < h->last_nimg && level >= 0 && level < h->geom.nlevels);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));
@@ -1444,14 +1440,14 @@ dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level,
   return read_packed(h, h->d_lvlkp + (uint64_t)frame * h->geom.kpBlock + h->geom.lv[level].kpOff, cnt, xys);
 }
 
-dvs_status dvs_orb_enable_stage_timing(dvs_orb* h, int32_t on) {
+DVS_HOOK dvs_status dvs_orb_enable_stage_timing(dvs_orb* h, int32_t on) {
   DVS_ARG(h);
   h->timer.resolve();
   h->timer.on = on != 0;
   return DVS_OK;
 }
 
-dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32_t reset) {
+DVS_HOOK dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32_t reset) {
   DVS_ARG(h);
   DVS_HIP(hipSetDevice(h->device));
   DVS_HIP(hipStreamSynchronize(h->stream));

@@ -302,11 +302,28 @@ dvs_status dvs_pipeline_get_set(const dvs_pipeline* p, int64_t step, dvs_pipelin
   return DVS_OK;
 }
 
+dvs_status dvs_pipeline_set_serialized(dvs_pipeline* p, int32_t on) {
+  DVS_ARG(p);
+  if (p->lanes >= 2) { set_error("dvs_pipeline_set_serialized: the lane schedule's extractors have one stream for good (nothing to serialise)"); return DVS_ERR_UNSUPPORTED; }
+  DVS_TRY(dvs_pipeline_synchronize(p));
+  return dvs_orb_set_overlap(p->orb, on ? 0 : 1);
+}
+
+dvs_status dvs_pipeline_stage_timing(dvs_pipeline* p, int32_t on) {
+  DVS_ARG(p);
+  return dvs_orb_enable_stage_timing(p->orb, on);
+}
+
+dvs_status dvs_pipeline_get_stage_times(dvs_pipeline* p, double* ms, int64_t* calls, int32_t reset) {
+  DVS_ARG(p);
+  return dvs_orb_get_stage_times(p->orb, ms, calls, reset);
+}
+
 int32_t dvs_pipeline_quadtree_async(const dvs_pipeline* p) { return p && p->quadtree_async ? 1 : 0; }
 int32_t dvs_pipeline_nsets(const dvs_pipeline* p) { return p ? p->nsets : 0; }
 int32_t dvs_pipeline_lanes(const dvs_pipeline* p) { return !p ? 0 : (p->pipelined ? p->lanes : 0); }
-dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p) { return p ? p->orb : nullptr; }
-dvs_matcher* dvs_pipeline_matcher(dvs_pipeline* p) { return p ? p->mat : nullptr; }
-void* dvs_pipeline_match_stream(dvs_pipeline* p) { return p ? (void*)p->M : nullptr; }
+DVS_HOOK dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p) { return p ? p->orb : nullptr; }
+DVS_HOOK dvs_matcher* dvs_pipeline_matcher(dvs_pipeline* p) { return p ? p->mat : nullptr; }
+DVS_HOOK void* dvs_pipeline_match_stream(dvs_pipeline* p) { return p ? (void*)p->M : nullptr; }
 
 }  // extern "C"

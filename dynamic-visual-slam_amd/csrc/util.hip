@@ -1,9 +1,12 @@
 // util.hip — error text, device selection, raw device-memory helpers of the C-ABI
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #ifdef DVS_TEST_HOOKS
 #include "../../include/dvslam_hip_test.h"
 #endif
+
+extern "C" char** environ;   // (POSIX)
 
 namespace dvs {
 
@@ -16,7 +19,64 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- the environment switches of the library: ONE table (DESIGN.md section 4a' lists them with the test that covers each).  Every
+// DVS_* variable of the environment must be one of these with an allowed value: a mistyped name or value fails the first handle
+// creation loudly (DVS_ERR_ARG) instead of silently running the default.
+namespace {
+struct EnvSwitch { const char* name; int allowed[4]; int nallowed; };
+const EnvSwitch kSwitches[] = {
+    {"DVS_NO_OVERLAP", {0, 1}, 2},         // 1: every kernel alone on the handle's main stream
+    {"DVS_CASCADE", {-1, 0, 1}, 3},        // pyramid by the launch chain / by k_pyr_cascade whatever the batch (-1: by batch size)
+    {"DVS_CHAIN_GRAPH", {-1, 0, 1}, 3},    // the announced batch's level chain never / always as one graph launch (-1: by batch size)
+    {"DVS_BLUR_MFMA", {0, 1, 2}, 3},       // matrix-core blur: LDS-tiled / LDS-free
+    {"DVS_HOST_POLL", {0, 1}, 2},          // 0: dvs_orb_extract returns its results by copy commands
+    {"DVS_OCT_T", {0, 256, 512}, 3},       // quad-tree workgroup size for every batch size (0: by batch size)
+    {"DVS_DESC_ORDER", {0, 1}, 2},         // 0: the descriptor stage visits keypoints in list order
+    {"DVS_FAST_BYTE_DMA", {0, 1}, 2},      // 0: FAST tiles staged from dword-aligned origins
+    {"DVS_MATCH_MFMA", {0, 1}, 2},         // 0: popcount kernels for every job count
+    {"DVS_MATCH_LDS", {0, 1}, 2},          // 0: up to 6 jobs by k_match<16, 1> instead of k_match_lds
+    {"DVS_LM_POLL", {0, 1}, 2},            // 0: device LM without host polling
+    {"DVS_LM_SPECULATE", {0, 1}, 2},       // 0: ... without the speculatively enqueued accepted-step launches
+};
+const EnvSwitch* find_switch(const char* name, size_t len) {
+  for (const EnvSwitch& s : kSwitches)
+    if (strlen(s.name) == len && strncmp(s.name, name, len) == 0) return &s;
+  return nullptr;
+}
+}  // namespace
+
+dvs_status env_check() {
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "DVS_", 4) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    if (!eq) continue;
+    const EnvSwitch* s = find_switch(*e, (size_t)(eq - *e));
+    if (!s) {
+      set_error("unknown environment switch %.*s (the library reads: DVS_NO_OVERLAP DVS_CASCADE DVS_CHAIN_GRAPH DVS_BLUR_MFMA DVS_HOST_POLL DVS_OCT_T "
+                "DVS_DESC_ORDER DVS_FAST_BYTE_DMA DVS_MATCH_MFMA DVS_MATCH_LDS DVS_LM_POLL DVS_LM_SPECULATE)", (int)(eq - *e), *e);
+      return DVS_ERR_ARG;
+    }
+    char* end = nullptr;
+    const long v = strtol(eq + 1, &end, 10);
+    bool ok = end != eq + 1 && *end == 0;
+    if (ok) { ok = false; for (int i = 0; i < s->nallowed; i++) ok = ok || s->allowed[i] == (int)v; }
+    if (!ok) {
+      char list[64] = ""; size_t o = 0;
+      for (int i = 0; i < s->nallowed; i++) o += (size_t)snprintf(list + o, sizeof(list) - o, "%s%d", i ? ", " : "", s->allowed[i]);
+      set_error("%s=%s: not a value of this switch (allowed: %s)", s->name, eq + 1, list);
+      return DVS_ERR_ARG;
+    }
+  }
+  return DVS_OK;
+}
+
+int env_switch(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && find_switch(name, strlen(name)) ? atoi(v) : dflt;
+}
+
 dvs_status check_device(int device) {
+  DVS_TRY(env_check());   // (before the device: a bad switch is an error with or without a GPU)
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {

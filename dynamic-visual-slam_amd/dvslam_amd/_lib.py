@@ -52,15 +52,8 @@ def build_library():
 _lib = None
 
 
-def lib():
-    """Load the HIP library; raise loudly if it is missing (no fallback path exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(SO_PATH):
-        raise RuntimeError(f"{SO_PATH} not found: build it with `make -C {_PKG}` (hipcc --offload-arch=gfx950); "
-                           "dvslam_amd has no CPU fallback")
-    L = C.CDLL(SO_PATH)
+def _bind(L):
+    """argument types of the product ABI (include/dvslam_hip.h) — both libraries export it"""
     vp, i32, sz, dbl = C.c_void_p, C.c_int32, C.c_size_t, C.c_double
     L.dvs_last_error.restype = C.c_char_p
     L.dvs_device_count.restype = i32
@@ -75,9 +68,6 @@ def lib():
     L.dvs_orb_max_keypoints.argtypes = [vp]
     L.dvs_orb_set_stream.argtypes = [vp, vp]
     L.dvs_orb_get_stream.argtypes = [vp]; L.dvs_orb_get_stream.restype = vp
-    L.dvs_orb_use_own_stream.argtypes = [vp]
-    L.dvs_orb_set_overlap.argtypes = [vp, i32]
-    L.dvs_matcher_use_own_stream.argtypes = [vp]
     L.dvs_orb_synchronize.argtypes = [vp]
     L.dvs_orb_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.dvs_orb_level_size.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -94,23 +84,11 @@ def lib():
     L.dvs_event_synchronize.argtypes = [vp]
     L.dvs_event_record.argtypes = [vp, vp]
     L.dvs_stream_wait_event.argtypes = [vp, vp]
-    L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
-    L.dvs_orb_set_after_fast_event.argtypes = [vp, vp]
-    L.dvs_orb_set_output_event.argtypes = [vp, vp]
-    L.dvs_orb_set_defer_outputs.argtypes = [vp, i32]
-    L.dvs_orb_set_reuse_guard_event.argtypes = [vp, vp]
-    L.dvs_orb_set_async_quadtree.argtypes = [vp, i32]
-    L.dvs_orb_set_tail_stream.argtypes = [vp, vp]
-    L.dvs_orb_chain_graph_launches.argtypes = [vp]; L.dvs_orb_chain_graph_launches.restype = C.c_int64
     L.dvs_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp]
     L.dvs_orb_level_block_bytes.argtypes = [vp, i32]; L.dvs_orb_level_block_bytes.restype = sz
     L.dvs_orb_extract_levels_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, C.c_uint32, vp]
     L.dvs_orb_merge_levels_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp]
     L.dvs_orb_get_level.argtypes = [vp, i32, i32, i32, vp, i32]
-    L.dvs_orb_get_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
-    L.dvs_orb_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
-    L.dvs_orb_enable_stage_timing.argtypes = [vp, i32]
-    L.dvs_orb_get_stage_times.argtypes = [vp, vp, vp, i32]
     L.dvs_matcher_create.argtypes = [i32, C.POINTER(vp)]
     L.dvs_matcher_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
     L.dvs_match_hamming_sequence_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
@@ -145,11 +123,9 @@ def lib():
     L.dvs_pipeline_lanes.argtypes = [vp]
     L.dvs_pipeline_nsets.argtypes = [vp]
     L.dvs_pipeline_quadtree_async.argtypes = [vp]
-    L.dvs_orb_create_single_stream.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
-    L.dvs_orb_create_on_stream.argtypes = [C.POINTER(OrbParams), i32, vp, C.POINTER(vp)]
-    L.dvs_pipeline_extractor.argtypes = [vp]; L.dvs_pipeline_extractor.restype = vp
-    L.dvs_pipeline_matcher.argtypes = [vp]; L.dvs_pipeline_matcher.restype = vp
-    L.dvs_pipeline_match_stream.argtypes = [vp]; L.dvs_pipeline_match_stream.restype = vp
+    L.dvs_pipeline_set_serialized.argtypes = [vp, i32]
+    L.dvs_pipeline_stage_timing.argtypes = [vp, i32]
+    L.dvs_pipeline_get_stage_times.argtypes = [vp, vp, vp, i32]
     L.dvs_find_fundamental_ransac.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, C.c_uint64, vp, vp, C.POINTER(i32)]
     L.dvs_solve_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_uint64, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.dvs_find_fundamental_cv.argtypes = [vp, vp, vp, i32, dbl, dbl, i32, vp, vp, C.POINTER(i32), C.POINTER(i32)]
@@ -171,6 +147,44 @@ def lib():
         L.dvs_ba_get_trace.argtypes = [vp, vp, i32, C.POINTER(i32)]
         L.dvs_ba_pose_from_rt.argtypes = [vp, vp, vp, vp]
         L.dvs_ba_pose_to_rt.argtypes = [vp, vp, vp, vp]
+
+
+def _bind_hooks(L):
+    """... and of what only lib/libdvslam_hip_test.so exports beside the dvs_test_* functions: the extractor's scheduling / introspection hooks
+    (include/dvslam_hip_test.h; hidden in the product library since round 5)"""
+    vp, i32, sz, dbl = C.c_void_p, C.c_int32, C.c_size_t, C.c_double
+    L.dvs_orb_use_own_stream.argtypes = [vp]
+    L.dvs_orb_set_overlap.argtypes = [vp, i32]
+    L.dvs_matcher_use_own_stream.argtypes = [vp]
+    L.dvs_orb_hint_next_batch_device.argtypes = [vp, vp]
+    L.dvs_orb_set_after_fast_event.argtypes = [vp, vp]
+    L.dvs_orb_set_output_event.argtypes = [vp, vp]
+    L.dvs_orb_set_defer_outputs.argtypes = [vp, i32]
+    L.dvs_orb_set_reuse_guard_event.argtypes = [vp, vp]
+    L.dvs_orb_set_async_quadtree.argtypes = [vp, i32]
+    L.dvs_orb_set_tail_stream.argtypes = [vp, vp]
+    L.dvs_orb_chain_graph_launches.argtypes = [vp]; L.dvs_orb_chain_graph_launches.restype = C.c_int64
+    L.dvs_orb_get_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_orb_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.dvs_orb_enable_stage_timing.argtypes = [vp, i32]
+    L.dvs_orb_get_stage_times.argtypes = [vp, vp, vp, i32]
+    L.dvs_orb_create_single_stream.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
+    L.dvs_orb_create_on_stream.argtypes = [C.POINTER(OrbParams), i32, vp, C.POINTER(vp)]
+    L.dvs_pipeline_extractor.argtypes = [vp]; L.dvs_pipeline_extractor.restype = vp
+    L.dvs_pipeline_matcher.argtypes = [vp]; L.dvs_pipeline_matcher.restype = vp
+    L.dvs_pipeline_match_stream.argtypes = [vp]; L.dvs_pipeline_match_stream.restype = vp
+
+
+def lib():
+    """Load the HIP library; raise loudly if it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} not found: build it with `make -C {_PKG}` (hipcc --offload-arch=gfx950); "
+                           "dvslam_amd has no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    _bind(L)
     _lib = L
     return L
 
@@ -180,16 +194,18 @@ _test_lib = None
 
 
 def test_lib():
-    """lib/libdvslam_hip_test.so: the same sources built with -DDVS_TEST_HOOKS (include/dvslam_hip_test.h).  Only the dvs_test_* hooks are
-    called through it; the product library exports none of them."""
+    """lib/libdvslam_hip_test.so: the same sources built with -DDVS_TEST_HOOKS (include/dvslam_hip_test.h): the whole product ABI plus the
+    dvs_test_* functions and the extractor's scheduling / introspection hooks, which the product library does not export.  Wrapper objects
+    built with hooks=True make ALL their calls through it."""
     global _test_lib
     if _test_lib is not None:
         return _test_lib
     if not os.path.exists(TEST_SO_PATH):
         subprocess.check_call(["make", "-s", "-j4", "-C", _PKG, "test-lib"])
     L = C.CDLL(TEST_SO_PATH)
+    _bind(L)
+    _bind_hooks(L)
     vp, i32, dbl = C.c_void_p, C.c_int32, C.c_double
-    L.dvs_last_error.restype = C.c_char_p
     L.dvs_test_stream_delay.argtypes = [vp, i32]
     L.dvs_test_sort_nodes.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes.restype = None
     L.dvs_test_sort_nodes_ranked.argtypes = [vp, vp, i32, vp]; L.dvs_test_sort_nodes_ranked.restype = None
@@ -206,7 +222,8 @@ def test_lib():
 
 def check(code):
     if code != 0:
-        raise DvsError(code, lib().dvs_last_error().decode(errors="replace"))
+        msgs = [L.dvs_last_error().decode(errors="replace") for L in (_lib, _test_lib) if L is not None]
+        raise DvsError(code, " | ".join(m for m in msgs if m) or "(no message)")
 
 
 def device_count():

@@ -103,16 +103,17 @@ class Comm:
     is the caller's out-of-band broadcast of the 128-byte unique id from rank 0 (bench.py: torch.distributed's store)."""
 
     @classmethod
-    def loopback(cls, device: int, world: int):
+    def loopback(cls, device: int, world: int, hooks: bool = False):
         """`world` logical ranks of this process on one device (dvs_comm_create_loopback): a list of Comm, one per rank, each to be
         driven by its own thread — a collective call blocks until every rank of the group has made it"""
-        from ._lib import lib, check
+        from ._lib import lib, test_lib, check
+        L = test_lib() if hooks else lib()   # (the library of the pipelines the ranks will be attached to)
         hs = (C.c_void_p * world)()
-        check(lib().dvs_comm_create_loopback(device, world, hs))
+        check(L.dvs_comm_create_loopback(device, world, hs))
         out = []
         for r in range(world):
             c = cls.__new__(cls)
-            c._L, c._check, c.h, c.rank, c.world = lib(), check, C.c_void_p(hs[r]), r, world
+            c._L, c._check, c.h, c.rank, c.world = L, check, C.c_void_p(hs[r]), r, world
             out.append(c)
         return out
 

@@ -1,6 +1,6 @@
 import ctypes as C
 import numpy as np
-from ._lib import lib, check, ptr
+from ._lib import lib, test_lib, check, ptr
 
 
 class BFMatcher:
@@ -8,9 +8,10 @@ class BFMatcher:
     (frontend.cpp:220,614,1123; backend.cpp:222,1072).  match(query, train) returns one
     (queryIdx=i, trainIdx, distance) per query row as two int32 arrays (trainIdx, distance)."""
 
-    def __init__(self, device=0, stream=None):
-        """stream: raw hipStream_t (int) the matcher enqueues on from the start; None = a stream of its own"""
-        self._L = lib()
+    def __init__(self, device=0, stream=None, hooks=False):
+        """stream: raw hipStream_t (int) the matcher enqueues on from the start; None = a stream of its own.  hooks=True: all calls through
+        lib/libdvslam_hip_test.so (an object shared with a hooks=True extractor or pipeline must live in the same library)"""
+        self._L = test_lib() if hooks else lib()
         h = C.c_void_p()
         if stream is None:
             check(self._L.dvs_matcher_create(device, C.byref(h)))
@@ -19,10 +20,10 @@ class BFMatcher:
         self._h = h
 
     @classmethod
-    def from_handle(cls, handle):
-        """non-owning view of a dvs_matcher* that lives inside another handle (dvs_pipeline_matcher)"""
+    def from_handle(cls, handle, L=None):
+        """non-owning view of a dvs_matcher* that lives inside another handle (dvs_pipeline_matcher: test library only)"""
         m = cls.__new__(cls)
-        m._L, m._h, m._owned = lib(), C.c_void_p(handle), False
+        m._L, m._h, m._owned = (L or lib()), C.c_void_p(handle), False
         return m
 
     def close(self):

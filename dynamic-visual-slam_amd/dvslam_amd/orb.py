@@ -1,6 +1,6 @@
 import ctypes as C
 import numpy as np
-from ._lib import lib, check, ptr, OrbParams, KP_DTYPE, DvsError
+from ._lib import lib, test_lib, check, ptr, OrbParams, KP_DTYPE, DvsError
 
 STAGES = ("pyramid", "fast", "octree", "blur", "describe")
 
@@ -14,8 +14,11 @@ class ORBextractor:
     descriptors an n x 32 uint8 array."""
 
     def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0, max_batch=1,
-                 gauss_kernel=None):
-        self._L = lib()
+                 gauss_kernel=None, hooks=False):
+        # hooks=True: every call of this object goes through lib/libdvslam_hip_test.so, which also exports the scheduling / introspection
+        # hooks (hint_next_batch_device, set_*_event, set_overlap, candidates, level_keypoints, stage timing); the product library does not
+        self._L = test_lib() if hooks else lib()
+        self.hooks = bool(hooks)
         p = OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, (C.c_int32 * 7)(*(gauss_kernel or [0] * 7)), max_batch)
         h = C.c_void_p()
         check(self._L.dvs_orb_create(C.byref(p), device, C.byref(h)))
@@ -24,10 +27,11 @@ class ORBextractor:
         self.capacity = self._L.dvs_orb_max_keypoints(self._h)
 
     @classmethod
-    def from_handle(cls, handle, nfeatures, nlevels, scaleFactor, device, max_batch):
-        """non-owning view of a dvs_orb* that lives inside another handle (dvs_pipeline_extractor)"""
+    def from_handle(cls, handle, nfeatures, nlevels, scaleFactor, device, max_batch, L=None):
+        """non-owning view of a dvs_orb* that lives inside another handle (dvs_pipeline_extractor: test library only)"""
         o = cls.__new__(cls)
-        o._L, o._h, o._owned = lib(), C.c_void_p(handle), False
+        o._L, o._h, o._owned = (L or lib()), C.c_void_p(handle), False
+        o.hooks = L is not None and L is not lib()
         o.nfeatures, o.nlevels, o.scaleFactor, o.device, o.max_batch = nfeatures, nlevels, scaleFactor, device, max_batch
         o.capacity = o._L.dvs_orb_max_keypoints(o._h)
         return o

@@ -24,19 +24,23 @@ from .orb import ORBextractor
 class _Ptr:
     """a device pointer inside the pipeline's output arena, with DeviceBuffer's download()"""
 
-    def __init__(self, ptr, nbytes, device):
-        self.ptr, self.nbytes, self.device = int(ptr or 0), int(nbytes), device
+    def __init__(self, ptr, nbytes, device, L):
+        self.ptr, self.nbytes, self.device, self.L = int(ptr or 0), int(nbytes), device, L
 
     def download(self, dtype, count):
         out = np.empty(count, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        _lib.check(_lib.lib().dvs_memcpy_d2h(self.device, _lib.ptr(out), self.ptr, out.nbytes))
+        _lib.check(self.L.dvs_memcpy_d2h(self.device, _lib.ptr(out), self.ptr, out.nbytes))
         return out
 
 
 class StreamingPipeline:
-    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=0, pipelined=True, params=(1.2, 8, 20, 7), lanes=0, quadtree_async=0):
-        self.L = L = _lib.lib()
+    def __init__(self, B, rows, cols, nfeatures=2000, device=0, nsets=0, pipelined=True, params=(1.2, 8, 20, 7), lanes=0, quadtree_async=0,
+                 hooks=False):
+        # hooks=True: through lib/libdvslam_hip_test.so, which also exports the handles inside (`orb`, `mat`, the streams `T`, `M`) for the
+        # tests that look at single stages; the product library exposes the step, its results and the measurement calls only
+        self.L = L = _lib.test_lib() if hooks else _lib.lib()
+        self.hooks = bool(hooks)
         self.B, self.rows, self.cols, self.device, self.nsets, self.pipelined = B, rows, cols, device, nsets, pipelined
         prm = _lib.PipelineParams(_lib.OrbParams(nfeatures, params[0], params[1], params[2], params[3], (C.c_int32 * 7)(*([0] * 7)), B),
                                   B, rows, cols, nsets, int(bool(pipelined)), lanes, quadtree_async)
@@ -49,19 +53,21 @@ class StreamingPipeline:
         self.nsets = nsets = int(L.dvs_pipeline_nsets(h))   # nsets = 0 asks for the schedule's default
         self.quadtree_async = bool(L.dvs_pipeline_quadtree_async(h))   # the four-stream form (dvs_pipeline_params::quadtree_async)
         self.lanes = int(L.dvs_pipeline_lanes(h))   # 0: serial, 1: two-stream software pipeline, >= 2: lane schedule
-        # non-owning views of the handles inside (stage timing, overlap switch, the bench's serial re-run of a match job)
-        self.orb = ORBextractor.from_handle(L.dvs_pipeline_extractor(h), nfeatures, params[1], params[0], device, B)
-        self.mat = BFMatcher.from_handle(L.dvs_pipeline_matcher(h))
-        self.cap = cap = self.orb.capacity
-        self.T = self.orb.get_stream()
-        self.M = int(L.dvs_pipeline_match_stream(h) or 0)
+        st0 = _lib.PipelineSet()
+        _lib.check(L.dvs_pipeline_get_set(h, 0, C.byref(st0)))
+        self.cap = cap = int(st0.capacity)
+        if hooks:   # non-owning views of the handles inside
+            self.orb = ORBextractor.from_handle(L.dvs_pipeline_extractor(h), nfeatures, params[1], params[0], device, B, L=L)
+            self.mat = BFMatcher.from_handle(L.dvs_pipeline_matcher(h), L=L)
+            self.T = self.orb.get_stream()
+            self.M = int(L.dvs_pipeline_match_stream(h) or 0)
         self.kps, self.desc, self.n, self.idx, self.dist = [], [], [], [], []
         for s in range(nsets):
             st = _lib.PipelineSet()
             _lib.check(L.dvs_pipeline_get_set(h, s, C.byref(st)))
-            self.kps.append(_Ptr(st.d_kps, B * cap * 28, device)); self.desc.append(_Ptr(st.d_desc, B * cap * 32, device))
-            self.n.append(_Ptr(st.d_n, B * 4, device))
-            self.idx.append(_Ptr(st.d_idx, B * cap * 4, device)); self.dist.append(_Ptr(st.d_dist, B * cap * 4, device))
+            self.kps.append(_Ptr(st.d_kps, B * cap * 28, device, L)); self.desc.append(_Ptr(st.d_desc, B * cap * 32, device, L))
+            self.n.append(_Ptr(st.d_n, B * 4, device, L))
+            self.idx.append(_Ptr(st.d_idx, B * cap * 4, device, L)); self.dist.append(_Ptr(st.d_dist, B * cap * 4, device, L))
         self.comm = None
 
     @property
@@ -72,8 +78,24 @@ class StreamingPipeline:
         """synchronise and restart the sequence at step 0"""
         _lib.check(self.L.dvs_pipeline_reset(self._h))
 
+    # ---- measurement (dvs_pipeline_set_serialized / _stage_timing / _get_stage_times: bench.py's per-stage report) ----
+    def set_serialized(self, on):
+        """True: every kernel of an extraction alone on the main stream (per-kernel durations); False: the shipped schedule"""
+        _lib.check(self.L.dvs_pipeline_set_serialized(self._h, int(bool(on))))
+
+    def stage_timing(self, on=True):
+        _lib.check(self.L.dvs_pipeline_stage_timing(self._h, int(bool(on))))
+
+    def stage_times(self, reset=True):
+        """({stage: ms}, {stage: launch sequences}) accumulated since the last reset"""
+        from .orb import STAGES
+        ms = np.zeros(len(STAGES), np.float64); calls = np.zeros(len(STAGES), np.int64)
+        _lib.check(self.L.dvs_pipeline_get_stage_times(self._h, _lib.ptr(ms), _lib.ptr(calls), int(reset)))
+        return {k: float(ms[i]) for i, k in enumerate(STAGES)}, {k: int(calls[i]) for i, k in enumerate(STAGES)}
+
     def attach_comm(self, comm):
-        """frame-sharded run: `comm` is a dist.Comm (RCCL, or one rank of `dist.Comm.loopback`)"""
+        """frame-sharded run: `comm` is a dist.Comm (RCCL, or one rank of `dist.Comm.loopback`) made by the SAME library as this pipeline"""
+        assert comm is None or comm._L is self.L, "communicator and pipeline must come from one library (hooks=... on both)"
         self.comm = comm
         _lib.check(self.L.dvs_pipeline_attach_comm(self._h, comm.h if comm is not None else None))
 

@@ -68,8 +68,12 @@ class StreamingPipeline {
     if (dist) { dist->resize(B * cap); check(dvs_memcpy_d2h(device_, dist->data(), s.d_dist, B * cap * 4), "d2h"); }
   }
   dvs_pipeline* handle() { return h_; }
-  dvs_orb* extractor() { return dvs_pipeline_extractor(h_); }
-  dvs_matcher* matcher() { return dvs_pipeline_matcher(h_); }
+  // measurement (bench-style per-stage report): every kernel alone on the main stream / per-stage GPU times of lane 0's extractor
+  void setSerialized(bool on) { check(dvs_pipeline_set_serialized(h_, on ? 1 : 0), "dvs_pipeline_set_serialized"); }
+  void stageTiming(bool on) { check(dvs_pipeline_stage_timing(h_, on ? 1 : 0), "dvs_pipeline_stage_timing"); }
+  void stageTimes(double ms[DVS_STAGE_COUNT], int64_t calls[DVS_STAGE_COUNT], bool reset = true) {
+    check(dvs_pipeline_get_stage_times(h_, ms, calls, reset ? 1 : 0), "dvs_pipeline_get_stage_times");
+  }
 
  private:
   static void check(dvs_status s, const char* what) {

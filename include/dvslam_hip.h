@@ -93,23 +93,12 @@ typedef struct dvs_orb_params {
 #define DVS_MAX_LEVELS 16
 
 dvs_status dvs_orb_create(const dvs_orb_params* params, int32_t device, dvs_orb** out);
-/* the same extractor with ONE stream for good: every stage runs in order on the handle's stream, no auxiliary / prefetch streams are
- * created (every HIP stream is a hardware queue, and a process has four) and dvs_orb_set_overlap(h, 1) is refused.  What the lanes of
- * dvs_pipeline are made of; results are identical. */
-dvs_status dvs_orb_create_single_stream(const dvs_orb_params* params, int32_t device, dvs_orb** out);
-/* ... and a single-stream extractor on a stream the CALLER owns (NULL: HIP's legacy default stream) — it never creates one of its own;
- * dvs_orb_use_own_stream is refused.  dvs_pipeline's fourth lane lives on a stream of another dispatch priority this way. */
-dvs_status dvs_orb_create_on_stream(const dvs_orb_params* params, int32_t device, void* hip_stream, dvs_orb** out);
 void dvs_orb_destroy(dvs_orb* h);
 /* capacity a caller must provide per frame: nfeatures + 3 * nlevels (a level may return quota + 2, ORBextractor.cpp:746-747) */
 int32_t dvs_orb_max_keypoints(const dvs_orb* h);
 /* enqueue on a caller-owned hipStream_t (e.g. torch's current stream) instead of the handle's own non-blocking
- * stream; NULL selects HIP's legacy default stream.  dvs_orb_use_own_stream() switches back. */
+ * stream; NULL selects HIP's legacy default stream. */
 dvs_status dvs_orb_set_stream(dvs_orb* h, void* hip_stream);
-dvs_status dvs_orb_use_own_stream(dvs_orb* h);
-/* 1 (default): independent stages overlap on an internal auxiliary stream (pyramid chain beside FAST, blur beside the quad-tree);
- * 0: every kernel runs alone on the handle's stream — what the per-kernel roofline durations are measured with */
-dvs_status dvs_orb_set_overlap(dvs_orb* h, int32_t on);
 void* dvs_orb_get_stream(dvs_orb* h);
 dvs_status dvs_orb_synchronize(dvs_orb* h);
 
@@ -128,48 +117,6 @@ dvs_status dvs_orb_extract_batch(dvs_orb* h, const uint8_t* const* imgs, int32_t
 dvs_status dvs_orb_extract_batch_device(dvs_orb* h, const uint8_t* d_imgs, int32_t nimg, int32_t rows, int32_t cols,
                                         size_t step, size_t frame_stride, dvs_keypoint* d_kps, uint8_t* d_desc,
                                         int32_t capacity, int32_t* d_n_out);
-/* Cross-batch software pipeline for streaming callers that already hold the next batch in device memory: announce it before
- * the dvs_orb_extract_batch_device call of the CURRENT batch.  That call then also enqueues the next batch's pyramid (same
- * nimg / rows / cols / step / frame_stride) on the handle's auxiliary stream, beside its own descriptor stage and whatever
- * the caller enqueues next (the match); the following call, if it is for exactly that buffer, finds its pyramid built and
- * starts with FAST on all levels at once.  One-shot; results are identical with or without the hint.  The announced images
- * must not change between the two calls.  (No counterpart in the reference, whose ComputePyramid runs inside operator(),
- * ORBextractor.cpp:1081; this is the MI355X replacement for running consecutive frames on separate CPU threads.) */
-dvs_status dvs_orb_hint_next_batch_device(dvs_orb* h, const uint8_t* d_next_imgs);
-/* Scheduling hook for a pipelined caller: `hip_event` (a hipEvent_t of the caller, NULL to clear) is recorded on the handle's main
- * stream by every following device-resident extraction right behind its FAST launch, i.e. at the point from which the machine's
- * vector ALUs are mostly idle (quad-tree / blur / descriptor gathers).  A caller that has independent matrix-core or copy work —
- * the PREVIOUS batch's match (BFMatcher call of frontend.cpp:1123) — makes its stream wait on it so that the work runs beside
- * that phase instead of beside FAST.  Results are unaffected. */
-dvs_status dvs_orb_set_after_fast_event(dvs_orb* h, void* hip_event);
-/* Output event of a pipelined caller: while `hip_event` (a hipEvent_t of the caller, NULL to clear) is set, every device-resident
- * extraction records it where its keypoints, descriptors and counts are complete (the library also uses it as the gate of the next
- * call's prefetch chain, which saves a record of its own).  With dvs_orb_set_defer_outputs(h, 1) that point is NOT the end of the
- * call on the main stream: the descriptor stage — fetch-bound gathers — stays on the handle's auxiliary stream without joining the
- * main one, so that the next call's FAST starts immediately and runs beside it; the library orders everything else (the next
- * quad-tree, blur and prefetch wait for it), the caller orders its consumers on the event and must leave the call's level-0 images
- * untouched until then.  dvs_orb_synchronize waits for a deferred stage too.  Results are unaffected. */
-dvs_status dvs_orb_set_output_event(dvs_orb* h, void* hip_event);
-dvs_status dvs_orb_set_defer_outputs(dvs_orb* h, int32_t on);
-/* Reuse guard (one-shot, consumed by the next device-resident extraction): the call's OUTPUT buffers may still be read by work of
- * the caller on another stream (the match of an earlier batch); the extraction writes them only behind `hip_event`.  Same effect as
- * hipStreamWaitEvent on the main stream before the call, but the wait rides on the blur's stream, off the critical path in front of
- * FAST (outputs are only written by the descriptor stage, which joins the blur). */
-dvs_status dvs_orb_set_reuse_guard_event(dvs_orb* h, void* hip_event);
-/* Quad-tree off the main stream (pipelined callers: announced next batch + deferred outputs).  on = 1: the quad-tree of a call runs on
- * the auxiliary stream behind that call's FAST, so the next call's FAST follows immediately and the latency-bound tree runs beside it
- * (FAST writes three candidate-list sets in turn; with more than one workgroup per CU the tree is launched per level class with that
- * class's LDS footprint instead of level 0's).  Results are unaffected.  Synchronises the handle's streams. */
-dvs_status dvs_orb_set_async_quadtree(dvs_orb* h, int32_t on);
-/* ... and its descriptor stage on a stream of the caller (NULL: the auxiliary stream): with the quad-tree and the blur on the auxiliary
- * stream that stream alone would carry a whole step; a pipelined caller hands over its match stream (dvs_pipeline does). */
-dvs_status dvs_orb_set_tail_stream(dvs_orb* h, void* hip_stream);
-/* Diagnostics: how many announced level chains (dvs_orb_hint_next_batch_device) were enqueued as ONE hipGraphLaunch instead of one launch
- * per level.  The chain's arguments depend only on (source block, frame count, destination pyramid); the second time an argument set is
- * seen its chain is captured into a graph, from then on it is one runtime call (4 us of host time against 17).  Automatic up to 12 frames
- * per call, where the host's enqueue bounds the step (DVS_CHAIN_GRAPH=1 / 0: always / never). */
-int64_t dvs_orb_chain_graph_launches(const dvs_orb* h);
-
 /* ---- level-sharded extraction for SMALL batches on several GPUs (SURVEY.md §8e "Partitioning") --------------------------------
  * With fewer frames in flight than GPUs, frame sharding leaves GPUs idle; the stages after the pyramid are independent per
  * level (ORBextractor.cpp:787, 894, 1123), so every rank takes the same frames and a subset of the LEVELS: it rebuilds the
@@ -185,19 +132,8 @@ dvs_status dvs_orb_extract_levels_device(dvs_orb* h, const uint8_t* d_imgs, int3
 dvs_status dvs_orb_merge_levels_device(dvs_orb* h, const uint8_t* d_blocks, int32_t world, const int32_t* level_owner, int32_t nimg,
                                        dvs_keypoint* d_kps, uint8_t* d_desc, int32_t capacity, int32_t* d_n_out);
 
-/* parity introspection of the LAST extract call (mvImagePyramid is a public member, ORBextractor.hpp:84) */
+/* the pyramid of the LAST extract call (mvImagePyramid is a public member, ORBextractor.hpp:84); blurred = 1: the blurred levels */
 dvs_status dvs_orb_get_level(dvs_orb* h, int32_t frame, int32_t level, int32_t blurred, uint8_t* dst, int32_t cap_bytes);
-/* FAST candidates handed to the quad-tree, in candidate order: int32 triplets (x, y, score), region-relative */
-dvs_status dvs_orb_get_candidates(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n);
-/* per-level keypoints after the quad-tree, level coordinates: int32 triplets (x, y, score) in list order */
-dvs_status dvs_orb_get_level_keypoints(dvs_orb* h, int32_t frame, int32_t level, int32_t* xys, int32_t cap, int32_t* n);
-
-/* per-stage GPU timing with hipEvents on the handle's stream (bench.py roofline).  Stage ids below. */
-enum { DVS_STAGE_PYRAMID = 0, DVS_STAGE_FAST = 1, DVS_STAGE_OCTREE = 2, DVS_STAGE_BLUR = 3, DVS_STAGE_DESCRIBE = 4, DVS_STAGE_COUNT = 5 };
-dvs_status dvs_orb_enable_stage_timing(dvs_orb* h, int32_t on);
-/* accumulated milliseconds and launch-sequence counts per stage since the last reset; synchronises the stream */
-dvs_status dvs_orb_get_stage_times(dvs_orb* h, double* ms, int64_t* calls, int32_t reset);
-
 /* ======================================= B2: Hamming matcher =================================== */
 
 typedef struct dvs_matcher dvs_matcher;
@@ -207,7 +143,6 @@ dvs_status dvs_matcher_create(int32_t device, dvs_matcher** out);
 dvs_status dvs_matcher_create_on_stream(int32_t device, void* hip_stream, dvs_matcher** out);
 void dvs_matcher_destroy(dvs_matcher* m);
 dvs_status dvs_matcher_set_stream(dvs_matcher* m, void* hip_stream);
-dvs_status dvs_matcher_use_own_stream(dvs_matcher* m);
 dvs_status dvs_matcher_synchronize(dvs_matcher* m);
 
 /* BFMatcher(NORM_HAMMING).match(query, train): per query row the arg-min Hamming distance over train rows,
@@ -337,13 +272,22 @@ dvs_status dvs_pipeline_synchronize(dvs_pipeline* p);
 dvs_status dvs_pipeline_reset(dvs_pipeline* p);
 int64_t dvs_pipeline_steps(const dvs_pipeline* p);   /* steps enqueued since creation / reset */
 dvs_status dvs_pipeline_get_set(const dvs_pipeline* p, int64_t step, dvs_pipeline_set* out);
-/* the handles inside (stage timing, overlap switch, stream for a caller's own events); owned by the pipeline */
+/* which schedule the handle runs */
 int32_t dvs_pipeline_quadtree_async(const dvs_pipeline* p);   /* 1: the four-stream form is in use */
 int32_t dvs_pipeline_nsets(const dvs_pipeline* p);    /* output sets in rotation */
 int32_t dvs_pipeline_lanes(const dvs_pipeline* p);    /* 0: serial schedule, 1: two-stream software pipeline, >= 2: lanes */
-dvs_orb* dvs_pipeline_extractor(dvs_pipeline* p);      /* lane 0's */
-dvs_matcher* dvs_pipeline_matcher(dvs_pipeline* p);
-void* dvs_pipeline_match_stream(dvs_pipeline* p);
+/* ---- measurement (bench.py's per-stage report and roofline; results are unaffected) ----
+ * The extractor's scheduling hooks that this step is composed of (announced next batch, after-FAST event, deferred outputs, reuse guard,
+ * quad-tree / tail streams, single-stream handles) are internal to the library since round 5; libdvslam_hip_test.so exports them for the
+ * tests that pin them one by one (include/dvslam_hip_test.h). */
+enum { DVS_STAGE_PYRAMID = 0, DVS_STAGE_FAST = 1, DVS_STAGE_OCTREE = 2, DVS_STAGE_BLUR = 3, DVS_STAGE_DESCRIBE = 4, DVS_STAGE_COUNT = 5 };
+/* 1: every kernel of an extraction alone on the main stream (no overlap inside a step: what per-kernel durations are measured with);
+ * 0: the shipped schedule.  Synchronises; refused for the lane schedule (its handles have one stream for good). */
+dvs_status dvs_pipeline_set_serialized(dvs_pipeline* p, int32_t on);
+/* per-stage GPU time (hipEvents around every stage of lane 0's extractor): switch, then accumulated milliseconds and launch-sequence
+ * counts per stage since the last reset (synchronises) */
+dvs_status dvs_pipeline_stage_timing(dvs_pipeline* p, int32_t on);
+dvs_status dvs_pipeline_get_stage_times(dvs_pipeline* p, double* ms /* [DVS_STAGE_COUNT] */, int64_t* calls /* [DVS_STAGE_COUNT] */, int32_t reset);
 
 /* ======================= glue either side of the path =============== */
 /* A dvs_matcher handle is the context (stream + scratch).  Host pointers unless the name says _device. */

@@ -164,6 +164,30 @@ def test_batch_device_matrix_core(gpu, oracle):
             assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (rep, p)
 
 
+@pytest.mark.parametrize("env", [{"DVS_MATCH_MFMA": "0"}, {"DVS_MATCH_LDS": "0"}])
+def test_match_switches_are_result_neutral(gpu, oracle, monkeypatch, env):
+    """DVS_MATCH_MFMA=0 (popcount kernels for every job count) and DVS_MATCH_LDS=0 (few jobs by k_match<16, 1> instead of k_match_lds):
+    a batch of large jobs and a few-jobs sequence against the oracle under either switch"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = BFMatcher()     # (the switches are read when the handle is created / at the launch)
+    for F, S in ((9, 2024), (3, 2024)):
+        rng = np.random.Generator(np.random.PCG64(5 + F))
+        D = rng.integers(0, 256, size=(F, S, 32), dtype=np.uint8)
+        n = np.array([S - 7 * p for p in range(F)], np.int32)
+        dd = DeviceBuffer(D.nbytes).upload(D); dn = DeviceBuffer(F * 4).upload(n)
+        di = DeviceBuffer(F * S * 4); dq = DeviceBuffer(F * S * 4)
+        m.match_sequence_device(dd.ptr, dn.ptr, S, F, 0, 0, di.ptr, dq.ptr)
+        m.synchronize()
+        idx = di.download(np.int32, F * S).reshape(F, S); dist = dq.download(np.int32, F * S).reshape(F, S)
+        assert (idx[0, :n[0]] == -1).all()
+        for p in range(1, F):
+            i2, d2 = oracle.match(D[p, :n[p]], D[p - 1, :n[p - 1]])
+            assert (idx[p, :n[p]] == i2).all() and (dist[p, :n[p]] == d2).all(), (env, F, p)
+
+
 def test_matrix_core_extreme_popcounts_and_unaligned_bases(gpu, oracle):
     """rows of 0 and 256 set bits (the ninth k-step carries -64 |t| per train row: both ends of its range), rows that differ in one bit,
     and descriptor bases that are not 16-byte aligned (those jobs take the popcount kernel): all against the oracle"""

@@ -14,6 +14,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _pair(oracle, nf, nl, **kw):
+    """(HIP extractor, oracle).  hooks=True: the extractor lives in lib/libdvslam_hip_test.so, which also exports the stage introspection
+    (candidate lists, per-level keypoints) and the scheduling hooks; the default is the product library"""
     from dvslam_amd import ORBextractor
     return ORBextractor(nf, 1.2, nl, 20, 7, **kw), oracle.OracleORB(nf, 1.2, nl, 20, 7)
 
@@ -30,9 +32,14 @@ def _assert_same_result(n, kps, desc, n2, kps2, desc2):
                                                    (481, 643, 600, 6, 1), (250, 330, 200, 4, 4)])  # widths % 4 != 0: generic blur path
 def test_stage_and_end_to_end_parity(gpu, oracle, rows, cols, nf, nl, frame):
     img = synth.make_frame(frame, cols=cols, rows=rows)
-    g, o = _pair(oracle, nf, nl)
+    g, o = _pair(oracle, nf, nl, hooks=True)     # stage by stage: the test library (same sources + the introspection hooks) ...
     n, kps, desc = g(img)
     n2, kps2, desc2 = o.extract(img)
+    gp, _ = _pair(oracle, nf, nl)                # ... and end to end through the PRODUCT library as well
+    _assert_same_result(*gp(img), n2, kps2, desc2)
+    for l in range(nl):
+        assert (gp.level(l) == o.level(l)).all(), f"pyramid level {l} (product library)"
+    gp.close()
     for l in range(nl):
         assert (g.level(l) == o.level(l)).all(), f"pyramid level {l}"
         assert (g.candidates(l) == o.candidates(l)).all() if len(o.candidates(l)) == len(g.candidates(l)) else False, f"candidates level {l}"
@@ -58,7 +65,7 @@ def test_golden_fixture(gpu):
     img = synth.make_frame(meta["frame"], cols=320, rows=240, seed=meta["seed"])
     assert hashlib.sha256(img.tobytes()).hexdigest() == meta["image_sha256"]
     from dvslam_amd import ORBextractor
-    g = ORBextractor(meta["nfeatures"], 1.2, meta["nlevels"], 20, 7)
+    g = ORBextractor(meta["nfeatures"], 1.2, meta["nlevels"], 20, 7, hooks=True)
     n, kps, desc = g(img)
     gold = np.load(os.path.join(GOLD, "orb_320x240.npz"))
     assert n == int(gold["n"]) and kps.tobytes() == gold["kps"].tobytes() and (desc == gold["desc"]).all()
@@ -98,8 +105,10 @@ def test_threshold_orders_follow_the_two_literal_calls(gpu, oracle, ini, mn, col
     img = synth.make_frame(3, cols=cols, rows=480)
     low = (100 + (img.astype(np.int32) - 128) // 3).astype(np.uint8)
     for im in (img, low):
-        g = ORBextractor(600, 1.2, 6, ini, mn); o = oracle.OracleORB(600, 1.2, 6, ini, mn)
+        g = ORBextractor(600, 1.2, 6, ini, mn, hooks=True); o = oracle.OracleORB(600, 1.2, 6, ini, mn)
         r = g(im); r2 = o.extract(im)
+        gp = ORBextractor(600, 1.2, 6, ini, mn)     # the product library end to end
+        _assert_same_result(*gp(im), *r2); gp.close()
         for l in range(6):
             assert len(g.candidates(l)) == len(o.candidates(l)) and (g.candidates(l) == o.candidates(l)).all(), f"candidates level {l}"
         _assert_same_result(*r, *r2)
@@ -180,7 +189,7 @@ def test_resolution_changes_and_large_batch(gpu, oracle):
 def test_overlap_on_off_identical(gpu):
     from dvslam_amd import ORBextractor
     img = synth.make_frame(3)
-    a = ORBextractor(2000, 1.2, 8, 20, 7); b = ORBextractor(2000, 1.2, 8, 20, 7)
+    a = ORBextractor(2000, 1.2, 8, 20, 7); b = ORBextractor(2000, 1.2, 8, 20, 7, hooks=True)
     b.set_overlap(False)
     _assert_same_result(*a(img), *b(img))
 
@@ -228,7 +237,7 @@ def test_next_batch_hint_is_result_neutral(gpu, oracle):
     frames = [synth.make_frame(t, cols=cols, rows=rows) for t in range(6)]
     o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
     refs = [o.extract(f) for f in frames]
-    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B, hooks=True)
     cap = g.capacity
     bufs = [DeviceBuffer(B * rows * cols).upload(np.stack(frames[2 * i:2 * i + 2])) for i in range(3)]
     d_k = DeviceBuffer(B * cap * 28); d_d = DeviceBuffer(B * cap * 32); d_n = DeviceBuffer(B * 4)
@@ -344,8 +353,8 @@ def test_scheduling_hooks_leave_results_unchanged(gpu):
         ref.append((k.download(np.uint8, B * cap * 28), d.download(np.uint8, B * cap * 32), n.download(np.int32, B)))
     m0 = BFMatcher()
     ridx = _lib.DeviceBuffer(B * cap * 4); rdist = _lib.DeviceBuffer(B * cap * 4)
-    # pipelined: outputs by event, match of batch b - 1 on its own stream behind batch b's FAST
-    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    # pipelined: outputs by event, match of batch b - 1 on its own stream behind batch b's FAST (the hooks: test library)
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B, hooks=True)
     mstream = _lib.stream_create(0)
     mat = BFMatcher(stream=mstream)
     ev_out = [_lib.event_create(0) for _ in range(NBATCH)]
@@ -407,7 +416,7 @@ def test_opt_in_kernel_variants_are_bit_identical(gpu, oracle, env, rows, cols, 
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        g, o = _pair(oracle, nf, nl, max_batch=2)
+        g, o = _pair(oracle, nf, nl, max_batch=2, hooks=True)
     finally:
         for k, v in old.items():
             if v is None:
@@ -448,7 +457,7 @@ def test_deferred_stage_held_back_two_steps(gpu):
         k, d, n = mk()
         plain.extract_batch_device(d_img[b].ptr, B, rows, cols, cols, rows * cols, k.ptr, d.ptr, cap, n.ptr); plain.synchronize()
         ref.append((k.download(np.uint8, B * cap * 28), d.download(np.uint8, B * cap * 32), n.download(np.int32, B)))
-    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B)
+    g = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=B, hooks=True)
     side = _lib.stream_create(0)
     ev_out = [_lib.event_create(0) for _ in range(NBATCH)]
     ev_slow = _lib.event_create(0)

@@ -116,13 +116,13 @@ def test_level_chain_as_graph_launch(gpu, oracle, monkeypatch, B, rows, cols, nf
     if B > 12:
         monkeypatch.setenv("DVS_CHAIN_GRAPH", "1")
     graphs = []
-    _run_shape(oracle, B, rows, cols, nf, 4, 22, lanes=1, quadtree_async=qa, probe=lambda pipe: graphs.append(
-        _lib_mod().lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
+    _run_shape(oracle, B, rows, cols, nf, 4, 22, lanes=1, quadtree_async=qa, hooks=True, probe=lambda pipe: graphs.append(
+        _lib_mod().test_lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
     assert graphs[0] >= 8, graphs                                      # 3 resident batches x 2 or 3 pyramids: every set seen twice by step 13
     monkeypatch.setenv("DVS_CHAIN_GRAPH", "0")
     graphs.clear()
-    _run_shape(oracle, B, rows, cols, nf, 4, 5, lanes=1, quadtree_async=qa, probe=lambda pipe: graphs.append(
-        _lib_mod().lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
+    _run_shape(oracle, B, rows, cols, nf, 4, 5, lanes=1, quadtree_async=qa, hooks=True, probe=lambda pipe: graphs.append(
+        _lib_mod().test_lib().dvs_orb_chain_graph_launches(pipe.orb._h)))
     assert graphs == [0]
 
 
@@ -145,7 +145,7 @@ def test_level_chain_graph_cache_stays_bounded(gpu, oracle):
     B, rows, cols, nf, NB, steps = 7, 240, 320, 300, 17, 150
     frames = [np.stack([synth.make_frame(3 * g + i, cols, rows, seed=5 + g) for i in range(B)]) for g in range(NB)]
     d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
-    pipe = StreamingPipeline(B, rows, cols, nf, nsets=4, pipelined=True)
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=4, pipelined=True, hooks=True)
     assert pipe.quadtree_async
     # 45 steps over 5 blocks (20 argument sets: graphs from the second round on), then all 17 (the 49th set drops the cache; with 68 sets
     # in rotation none comes back before the next drop: plain launches from there on)
@@ -153,7 +153,7 @@ def test_level_chain_graph_cache_stays_bounded(gpu, oracle):
     for i in range(steps):
         pipe.step(d_img[order[i]].ptr, d_img[order[i + 1]].ptr if i + 1 < steps else 0)
     pipe.flush(); pipe.synchronize()
-    assert 15 <= _lib.lib().dvs_orb_chain_graph_launches(pipe.orb._h) <= 45
+    assert 15 <= _lib.test_lib().dvs_orb_chain_graph_launches(pipe.orb._h) <= 45
     o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
     for i in range(steps - 3, steps):
         n, k, d = pipe.outputs(i)
@@ -167,7 +167,7 @@ def _lib_mod():
     return _lib
 
 
-def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=0, probe=None):
+def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=0, probe=None, hooks=False):
     from dvslam_amd import _lib
     from dvslam_amd.pipeline import StreamingPipeline
     NB = 3
@@ -175,7 +175,7 @@ def _run_shape(oracle, B, rows, cols, nf, nsets, steps, lanes=0, quadtree_async=
     o = oracle.OracleORB(nf, 1.2, 8, 20, 7)
     ref = [[o.extract(f) for f in batch] for batch in frames]
     d_img = [_lib.DeviceBuffer(b.nbytes).upload(b) for b in frames]
-    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True, lanes=lanes, quadtree_async=quadtree_async)
+    pipe = StreamingPipeline(B, rows, cols, nf, nsets=nsets, pipelined=True, lanes=lanes, quadtree_async=quadtree_async, hooks=hooks)
     assert quadtree_async == 0 or pipe.quadtree_async == (quadtree_async == 1)
     used, nsets = pipe.lanes, pipe.nsets
     for i in range(steps):

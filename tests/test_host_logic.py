@@ -25,6 +25,52 @@ def test_exports_every_declared_symbol(hiplib):
     assert len(tnames) == 10
     assert not [n for n in tnames if hasattr(hiplib, n)], "the product library must not export test hooks"
     assert not [n for n in tnames if not hasattr(_hooks(), n)]
+    # round 5: the extractor's scheduling / introspection hooks and the handles inside a pipeline are declared in the
+    # test header too — internal to the product library (hidden visibility: csrc/pipeline.hip composes the step from them), exported by
+    # the test library, which also exports the whole product ABI
+    hooks = sorted(set(re.findall(r"\b(dvs_(?:orb|matcher|pipeline)_[a-z0-9_]+)\s*\(", thdr)))
+    assert len(hooks) == 20 and "dvs_orb_set_after_fast_event" in hooks and "dvs_pipeline_extractor" in hooks
+    assert not [n for n in hooks if hasattr(hiplib, n)], "scheduling hooks must stay internal to the product library"
+    assert not [n for n in hooks + names if not hasattr(_hooks(), n)]
+    assert not set(hooks) & set(names)
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "dynamic-visual-slam_amd", "lib", "libdvslam_hip.so")],
+                              capture_output=True, text=True, check=True).stdout
+    extra = sorted(set(re.findall(r" T (dvs_[a-z0-9_]+)", exported)) - set(names))
+    assert not extra, f"exported by the product library but not declared in include/dvslam_hip.h: {extra}"
+
+
+def test_environment_switches_fail_loudly(hiplib, monkeypatch):
+    """the one table of DVS_* switches (csrc/util.hip): a name the library does not read, or a value outside the switch's set, is
+    DVS_ERR_ARG at the first handle creation — with or without a GPU — instead of a silent default"""
+    import ctypes as C
+    from dvslam_amd import _lib
+    h = C.c_void_p()
+
+    def create():
+        code = hiplib.dvs_matcher_create(0, C.byref(h))
+        if code == 0:
+            hiplib.dvs_matcher_destroy(h)
+        return code, hiplib.dvs_last_error().decode()
+    monkeypatch.setenv("DVS_MATCH_MFMA", "0")
+    assert create()[0] in (0, -5)                       # a known switch with an allowed value: fine (no device here: -5)
+    monkeypatch.setenv("DVS_MATCH_MFMA", "2")
+    code, msg = create()
+    assert code == -6 and "DVS_MATCH_MFMA=2" in msg and "allowed: 0, 1" in msg
+    monkeypatch.setenv("DVS_MATCH_MFMA", "off")
+    assert create()[0] == -6
+    monkeypatch.delenv("DVS_MATCH_MFMA")
+    monkeypatch.setenv("DVS_MTACH_LDS", "0")            # a typo
+    code, msg = create()
+    assert code == -6 and "unknown environment switch DVS_MTACH_LDS" in msg
+    monkeypatch.delenv("DVS_MTACH_LDS")
+    monkeypatch.setenv("DVS_OCT_T", "384")
+    p = _lib.OrbParams(500, 1.2, 8, 20, 7, (C.c_int32 * 7)(*([0] * 7)), 1)
+    assert hiplib.dvs_orb_create(C.byref(p), 0, C.byref(h)) == -6 and "allowed: 0, 256, 512" in hiplib.dvs_last_error().decode()
+    monkeypatch.delenv("DVS_OCT_T")
+    assert create()[0] in (0, -5)
+    monkeypatch.setenv("DVSLAM_HIP_SO_NOTE", "x")       # not a DVS_ name: none of the library's business
+    assert create()[0] in (0, -5)
 
 
 def test_no_gpu_means_error_not_fallback(hiplib):

@@ -10,7 +10,7 @@ from dvslam_amd import synth, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 imgs = np.stack([synth.make_frame(i, 1280, 720) for i in range(B)])
 d = _lib.DeviceBuffer(imgs.nbytes).upload(imgs)
-g = dvslam_amd.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=B)
+g = dvslam_amd.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=B, hooks=True)   # (scheduling hooks: the test library)
 cap = g.capacity
 k, de, n = _lib.DeviceBuffer(B * cap * 28), _lib.DeviceBuffer(B * cap * 32), _lib.DeviceBuffer(4 * B)
 g.set_overlap(False)

@@ -6,7 +6,7 @@ from dvslam_amd import synth, _lib
 img = synth.make_frame(0, 1280, 720)
 d = _lib.DeviceBuffer(img.nbytes).upload(img)
 for nl in (2, 3, 4, 6, 8):
-    g = dvslam_amd.ORBextractor(2000, 1.2, nl, 20, 7, max_batch=1)
+    g = dvslam_amd.ORBextractor(2000, 1.2, nl, 20, 7, max_batch=1, hooks=True)   # (scheduling hooks: the test library)
     cap = g.capacity
     k, de, n = _lib.DeviceBuffer(cap*28), _lib.DeviceBuffer(cap*32), _lib.DeviceBuffer(4)
     g.set_overlap(False)
