@@ -230,39 +230,47 @@ static inline void launch_match_few(hipStream_t st, dim3 grid, const u64* q, con
 }
 
 // =============================================================================================================================
-// Matrix-core match for batches of large jobs (rebuilt in round 5).  north_star says "no MFMA: none of this is a dense
-// contraction" — the match is one once the bits are bytes: Hamming distance as an exact integer contraction on
-// v_mfma_i32_32x32x32_i8 (int32 accumulation) replaces 16 M (v_xor, v_bcnt) pairs per 2000 x 2000 job on the vector pipe, which every
-// other kernel of the path saturates while the matrix cores sit idle.
-//   dist(q, t) = |q| + |t| - 2 |q AND t|.   Train bit -> byte 0 / 2, query bit -> byte 0 / 64: the eight data k-steps give
-//   128 |q AND t|; a ninth step adds, per train row, -64 |t| (each wavefront the count of the bits it expanded, in a slot of its own),
-//   63 - code(row) — code = the row's place among the 64 rows a lane's accumulators hold per 128-row chunk, so that ONE signed max over
-//   the accumulator registers picks the smallest distance and, among equals, the lowest row (cv::BFMatcher's tie-break) — and -8192 for
-//   rows past the set's count:   key = 64 (2 |q AND t| - |t|) + 63 - code,   dist = |q| - (key >> 6).
-// Both operands are built IN the kernel straight from the 32-byte descriptor rows (rounds 2-4 wrote +8 / -8 byte images of every set to
-// HBM with a second kernel — 41.6 MB written + 76 MB read per 64 jobs for 9.2 MB of descriptors — and streamed them through 72 KB of
-// LDS per workgroup, which beside FAST cost the 64-frame step 57 us: EXPERIMENTS.md, round 5):
-//   * contraction order: lane (h, r) of an operand fragment supplies 16 k-values of row r; which of the 256 bits they are is free as
-//     long as both operands agree, so half h takes bytes [16 h, 16 h + 16) of the row and k-step j the bits [16 (j & 1), +16) of its
-//     word j >> 1
-//   * the nibble-to-bytes spread is one multiply and one mask per four bytes: nibble x (1 + 2^7 + 2^14 + 2^21) V puts bit i at byte i
-//     (the terms never overlap)
-//   * the train fragments are SHARED by the four wavefronts of a workgroup through 18 KB of LDS: wavefront w expands k-steps 2 w and
-//     2 w + 1 of a tile of 32 rows (word w of every row half: together they read each descriptor byte once) — 24 vector instructions
-//     per wavefront and tile; two 9-KB tile buffers, one barrier per tile; every wavefront holds the 9 query fragments of NQ tiles
-//     in registers.  Rows past the count repeat row nt - 1 (clamped loads): a repeat can never beat its original.
+// Matrix-core match for batches of large jobs (rebuilt twice in round 5).  north_star says "no MFMA: none of this is
+// a dense contraction" — the match is one once the bits are matrix elements: a 2000 x 256 . 256 x 2000 product with exact accumulation
+// replaces 16 M (v_xor, v_bcnt) pairs per job on the vector pipe, which every other kernel of the path saturates while the matrix cores
+// sit idle.  DVS_MATCH_MFMA=0 selects the popcount kernels.
+//   dist(q, t) = |q| + |t| - 2 |q AND t|,    key = 128 |q AND t| - 64 |t| + 63 - code(row)  [- 32768 for rows past the count],
+// code = the row's place among the 64 rows a lane's accumulators hold per 128-row chunk: ONE maximum over the accumulator registers picks
+// the smallest distance and, among equals, the lowest row (cv::BFMatcher's tie-break); dist = |q| - (key >> 6).  Rows past the count
+// repeat row nt - 1 (clamped loads): a repeat can never beat its original.
+// Rounds 2-4: int8 MFMA on +8 / -8 byte images that a second kernel wrote to HBM (41.6 MB written + 76 MB read per 64 jobs for 9.2 MB of
+// descriptors), streamed through 72 KB of LDS per workgroup — 57 us (12 %) of the 64-frame step beside FAST.  Round 5, first step: int8
+// operands built in the kernel, 18 KB of LDS, one launch (-5.3 % step).  Second step, this kernel: the matrix pipe's TIME shows in the
+// step — doubling the int8 kernel's matrix work (2.3 M instructions of 17.4 ns = 61 us of every SIMD's matrix pipe per 64 jobs)
+// lengthened the step by 37 us (profiles/r05_mfma_exposure_ab.log) — and v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 (e2m1) operands
+// contracts 64 k-values in the time the int8 form takes for 32 (tools/probe/mfma_f8_probe.hip: 16.4 ns; semantics, operand and result
+// layouts checked there against a host sum).  A descriptor BIT is one FP4 nibble: set -> 0x2 (1.0), clear -> 0; the query operand's
+// block scale is 2^7, so four k-steps give 128 |q AND t| as exact f32 integers (everything stays below 2^24).  The per-row terms of the
+// key no longer take a k-step of their own: they are the C operand — the wavefront whose turn it is computes the tile's 32 row constants
+// (it holds the 16 bytes of every row half: popcount + one cross-half swap), all four read them as the accumulators' initial value.
+// Contraction order: lane (h, r) of a fragment supplies 32 k-values of row r; which bits they are is free as long as both operands
+// agree, so half h takes bytes [16 h, 16 h + 16) of the row and k-step j its word j.
+// Per 32-row tile and wavefront: ONE ds_write_b128 (word w of every row half -> 32 nibbles through a 256-entry LUT in LDS: 8 bits ->
+// 8 nibbles), 4 + 4 ds_read_b128, 4 NQ matrix instructions of 16.4 ns (int8: 9 NQ of 17.4), 8 NQ v_max3_f32; two 4.1-KB tile buffers,
+// one barrier per tile.  The query fragments are 4 registers per k-step, so NQ = 4 tiles fit a wavefront without spills (248 VGPRs): the
+// kernel of >= 32 jobs; fewer jobs take NQ = 2 (twice the workgroups: at 8..31 jobs the machine is not full and latency counts).
+// Same-box (64-frame step): 0.4673 ms (rounds 2-4's kernels) -> 0.4426 (int8 in-kernel) -> 0.436 (this).  HBM: 9.2 MB per 64 jobs = the
+// algorithmic bytes.  Bit-exact against the oracle: tests/test_gpu_match.py, tests/test_gpu_pipeline.py.
 // =============================================================================================================================
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-template <int NQ, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void k_match_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nqArr, int qStrideRows,
-                                                        const uint8_t* __restrict__ t, const int* __restrict__ ntArr, int tStrideRows,
-                                                        const uint8_t* __restrict__ t0, const int* __restrict__ nt0,
-                                                        int* __restrict__ outIdx, int* __restrict__ outDist) {
-  __shared__ __attribute__((aligned(16))) uint8_t tl[2][9 * 1024];
+template <int NQ>
+__global__ __launch_bounds__(256) void k_match_fp4(const uint8_t* __restrict__ q, const int* __restrict__ nqArr, int qStrideRows,
+                                                   const uint8_t* __restrict__ t, const int* __restrict__ ntArr, int tStrideRows,
+                                                   const uint8_t* __restrict__ t0, const int* __restrict__ nt0,
+                                                   int* __restrict__ outIdx, int* __restrict__ outDist) {
+  constexpr int kTile = 4 * 1024 + 128;   // four 1-KB fragments (k-steps) + the 32 row constants (f32) of a 32-row tile
+  __shared__ uint32_t lut[256];           // 8 descriptor bits -> 8 FP4 nibbles of 0 / 1.0
+  __shared__ __attribute__((aligned(16))) uint8_t tl[2][kTile];
   int pair = blockIdx.y, qt = blockIdx.x;
-  if ((gridDim.y & 7) == 0) {
+  if ((gridDim.y & 7) == 0) {   // pair p entirely on XCD p % 8: its workgroups stream the same train set through ONE L2
     const int lid = blockIdx.x + gridDim.x * blockIdx.y, xcd = lid & 7, k = lid >> 3;
     pair = xcd + 8 * (k / (int)gridDim.x);
     qt = k % (int)gridDim.x;
@@ -270,102 +278,105 @@ __global__ __launch_bounds__(64 * NW) void k_match_mfma(const uint8_t* __restric
   const bool first = pair == 0 && t0 != nullptr;
   const int nq = min(max(nqArr[pair], 0), qStrideRows);
   const int nt = min(max(first ? *nt0 : ntArr[pair], 0), tStrideRows);
-  if (qt * 32 * NW * NQ >= nq) return;   // (uniform over the workgroup: no barrier is skipped by a part of it)
+  if (qt * 128 * NQ >= nq) return;   // (uniform over the workgroup: no barrier is skipped by a part of it)
   const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint8_t* qb = q + (size_t)pair * qStrideRows * 32 + 16 * h;
-  constexpr int NS = 8 / NW;   // k-steps a wavefront expands per tile: 2 (a word of the row half) or 1 (16 bits of it)
-  const uint8_t* tb = (first ? t0 : t + (ptrdiff_t)pair * tStrideRows * 32) + 16 * h + 2 * NS * w;
+  {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= ((threadIdx.x >> i) & 1u) ? 2u << (4 * i) : 0u;
+    lut[threadIdx.x] = o;
+  }
+  __syncthreads();
+  auto nib = [&](uint32_t x) -> v4i {   // 32 bits -> 32 nibbles
+    return v4i{(int)lut[x & 255u], (int)lut[(x >> 8) & 255u], (int)lut[(x >> 16) & 255u], (int)lut[x >> 24]};
+  };
   auto word = [](const uint4& v, int i) -> uint32_t { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); };
-  v4i bq[NQ][9];
+  const uint8_t* qb = q + (size_t)pair * qStrideRows * 32 + 16 * h;
+  const uint8_t* tb = (first ? t0 : t + (ptrdiff_t)pair * tStrideRows * 32) + 16 * h;
+  v4i bq[NQ][4];
   int popq[NQ];
-  const int qtile0 = (qt * NW + w) * NQ;
+  const int qtile0 = (qt * 4 + w) * NQ;
 #pragma unroll
   for (int u = 0; u < NQ; u++) {
-    const int row = min((qtile0 + u) * 32 + r, nq - 1);
+    const int row = min((qtile0 + u) * 32 + r, nq - 1);   // rows past the count repeat the last one (never written out)
     const uint4 v = *reinterpret_cast<const uint4*>(qb + (size_t)row * 32);
     const int ph = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
     popq[u] = ph + __shfl_xor(ph, 32);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t x = word(v, j >> 1) >> (16 * (j & 1));
-      bq[u][j] = v4i{(int)((((x >> 0) & 15u) * 0x08102040u) & 0x40404040u), (int)((((x >> 4) & 15u) * 0x08102040u) & 0x40404040u),
-                     (int)((((x >> 8) & 15u) * 0x08102040u) & 0x40404040u), (int)((((x >> 12) & 15u) * 0x08102040u) & 0x40404040u)};
-    }
-    // slot 0: x 1 (code); slots 1..NW: x 64 (the wavefronts' counts); slot NW + 1: x 64 (past-the-count)
-    bq[u][8] = NW == 4 ? v4i{0x40404001, 0x00004040, 0, 0} : v4i{0x40404001, 0x40404040, 0x00004040, 0};
+    for (int j = 0; j < 4; j++) bq[u][j] = nib(word(v, j));
   }
   const int nchunks = (nt + 127) >> 7, ntiles = nchunks * 4;
   int bestc[NQ], besti[NQ];
 #pragma unroll
   for (int u = 0; u < NQ; u++) { bestc[u] = INT_MIN; besti[u] = -1; }
-  const int lanePart = (r >> 3) * 4 + (r & 3);
-  // the ninth piece's bytes 6..15 stay zero; bytes 0..5 are rewritten for every tile
-  if (w < 2) *reinterpret_cast<uint4*>(&tl[w][8 * 1024 + lane * 16]) = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
-  // expansion of this wavefront's two k-steps of a tile + its bytes of the ninth piece
-  auto expand = [&](int tile, uint32_t x, uint8_t* buf) {
-    constexpr uint32_t M = 0x00408102u, K = 0x02020202u;
-    const v4i a0 = v4i{(int)(__umul24(__builtin_amdgcn_ubfe(x, 0, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 4, 4), M) & K),
-                       (int)(__umul24(__builtin_amdgcn_ubfe(x, 8, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 12, 4), M) & K)};
-    *reinterpret_cast<v4i*>(buf + (NS * w) * 1024 + lane * 16) = a0;
-    if (NS == 2) {
-      const v4i a1 = v4i{(int)(__umul24(__builtin_amdgcn_ubfe(x, 16, 4), M) & K), (int)(__umul24(__builtin_amdgcn_ubfe(x, 20, 4), M) & K),
-                         (int)(__umul24(__builtin_amdgcn_ubfe(x, 24, 4), M) & K), (int)(__umul24(x >> 28, M) & K)};
-      *reinterpret_cast<v4i*>(buf + (2 * w + 1) * 1024 + lane * 16) = a1;
+  const int lanePart = (r >> 3) * 4 + (r & 3);   // the row's place among the 16 accumulator registers of the lane that holds it
+  // this wavefront's k-step of a tile (word w of every row half) and, for the wavefront whose turn it is, the tile's row constants
+  auto expand = [&](int tile, const uint4& v, uint8_t* buf) {
+    *reinterpret_cast<v4i*>(buf + w * 1024 + lane * 16) = nib(w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w)));
+    if ((tile & 3) == w) {
+      const int ph = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      const int pop = ph + __shfl_xor(ph, 32);
+      const int code = (tile & 3) * 16 + lanePart;
+      const int c = 63 - code - 64 * pop - (tile * 32 + r < nt ? 0 : 32768);
+      // row r lives in the accumulators of the lanes of half (r >> 2) & 1, register lanePart
+      if (h == 0) *reinterpret_cast<float*>(buf + 4096 + (((r >> 2) & 1) * 16 + lanePart) * 4) = (float)c;
     }
-    const uint32_t np = (uint32_t)(-__popc(x)) & 0xFFu;
-    uint8_t* e = buf + 8 * 1024 + lane * 16;
-    if (w == 0) *reinterpret_cast<uint16_t*>(e) = (uint16_t)((h == 0 ? (uint32_t)(63 - ((tile & 3) * 16 + lanePart)) : 0u) | np << 8);
-    else if (w == NW - 1) *reinterpret_cast<uint16_t*>(e + NW) = (uint16_t)(np | (tile * 32 + r < nt ? 0u : 0x8000u));
-    else e[1 + w] = (uint8_t)np;
   };
-  auto load = [&](int tile) -> uint32_t {
-    const uint8_t* a = tb + (size_t)min(tile * 32 + r, nt - 1) * 32;
-    return NS == 2 ? *reinterpret_cast<const uint32_t*>(a) : (uint32_t)*reinterpret_cast<const uint16_t*>(a);
-  };
-  uint32_t wnext = 0;
+  auto load = [&](int tile) -> uint4 { return *reinterpret_cast<const uint4*>(tb + (size_t)min(tile * 32 + r, nt - 1) * 32); };
+  uint4 wnext = make_uint4(0u, 0u, 0u, 0u);
   if (ntiles > 0) {
     expand(0, load(0), tl[0]);
     wnext = load(1);
   }
   __syncthreads();
   for (int c = 0; c < nchunks; c++) {
-    int key[NQ];
+    float key[NQ];
 #pragma unroll
-    for (int u = 0; u < NQ; u++) key[u] = INT_MIN;
+    for (int u = 0; u < NQ; u++) key[u] = -3.0e38f;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
       const int tile = c * 4 + m;
-      const uint32_t wcur = wnext;
+      const uint4 wcur = wnext;
       wnext = load(tile + 2);                                     // two tiles ahead (clamped: always a valid address)
       if (tile + 1 < ntiles) expand(tile + 1, wcur, tl[(tile + 1) & 1]);
-      const uint8_t* buf = tl[tile & 1] + lane * 16;
-      v16i acc[NQ];
+      const uint8_t* buf = tl[tile & 1];
+      v16f rc;
 #pragma unroll
-      for (int u = 0; u < NQ; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 4; i++) {
+        const float4 f = *reinterpret_cast<const float4*>(buf + 4096 + h * 64 + i * 16);
+        rc[4 * i] = f.x; rc[4 * i + 1] = f.y; rc[4 * i + 2] = f.z; rc[4 * i + 3] = f.w;
+      }
+      v16f acc[NQ];
 #pragma unroll
-      for (int s9 = 0; s9 < 9; s9++) {
-        const v4i a = *reinterpret_cast<const v4i*>(buf + s9 * 1024);
+      for (int u = 0; u < NQ; u++) acc[u] = rc;
 #pragma unroll
-        for (int u = 0; u < NQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s9], acc[u], 0, 0, 0);
+      for (int j = 0; j < 4; j++) {
+        const v4i a4 = *reinterpret_cast<const v4i*>(buf + j * 1024 + lane * 16);
+        const v8i a = v8i{a4.x, a4.y, a4.z, a4.w, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+          const v8i b = v8i{bq[u][j].x, bq[u][j].y, bq[u][j].z, bq[u][j].w, 0, 0, 0, 0};
+          acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[u], 4, 4, 0, 0x7f7f7f7f, 0, (int)0x86868686u);   // FP4 x FP4, query block scale 2^7
+        }
       }
 #pragma unroll
       for (int u = 0; u < NQ; u++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) key[u] = max(key[u], acc[u][i]);
+        for (int i = 0; i < 16; i++) key[u] = fmaxf(key[u], acc[u][i]);
       __syncthreads();   // tile + 1 is complete for everyone; everyone has read tile's buffer, which tile + 2 overwrites
     }
 #pragma unroll
     for (int u = 0; u < NQ; u++) {
-      const int cval = key[u] >> 6, code = 63 - (key[u] & 63);
+      const int k = (int)key[u];   // exact: every term is an integer below 2^24
+      const int cval = k >> 6, code = 63 - (k & 63);
       const int row = c * 128 + (code >> 4) * 32 + ((code >> 2) & 3) * 8 + h * 4 + (code & 3);
-      if (cval > bestc[u]) { bestc[u] = cval; besti[u] = row; }
+      if (cval > bestc[u]) { bestc[u] = cval; besti[u] = row; }   // later chunks hold higher rows: strict '>' keeps the lowest on ties
     }
   }
 #pragma unroll
   for (int u = 0; u < NQ; u++) {
-    const int oc = __shfl_xor(bestc[u], 32), oi = __shfl_xor(besti[u], 32);
+    const int oc = __shfl_xor(bestc[u], 32), oi = __shfl_xor(besti[u], 32);   // the two lane halves hold interleaved rows of the same query
     int bc = bestc[u], bi = besti[u];
     if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
     const int qi = (qtile0 + u) * 32 + r;
@@ -447,6 +458,16 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
 }  // namespace dvs
 
 using namespace dvs;
+
+// NQ = 4 query tiles per wavefront from 32 jobs on (a full machine: 64 jobs x 4 workgroups of 512 queries), NQ = 2 below (twice the
+// workgroups: 8 frames per step 82 -> 89 k frames/s against NQ = 4, 16 frames 116 -> 119 k; NQ = 1 gains nothing more)
+static inline void launch_match_fp4(hipStream_t st, int npairs, const uint8_t* q, const int* nq, int qStrideRows, const uint8_t* t, const int* nt, int tStrideRows,
+                                    const uint8_t* t0, const int* nt0, int* idx, int* dist) {
+  if (npairs >= 32)
+    hipLaunchKernelGGL(dvs::k_match_fp4<4>, dim3((qStrideRows + 511) / 512, npairs), dim3(256), 0, st, q, nq, qStrideRows, t, nt, tStrideRows, t0, nt0, idx, dist);
+  else
+    hipLaunchKernelGGL(dvs::k_match_fp4<2>, dim3((qStrideRows + 255) / 256, npairs), dim3(256), 0, st, q, nq, qStrideRows, t, nt, tStrideRows, t0, nt0, idx, dist);
+}
 
 struct dvs_matcher {
   int device = 0;
@@ -606,8 +627,7 @@ dvs_status dvs_match_hamming_batch_device(dvs_matcher* m, const uint8_t* d_q, co
   }
   // many large jobs: the contraction runs on the matrix cores, operands built in the kernel (16-byte row loads: other bases take k_match)
   if (m->use_mfma && t_stride_rows > 0 && (((uintptr_t)d_q | (uintptr_t)d_t) & 15) == 0) {
-    hipLaunchKernelGGL(k_match_mfma<2>, dim3((q_stride_rows + 255) / 256, npairs), dim3(256), 0, m->stream, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows,
-                       (const uint8_t*)nullptr, (const int*)nullptr, d_idx, d_dist);
+    launch_match_fp4(m->stream, npairs, d_q, d_nq, q_stride_rows, d_t, d_nt, t_stride_rows, nullptr, nullptr, d_idx, d_dist);
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }
@@ -641,8 +661,7 @@ dvs_status dvs_match_hamming_sequence_device(dvs_matcher* m, const uint8_t* d_de
   constexpr long long kMfmaMinRows = 14000;
   if (m->use_mfma && (long long)nframes * stride_rows > kMfmaMinRows && (((uintptr_t)d_desc | (uintptr_t)d_prev_desc) & 15) == 0) {
     // job p = frame p against frame p - 1 (job 0: the predecessor block): train base shifted back by one frame, never dereferenced for job 0
-    hipLaunchKernelGGL(k_match_mfma<2>, dim3((stride_rows + 255) / 256, nframes), dim3(256), 0, m->stream, d_desc, d_n, stride_rows,
-                       d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, d_idx, d_dist);
+    launch_match_fp4(m->stream, nframes, d_desc, d_n, stride_rows, d_desc - (size_t)stride_rows * 32, d_n - 1, stride_rows, d_prev_desc, d_prev_n, d_idx, d_dist);
     DVS_HIP(hipGetLastError());
     return DVS_OK;
   }

@@ -141,7 +141,7 @@ def _tie_heavy(n, seed, distinct=37):
 
 
 def test_batch_device_matrix_core(gpu, oracle):
-    """large batches run the int8 MFMA kernel (k_match_mfma): ragged counts incl. 0 / 1 / a partial last chunk / the full
+    """large batches run the matrix-core kernel (k_match_fp4: NQ = 2 below 32 jobs): ragged counts incl. 0 / 1 / a partial last chunk / the full
     stride, tie-heavy sets (lowest train index must win), every job against the oracle bit for bit"""
     from dvslam_amd import BFMatcher
     from dvslam_amd._lib import DeviceBuffer
@@ -216,6 +216,30 @@ def test_matrix_core_extreme_popcounts_and_unaligned_bases(gpu, oracle):
             i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
             assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (off, p)
     assert (idx[3] == 0).all() and (d[3] == 0).all() and (d[4] == 0).all()
+
+
+def test_matrix_core_full_machine_shape(gpu, oracle):
+    """from 32 jobs on the matrix-core kernel takes four query tiles per wavefront (k_match_fp4<4>): 40 ragged jobs — counts around the
+    512-query workgroup, the 128-row chunk and the 32-row tile boundaries, tie-heavy sets — against the oracle, and the XCD re-deal of
+    the job index (40 = a multiple of 8)"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    P, S = 40, 2024
+    rng = np.random.Generator(np.random.PCG64(91))
+    nq = rng.integers(1, S + 1, size=P).astype(np.int32); nt = rng.integers(1, S + 1, size=P).astype(np.int32)
+    nq[:8] = [2024, 513, 512, 511, 129, 128, 33, 1]; nt[:8] = [2024, 1, 31, 32, 33, 127, 128, 129]
+    Q = np.stack([_tie_heavy(S, 900 + p) if p % 3 == 0 else synth.make_descriptors(S, 900 + p) for p in range(P)])
+    T = np.stack([_tie_heavy(S, 900 + p) if p % 3 == 0 else synth.make_descriptors(S, 1900 + p) for p in range(P)])
+    dq = DeviceBuffer(Q.nbytes).upload(Q); dt = DeviceBuffer(T.nbytes).upload(T)
+    dnq = DeviceBuffer(P * 4).upload(nq); dnt = DeviceBuffer(P * 4).upload(nt)
+    di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
+    m.match_batch_device(dq.ptr, dnq.ptr, S, dt.ptr, dnt.ptr, S, P, di.ptr, dd.ptr)
+    m.synchronize()
+    idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
+    for p in range(P):
+        i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
+        assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), p
 
 
 def test_sequence_device_matrix_core(gpu, oracle):
