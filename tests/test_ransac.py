@@ -498,6 +498,30 @@ def test_gpu_pnp_cv(gpu, oracle, n, seed, outliers):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,outliers", [(600, 0, 0.0), (600, 1, 0.3), (120, 3, 0.2), (12, 5, 0.0)])
+def test_gpu_pnp_cv_against_real_opencv_when_present(gpu, n, seed, outliers):
+    """THE PIN THIS REPO LACKS: where `cv2` is importable, dvs_solve_pnp_ransac_cv is compared with cv2.solvePnPRansac itself on the
+    same correspondences — same call as frontend.cpp:911-921 (100 iterations, 4 px, 0.99, no distortion).  The image this repo is built and
+    judged in has no OpenCV (parity unpinned), so this test SKIPS there; on a machine with OpenCV 4.x it states the bar:
+    the same inlier set up to the documented deviations (Jacobi eigen-decompositions where OpenCV runs its SVD: IoU >= 0.98) and the refitted
+    pose to 1e-4."""
+    cv2 = pytest.importorskip("cv2")
+    from dvslam_amd import FrontendGlue
+    X, uv, K4, sc = _pnp_scene(n, seed, outliers)
+    K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], np.float64)
+    ok2, r2, t2, inl2 = cv2.solvePnPRansac(X.astype(np.float32), uv.astype(np.float32), K, None, iterationsCount=100, reprojectionError=4.0, confidence=0.99)
+    g = FrontendGlue()
+    ok, r, t, inl, its = g.solve_pnp_ransac_cv(X, uv, K4, 100, 4.0, 0.99)
+    g.close()
+    assert bool(ok) == bool(ok2)
+    if ok2:
+        a = np.zeros(len(X), bool); a[inl] = True
+        b = np.zeros(len(X), bool); b[np.asarray(inl2).reshape(-1)] = True
+        assert rs.iou(a, b) >= 0.98, (int(a.sum()), int(b.sum()))
+        assert np.abs(r - np.asarray(r2).reshape(3)).max() < 1e-4 and np.abs(t - np.asarray(t2).reshape(3)).max() < 1e-4
+
+
+@pytest.mark.gpu
 def test_gpu_pnp_cv_batch_and_refusals(gpu, oracle):
     """many problems in one launch sequence = the single calls bit for bit; fewer than 6 points are refused per problem; an exactly planar
     point set (EPnP's degenerate case, in OpenCV as here) must not fault or hang"""
