@@ -242,6 +242,37 @@ def test_matrix_core_full_machine_shape(gpu, oracle):
         assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), p
 
 
+@pytest.mark.parametrize("P,seed", [(9, 1), (16, 2), (33, 3), (48, 4)])
+def test_matrix_core_randomized_densities(gpu, oracle, P, seed):
+    """both shapes of the matrix-core kernel (NQ = 2 below 32 jobs, NQ = 4 from 32 on) on random jobs: counts anywhere in 1..2024, bit
+    densities from 2 % to 98 % per set (|t| and |q| far from 128: the row constants and the f32 keys over their whole range), train rows
+    that repeat (ties: the lowest index must win)"""
+    from dvslam_amd import BFMatcher
+    from dvslam_amd._lib import DeviceBuffer
+    m = BFMatcher()
+    S = 2024
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    nq = rng.integers(1, S + 1, size=P).astype(np.int32); nt = rng.integers(1, S + 1, size=P).astype(np.int32)
+    Q = np.zeros((P, S, 32), np.uint8); T = np.zeros((P, S, 32), np.uint8)
+    for p in range(P):
+        dq, dt = rng.uniform(0.02, 0.98, size=2)
+        Q[p] = np.packbits(rng.random((S, 256)) < dq, axis=1)
+        T[p] = np.packbits(rng.random((S, 256)) < dt, axis=1)
+        rep = rng.integers(0, max(int(nt[p]), 1), size=S // 4)          # a quarter of the train rows repeat earlier rows
+        T[p, S // 2:S // 2 + len(rep)] = T[p, rep]
+        hit = rng.integers(0, max(int(nt[p]), 1), size=8)               # and a few queries have exact twins
+        Q[p, :8] = T[p, hit]
+    dq_ = DeviceBuffer(Q.nbytes).upload(Q); dt_ = DeviceBuffer(T.nbytes).upload(T)
+    dnq = DeviceBuffer(P * 4).upload(nq); dnt = DeviceBuffer(P * 4).upload(nt)
+    di = DeviceBuffer(P * S * 4); dd = DeviceBuffer(P * S * 4)
+    m.match_batch_device(dq_.ptr, dnq.ptr, S, dt_.ptr, dnt.ptr, S, P, di.ptr, dd.ptr)
+    m.synchronize()
+    idx = di.download(np.int32, P * S).reshape(P, S); d = dd.download(np.int32, P * S).reshape(P, S)
+    for p in range(P):
+        i2, d2 = oracle.match(Q[p, :nq[p]], T[p, :nt[p]])
+        assert (idx[p, :nq[p]] == i2).all() and (d[p, :nq[p]] == d2).all(), (P, p, int(nq[p]), int(nt[p]))
+
+
 def test_sequence_device_matrix_core(gpu, oracle):
     """the bench's shape on the MFMA kernel: frames of up to 2024 descriptors, frame p against p - 1 (every set used in
     both roles), frame 0 against a predecessor elsewhere or against nothing"""
